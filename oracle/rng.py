@@ -1,0 +1,129 @@
+"""Counter-based RNG, alias-method negative sampler and dropout masks (oracle side).
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).
+
+The reference draws its dropout masks from Theano's MRG stream seeded with
+``np.random.randint`` (Keras 2.0 ``K.dropout``; call sites ``model.py:256,346,
+351,357,363,368,372``) -- not reproducible outside Theano -- and has no negative
+sampling at all (full softmax only, ``model.py:257,382-397``).  The build
+therefore defines its own integer-exact generator; this file is its
+specification and the HIP kernels in ``csrc/sampler.hip`` must agree with it
+bit for bit:
+
+    mix64(x):  x = (x ^ x>>30) * 0xBF58476D1CE4E5B9
+               x = (x ^ x>>27) * 0x94D049BB133111EB
+               return x ^ x>>31                      (splitmix64 finaliser)
+    key(seed, stream) = mix64((seed+1) * GOLD  ^  (stream+1) * 0xD1B54A32D192ED03)
+    rand64(seed, stream, ctr) = mix64(key + (ctr+1) * GOLD)      GOLD = 0x9E3779B97F4A7C15
+
+All arithmetic is modulo 2**64.
+"""
+import numpy as np
+
+GOLD = 0x9E3779B97F4A7C15
+M1 = 0xBF58476D1CE4E5B9
+M2 = 0x94D049BB133111EB
+SALT = 0xD1B54A32D192ED03
+MASK = (1 << 64) - 1
+
+# stream ids shared with the product (seq-recommendations_amd/_lib.py)
+STREAM_NEG = 1          # negatives: ctr = step*K + k
+STREAM_DROP_IN = 2      # y_to_z dropout        ctr = element index, step folded into stream
+STREAM_DROP_OUT = 3     # z_to_y dropout
+STREAM_DROP_REC = 4     # z_to_z (recurrent) dropout
+
+
+def _mix_int(x):
+    x &= MASK
+    x = ((x ^ (x >> 30)) * M1) & MASK
+    x = ((x ^ (x >> 27)) * M2) & MASK
+    return x ^ (x >> 31)
+
+
+def key64(seed, stream):
+    return _mix_int((((seed + 1) * GOLD) & MASK) ^ (((stream + 1) * SALT) & MASK))
+
+
+def rand64(seed, stream, ctr):
+    """ctr: integer array -> uint64 array of the same shape."""
+    ctr = np.asarray(ctr, dtype=np.uint64)
+    k = np.uint64(key64(seed, stream))
+    with np.errstate(over="ignore"):
+        x = k + (ctr + np.uint64(1)) * np.uint64(GOLD)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(M1)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(M2)
+        x = x ^ (x >> np.uint64(31))
+    return x
+
+
+def dropout_stream(base_stream, step):
+    """Fold the training-step index into the stream id (one mask set per step)."""
+    return base_stream + 16 * (step + 1)
+
+
+def dropout_mask(seed, stream, n, rate, dtype=np.float32):
+    """Inverted-dropout multipliers for n elements: 0 or 1/(1-rate).
+
+    keep iff (rand64 >> 40) < round((1-rate) * 2**24).
+    """
+    if rate <= 0.0:
+        return np.ones(n, dtype=dtype)
+    keep = 1.0 - rate
+    thr = int(round(keep * (1 << 24)))
+    r = rand64(seed, stream, np.arange(n, dtype=np.uint64)) >> np.uint64(40)
+    m = (r < np.uint64(thr)).astype(dtype)
+    return m * dtype(np.float32(1.0) / np.float32(keep))
+
+
+def build_alias_table(probs):
+    """Vose alias table for a discrete proposal distribution.
+
+    Returns (thresh uint32[V], alias int32[V]): draw bucket j uniformly, keep j
+    iff a fresh 32-bit uniform < thresh[j], else take alias[j].
+    Deterministic (float64, fixed processing order).
+    """
+    p = np.asarray(probs, dtype=np.float64)
+    V = p.shape[0]
+    p = p / p.sum()
+    scaled = p * V
+    alias = np.arange(V, dtype=np.int64)
+    accept = np.ones(V, dtype=np.float64)
+    small = [i for i in range(V) if scaled[i] < 1.0]
+    large = [i for i in range(V) if scaled[i] >= 1.0]
+    scaled = scaled.copy()
+    while small and large:
+        s = small.pop()
+        l = large.pop()
+        accept[s] = scaled[s]
+        alias[s] = l
+        scaled[l] = (scaled[l] + scaled[s]) - 1.0
+        if scaled[l] < 1.0:
+            small.append(l)
+        else:
+            large.append(l)
+    # leftovers keep accept = 1, alias = self
+    thresh = np.minimum(np.floor(accept * 4294967296.0), 4294967295.0).astype(np.uint64).astype(np.uint32)
+    return thresh, alias.astype(np.int32)
+
+
+def alias_draw(r64, thresh, alias):
+    """Map raw 64-bit draws to item ids through the alias table."""
+    r64 = np.asarray(r64, dtype=np.uint64)
+    V = np.uint64(thresh.shape[0])
+    hi = r64 >> np.uint64(32)
+    lo = (r64 & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    with np.errstate(over="ignore"):
+        j = ((hi * V) >> np.uint64(32)).astype(np.int64)
+    keep = lo < thresh[j]
+    return np.where(keep, j, alias[j].astype(np.int64)).astype(np.int32)
+
+
+def sample_negatives(seed, step, K, thresh, alias):
+    ctr = np.uint64(step) * np.uint64(K) + np.arange(K, dtype=np.uint64)
+    return alias_draw(rand64(seed, STREAM_NEG, ctr), thresh, alias)
+
+
+def log_uniform_probs(V):
+    """P(rank r) = log((r+2)/(r+1)) / log(V+1) -- the usual log-uniform (Zipfian) proposal."""
+    r = np.arange(V, dtype=np.float64)
+    return (np.log(r + 2.0) - np.log(r + 1.0)) / np.log(V + 1.0)
