@@ -1,0 +1,162 @@
+/*
+ * seqrec_hip.h  --  C ABI of libseqrec_hip.so (MI355X / gfx950).
+ *
+ * The reference (efikarra/seq-recommendations) has NO native boundary: its hot
+ * path sits behind the Python class surface of model.py (BaseRNNModel,
+ * model.py:170-238) and all arithmetic happens inside Keras 2.0.x / Theano.
+ * This header therefore declares the boundary a maintainer would bind with
+ * ctypes from model.py; each entry point names the Keras
+ * op / reference call site whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'ed, e.g. torch tensor
+ *     data_ptr()) unless its name ends in _host;
+ *   - fp32 everywhere ("dtype": "f32"), row-major, sizes in elements;
+ *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered,
+ *     nothing synchronises, allocates or touches global mutable state;
+ *   - return value: 0 = ok, negative = SEQREC_E_* (bad argument / unsupported
+ *     shape, detected on the host BEFORE anything is launched), positive =
+ *     hipError_t of a failed launch.  No exceptions cross the boundary.
+ *
+ * Ragged session batch layout ("time-major packed", produced by
+ * batching.pack_sessions; replaces the dense pre-padded (N,T,V) one-hot tensors
+ * of preprocessor.py:67-94 + the Masking layer of model.py:246,335-336):
+ *   sessions sorted by number of transitions L_b descending; B_t = #{b: L_b > t};
+ *   step_off[t] = sum_{s<t} B_s (T+1 entries); token p = step_off[t] + b.
+ */
+#ifndef SEQREC_HIP_H
+#define SEQREC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEQREC_ABI_VERSION 1
+
+enum { SEQREC_OK = 0, SEQREC_E_ARG = -1, SEQREC_E_SHAPE = -2, SEQREC_E_UNSUPPORTED = -3 };
+
+/* recurrent cell (Keras layer constructed at model.py:248-254,344-352; GRU = extension) */
+enum { SEQREC_CELL_SIMPLERNN = 0, SEQREC_CELL_LSTM = 1, SEQREC_CELL_GRU = 2 };
+/* activation = z_to_z_activation / z_activation (model.py:243,324); recurrent activation is
+ * always Keras' hard_sigmoid */
+enum { SEQREC_ACT_RELU = 0, SEQREC_ACT_TANH = 1, SEQREC_ACT_LINEAR = 2 };
+
+int seqrec_abi_version(void);
+/* name of the gfx target the code objects were built for ("gfx950") */
+const char* seqrec_build_arch(void);
+
+/* ---- item-embedding lookup: the `onehot . W` product inside Keras' SimpleRNN/LSTM
+ *      (model.py:248-255,345-369) and the Dense embed of NoRecurrenceModel (model.py:276-279).
+ *      out[i,:] (+)= table[ids[i],:] * (row_scale ? row_scale[i] : 1) + (bias ? bias[:] : 0)
+ *      ids[i] < 0 yields a zero row (used for "previous hidden state" of first steps).
+ *      Algorithmic HBM bytes: 8 * width per row (4 read + 4 written). */
+int seqrec_gather_rows(const float* table, const int32_t* ids, float* out, int64_t n, int width,
+                       const float* row_scale, const float* bias, int accumulate, void* stream);
+
+/* ---- dense GEMM on the fp32 MFMA path (exact fp32; v_mfma_f32_32x32x2_f32).
+ *      C[M,N] (+)= opA(A)[M,K] . opB(B)[K,N] (+ bias[N]).  Replaces the BLAS calls Theano makes for
+ *      the cell's x.W / TimeDistributed(Dense) (model.py:257,381-384) and their gradients.
+ *      a_kcontig: A(m,k)=A[m*lda+k] (row-major MxK) else A(m,k)=A[k*lda+m] (stored KxM);
+ *      b_kcontig: B(k,n)=B[n*ldb+k] (stored NxK)     else B(k,n)=B[k*ldb+n] (row-major KxN).
+ *      splitk > 1 needs `workspace` of splitk*M*N floats.  accumulate != 0: C += result. */
+int seqrec_gemm_f32(int a_kcontig, int b_kcontig, int64_t M, int64_t N, int64_t K,
+                    const float* A, int64_t lda, const float* B, int64_t ldb,
+                    float* C, int64_t ldc, const float* bias, int accumulate,
+                    int splitk, float* workspace, void* stream);
+int64_t seqrec_gemm_workspace_floats(int64_t M, int64_t N, int splitk);
+
+/* ---- recurrent scan over the ragged batch (Keras K.rnn under Masking).
+ *      H must be 64, 128, 256 or 512 (callers zero-pad); H_real <= H are the live units.
+ *      XW   [N_tok, G*H]  input projection incl. bias (gate order i,f,c,o | z,r,h)
+ *      U    [H, G*H]      recurrent kernel
+ *      Hout [N_tok, H]    hidden state per token (the layer output, return_sequences=True)
+ *      gates[N_tok, G*H]  post-activation gate values (stash for BPTT; unused for SimpleRNN)
+ *      aux  [N_tok, H]    LSTM: cell state c_t;  GRU: r_t * h_{t-1};  SimpleRNN: unused
+ *      upack: workspace of seqrec_rnn_upack_floats() floats (re-laid-out copy of U)
+ *      step_off: DEVICE int32[T+1]; B = number of sessions (= step_off[1]) */
+int64_t seqrec_rnn_upack_floats(int cell, int H);
+int seqrec_rnn_fwd(int cell, int act, int H, int H_real, int T, int B, const int32_t* step_off,
+                   const float* XW, const float* U, float* Hout, float* gates, float* aux,
+                   float* upack, void* stream);
+/*      BPTT of the same scan (Theano autodiff through scan).
+ *      dHout [N_tok,H]  in: dLoss/dHout;  dPre [N_tok,G*H] out: dLoss/d(pre-activations) = dLoss/dXW.
+ *      dU, dW, db follow from dPre by seqrec_gemm_f32 / seqrec_colsum. */
+int seqrec_rnn_bwd(int cell, int act, int H, int H_real, int T, int B, const int32_t* step_off,
+                   const float* dHout, const float* Hout, const float* gates, const float* aux,
+                   const float* U, float* dPre, float* upack, void* stream);
+
+/* ---- softmax + Theano categorical_crossentropy under the Keras token-mean mask
+ *      (model.py:175-177,257,397), fused with its gradient.
+ *      logits [n,V] is overwritten by dlogits = (p - onehot) * active * inv_denom, where active = 0
+ *      when the target probability is clipped (outside [1e-7, 1-1e-7]).  loss_rows [n] receives
+ *      -log(clip(p_i[tgt_i])) per token (sum it with seqrec_reduce_sum).  probs (nullable) gets p.
+ *      tgt == NULL: prediction only (probs required, logits untouched). */
+int seqrec_full_softmax_ce(float* logits, int64_t ld, const int32_t* tgt, int64_t n, int V,
+                           float inv_denom, float* loss_rows, float* probs, void* stream);
+/*      sampled softmax over {target} U K shared negatives (extension).
+ *      ln [n,K] = Hd . Eout[neg]^T is overwritten by dln.  The target logit is computed here from
+ *      hd[n,H] and Eout[tgt] (row gather); bout (nullable, [V]) is added and logq (nullable, [V])
+ *      subtracted for every candidate; accidental hits (neg == tgt) are removed.  dlt [n] out. */
+int seqrec_sampled_softmax_ce(float* ln, int64_t ld, const float* hd, int H, const float* Eout,
+                              const float* bout, const float* logq, const int32_t* tgt,
+                              const int32_t* neg, int64_t n, int K, float inv_denom,
+                              float* loss_rows, float* dlt, void* stream);
+/* ---- out[0] (+)= sum_i x[i], one workgroup, fixed summation order (deterministic) */
+int seqrec_reduce_sum(const float* x, int64_t n, float* out, int accumulate, void* stream);
+
+/* ---- column sum: out[j] (+)= sum_i X[i,j]   (bias gradients); two-stage, deterministic.
+ *      workspace: 64*width floats. */
+int seqrec_colsum(const float* X, int64_t n, int width, int64_t ld, float* out, int accumulate,
+                  float* workspace, void* stream);
+/* ---- y[i,:] = x[i,:] * m[i,:]  (Dropout layers, model.py:256,357,363,368,372); in place allowed */
+int seqrec_mul(const float* x, const float* m, float* y, int64_t n, void* stream);
+/* ---- fill n floats / n int32 */
+int seqrec_fill_f32(float* x, float v, int64_t n, void* stream);
+int seqrec_fill_i32(int32_t* x, int32_t v, int64_t n, void* stream);
+
+/* ---- row-sparse gradient path for the item tables (E, Eout, Wk, bout) -- the exact sparse
+ *      equivalent of Keras' dense Adagrad (experiments_methods.py:41): a row with zero gradient is
+ *      left untouched by the dense rule.  `gtab` is a table-shaped gradient accumulator that is all
+ *      zero between steps; `slot` (int32[rows of table], all INT32_MAX between steps) elects one
+ *      owner per touched row (the smallest contribution index).
+ *      scatter_add: gtab[rows[i],:] += vals[i,:] * (row_scale ? row_scale[i] : 1)  (float atomics),
+ *                   slot[rows[i]] = min(slot[rows[i]], base + i)
+ *      sqnorm:      partial[blockIdx] = sum over owned rows of |gtab[row,:]|^2  (added to sq_accum)
+ *      adagrad:     owner applies a += (s g)^2, p -= lr s g / (sqrt(a) + eps), then clears gtab row
+ *                   and slot.  s = *scale (device scalar from seqrec_clip_scale). */
+int seqrec_rows_scatter_add(float* gtab, int32_t* slot, const int32_t* rows, const float* vals,
+                            int64_t ldv, const float* row_scale, int64_t n, int width, int32_t base,
+                            void* stream);
+int seqrec_rows_sqnorm(const float* gtab, const int32_t* slot, const int32_t* rows, int64_t n,
+                       int width, int32_t base, float* sq_accum, void* stream);
+int seqrec_rows_adagrad(float* table, float* accum, float* gtab, int32_t* slot, const int32_t* rows,
+                        int64_t n, int width, int32_t base, float lr, float eps, const float* scale,
+                        void* stream);
+
+/* ---- dense tensors: sq_accum += |g|^2 ; scale = (norm >= clipnorm) ? clipnorm/norm : 1 (Keras
+ *      clip_norm); Adagrad update (Keras optimizers.Adagrad, epsilon=1e-8, decay=0). */
+int seqrec_sqnorm(const float* g, int64_t n, float* sq_accum, void* stream);
+int seqrec_clip_scale(const float* sq_accum, float clipnorm, float* scale, void* stream);
+int seqrec_adagrad_dense(float* p, float* a, const float* g, int64_t n, float lr, float eps,
+                         const float* scale, void* stream);
+
+/* ---- counter RNG (specification: oracle/rng.py).  Alias-method draw of K negatives for
+ *      training step `step`; inverted-dropout multipliers out[r*ld + j] (j < width) drawn with
+ *      counter rowkey[r]*width + j (rowkey nullable -> r): 0 or 1/(1-rate). */
+int seqrec_sample_negatives(uint64_t seed, uint64_t step, int K, const uint32_t* thresh,
+                            const int32_t* alias, int V, int32_t* out, void* stream);
+int seqrec_dropout_mask(uint64_t seed, uint64_t stream_id, const int64_t* rowkey, int64_t n_rows,
+                        int width, int64_t ld, double rate, float* out, void* stream);
+
+/* ---- Recall@K support (extension): rank[i] = #{v : score(i,v) > score(i,tgt_i)},
+ *      score(i,v) = hd[i,:] . Eout[v,:] (+ bout[v]).  rank must be zeroed by the caller. */
+int seqrec_rank_count(const float* hd, int H, const float* Eout, const float* bout,
+                      const int32_t* tgt, int64_t n, int V, int32_t* rank, float* thr_workspace /* n floats */,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEQREC_HIP_H */

@@ -61,18 +61,27 @@ def dropout_stream(base_stream, step):
     return base_stream + 16 * (step + 1)
 
 
-def dropout_mask(seed, stream, n, rate, dtype=np.float32):
-    """Inverted-dropout multipliers for n elements: 0 or 1/(1-rate).
+def dropout_mask(seed, stream, rowkey, width, rate, dtype=np.float32):
+    """Inverted-dropout multipliers, shape (len(rowkey), width): 0 or 1/(1-rate).
 
-    keep iff (rand64 >> 40) < round((1-rate) * 2**24).
+    element (r, j) uses counter rowkey[r]*width + j; keep iff
+    (rand64 >> 40) < round((1-rate) * 2**24).
     """
+    rowkey = np.asarray(rowkey, dtype=np.uint64)
     if rate <= 0.0:
-        return np.ones(n, dtype=dtype)
+        return np.ones((rowkey.shape[0], width), dtype=dtype)
     keep = 1.0 - rate
     thr = int(round(keep * (1 << 24)))
-    r = rand64(seed, stream, np.arange(n, dtype=np.uint64)) >> np.uint64(40)
+    with np.errstate(over="ignore"):
+        ctr = rowkey[:, None] * np.uint64(width) + np.arange(width, dtype=np.uint64)[None, :]
+    r = rand64(seed, stream, ctr) >> np.uint64(40)
     m = (r < np.uint64(thr)).astype(dtype)
     return m * dtype(np.float32(1.0) / np.float32(keep))
+
+
+def token_key(tok_b, tok_s):
+    """Row key of a token: (original batch index << 16) + step index."""
+    return (np.asarray(tok_b, dtype=np.uint64) << np.uint64(16)) + np.asarray(tok_s, dtype=np.uint64)
 
 
 def build_alias_table(probs):

@@ -1,0 +1,302 @@
+// fp32 GEMM on the gfx950 f32-input matrix cores (v_mfma_f32_32x32x2_f32): exact fp32
+// (bitwise a k-ordered fmaf chain), so the 1e-3 parity budget of the hot path is untouched.
+//
+// Block = 256 threads = 4 waves in a 2x2 grid; block tile BM x BN (64 or 128 each), BK = 16.
+// Both operand tiles live k-major in LDS ([k][m] / [k][n], row stride R+2 floats) so that the
+// MFMA operand read  A[i = lane&31][k = lane>>5]  is one conflict-free ds_read_b32 per lane.
+// Global->LDS staging goes through registers (issue next tile's loads, compute, then write),
+// one barrier per K tile, two LDS buffers.
+//
+// Roofline: MFMA-bound, 157.3 TFLOP/s fp32; algorithmic flops = 2*M*N*K.
+#include "common.h"
+
+namespace {
+
+struct GemmArgs {
+    const float* A; const float* B; float* C; const float* bias;
+    long M, N, K, lda, ldb, ldc;
+    long k_per_split;      // multiple of 16
+    int accumulate;        // C += result (only when splits == 1)
+    int a_vec, b_vec;      // 16-byte vector loads legal for this operand
+    int tiles_n;
+    // epilogue 1 (Recall@K): rank[row] += #{col != tgt[row] : acc + bias[col] > thr[row]}
+    int epi;
+    const int* tgt; const float* thr; int* rank;
+};
+
+constexpr int BK = 16;
+
+// Load the 4 consecutive-k (KCONTIG) or consecutive-r (!KCONTIG) elements that thread `idx` owns.
+template <int BR, bool KCONTIG>
+__device__ __forceinline__ float4 load_tile4(const float* __restrict__ X, long ld, long r0, long k0,
+                                             long R, long Kend, int idx, bool vec_ok) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KCONTIG) {
+        const int r = idx >> 2, kq = idx & 3;
+        const long gr = r0 + r, gk = k0 + 4 * kq;
+        if (gr < R) {
+            const float* p = X + gr * ld + gk;
+            if (vec_ok && gk + 3 < Kend) {
+                v = *reinterpret_cast<const float4*>(p);
+            } else {
+                if (gk + 0 < Kend) v.x = p[0];
+                if (gk + 1 < Kend) v.y = p[1];
+                if (gk + 2 < Kend) v.z = p[2];
+                if (gk + 3 < Kend) v.w = p[3];
+            }
+        }
+    } else {
+        const int k = idx / (BR / 4), rq = idx % (BR / 4);
+        const long gk = k0 + k, gr = r0 + 4 * rq;
+        if (gk < Kend) {
+            const float* p = X + gk * ld + gr;
+            if (vec_ok && gr + 3 < R) {
+                v = *reinterpret_cast<const float4*>(p);
+            } else {
+                if (gr + 0 < R) v.x = p[0];
+                if (gr + 1 < R) v.y = p[1];
+                if (gr + 2 < R) v.z = p[2];
+                if (gr + 3 < R) v.w = p[3];
+            }
+        }
+    }
+    return v;
+}
+
+template <int BR, bool KCONTIG>
+__device__ __forceinline__ void store_tile4(float* __restrict__ S, int idx, float4 v) {
+    constexpr int LD = BR + 2;
+    if (KCONTIG) {
+        const int r = idx >> 2, kq = idx & 3;
+        S[(4 * kq + 0) * LD + r] = v.x;
+        S[(4 * kq + 1) * LD + r] = v.y;
+        S[(4 * kq + 2) * LD + r] = v.z;
+        S[(4 * kq + 3) * LD + r] = v.w;
+    } else {
+        const int k = idx / (BR / 4), rq = idx % (BR / 4);
+        float* q = S + k * LD + 4 * rq;
+        q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+    }
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+    constexpr int LDA = BM + 2, LDB = BN + 2;
+    constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 MFMA tiles per wave
+    constexpr int NA = BM / 64, NB = BN / 64;     // float4 loads per thread per operand
+    __shared__ float As[2][BK * LDA];
+    __shared__ float Bs[2][BK * LDB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = blockIdx.x;
+    const long m0 = (long)(tile / g.tiles_n) * BM, n0 = (long)(tile % g.tiles_n) * BN;
+    const long kbeg = (long)blockIdx.z * g.k_per_split;
+    const long kend = min(g.K, kbeg + g.k_per_split);
+    const int nk = (int)((kend - kbeg + BK - 1) / BK);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[NA], rb[NB];
+    auto gload = [&](int kt) {
+        const long k0 = kbeg + (long)kt * BK;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[i] = load_tile4<BM, A_KC>(g.A, g.lda, m0, k0, g.M, kend, tid + 256 * i, g.a_vec);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = load_tile4<BN, B_KC>(g.B, g.ldb, n0, k0, g.N, kend, tid + 256 * i, g.b_vec);
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) store_tile4<BM, A_KC>(As[buf], tid + 256 * i, ra[i]);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) store_tile4<BN, B_KC>(Bs[buf], tid + 256 * i, rb[i]);
+    };
+
+    if (nk > 0) {
+        gload(0);
+        sstore(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
+        const float* as = As[cur] + wm * (BM / 2) + (lane & 31);
+        const float* bs = Bs[cur] + wn * (BN / 2) + (lane & 31);
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            const int kk = 2 * ks + (lane >> 5);
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = as[kk * LDA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = bs[kk * LDB + 32 * j];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) sstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    if (g.epi == 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const long col = n0 + wn * (BN / 2) + 32 * j + (lane & 31);
+                const float bv = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long row = m0 + wm * (BM / 2) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    bool pred = false;
+                    if (row < g.M && col < g.N) pred = (col != g.tgt[row]) && (acc[i][j][r] + bv > g.thr[row]);
+                    const unsigned long long bal = __ballot(pred);
+                    const int cnt = __popcll(lane < 32 ? (bal & 0xFFFFFFFFull) : (bal >> 32));
+                    if ((lane & 31) == 0 && cnt > 0 && row < g.M) atomicAdd(g.rank + row, cnt);
+                }
+            }
+        return;
+    }
+    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* Cb = g.C + (long)blockIdx.z * g.M * g.ldc;   // split-K slabs use ldc = N
+    const bool splits = gridDim.z > 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const long col = n0 + wn * (BN / 2) + 32 * j + (lane & 31);
+            if (col >= g.N) continue;
+            const float bv = (!splits && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = m0 + wm * (BM / 2) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < g.M) {
+                    float* c = Cb + row * g.ldc + col;
+                    float v = acc[i][j][r] + bv;
+                    if (!splits && g.accumulate) v += *c;
+                    *c = v;
+                }
+            }
+        }
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long M, long N,
+                                     float* __restrict__ C, long ldc, const float* __restrict__ bias,
+                                     int accumulate) {
+    const long total = M * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < splits; ++z) s += ws[(long)z * total + i];   // fixed order: deterministic
+        const long r = i / N, c = i % N;
+        if (bias) s += bias[c];
+        float* o = C + r * ldc + c;
+        if (accumulate) s += *o;
+        *o = s;
+    }
+}
+
+template <int BM, int BN>
+int launch_gemm(int a_kc, int b_kc, GemmArgs& g, int splits, hipStream_t st) {
+    const long tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    g.tiles_n = (int)tiles_n;
+    dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)splits), block(256);
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, block, 0, st, g);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, st, g);
+    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, block, 0, st, g);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t seqrec_gemm_workspace_floats(int64_t M, int64_t N, int splitk) {
+    return splitk > 1 ? (int64_t)splitk * M * N : 0;
+}
+
+extern "C" int seqrec_gemm_f32(int a_kcontig, int b_kcontig, int64_t M, int64_t N, int64_t K,
+                               const float* A, int64_t lda, const float* B, int64_t ldb,
+                               float* C, int64_t ldc, const float* bias, int accumulate,
+                               int splitk, float* workspace, void* stream) {
+    if (M < 0 || N < 0 || K < 0 || !C) return SEQREC_E_ARG;
+    if (M == 0 || N == 0) return 0;
+    if ((K > 0 && (!A || !B)) || splitk < 1) return SEQREC_E_ARG;
+    if (splitk > 1 && !workspace) return SEQREC_E_ARG;
+    hipStream_t st = as_stream(stream);
+    GemmArgs g;
+    g.A = A; g.B = B; g.bias = bias;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
+    g.accumulate = accumulate;
+    g.epi = 0; g.tgt = nullptr; g.thr = nullptr; g.rank = nullptr;
+    g.a_vec = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 4 == 0);
+    g.b_vec = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 4 == 0);
+    long kps = (K + splitk - 1) / splitk;
+    kps = (kps + BK - 1) / BK * BK;
+    if (kps == 0) kps = BK;
+    int splits = (int)((K + kps - 1) / kps);
+    if (splits < 1) splits = 1;
+    g.k_per_split = kps;
+    if (splits > 1) { g.C = workspace; g.ldc = N; } else { g.C = C; g.ldc = ldc; }
+    // tile choice: big tiles once they still give >= 2 workgroups per CU, else 64x64
+    const long t128 = ((M + 127) / 128) * ((N + 127) / 128) * splits;
+    int rc;
+    if (t128 >= 512) rc = launch_gemm<128, 128>(a_kcontig, b_kcontig, g, splits, st);
+    else rc = launch_gemm<64, 64>(a_kcontig, b_kcontig, g, splits, st);
+    if (rc) return rc;
+    if (splits > 1) {
+        const long total = M * N;
+        int blocks = (int)min((long)2048, (total + 255) / 256);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, splits, (long)M, (long)N,
+                           C, (long)ldc, bias, accumulate);
+        SEQREC_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+namespace {
+// thr[i] = hd[i,:] . Eout[tgt[i],:] + bout[tgt[i]]   (one wave per row)
+__global__ void target_score_kernel(const float* __restrict__ hd, int H, const float* __restrict__ Eout,
+                                    const float* __restrict__ bout, const int* __restrict__ tgt, long n,
+                                    float* __restrict__ thr) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int t = tgt[row];
+    const float* h = hd + row * H;
+    const float* e = Eout + (long)t * H;
+    float d = 0.f;
+    for (int j = lane; j < H; j += 64) d += h[j] * e[j];
+    d = wave_sum(d);
+    if (lane == 0) thr[row] = d + (bout ? bout[t] : 0.f);
+}
+}  // namespace
+
+extern "C" int seqrec_rank_count(const float* hd, int H, const float* Eout, const float* bout,
+                                 const int32_t* tgt, int64_t n, int V, int32_t* rank, float* thr_workspace,
+                                 void* stream) {
+    if (n < 0 || V <= 0 || H <= 0) return SEQREC_E_ARG;
+    if (n == 0) return 0;
+    if (!hd || !Eout || !tgt || !rank || !thr_workspace) return SEQREC_E_ARG;
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(target_score_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, hd, H, Eout, bout, tgt, (long)n,
+                       thr_workspace);
+    SEQREC_LAUNCH_CHECK();
+    GemmArgs g;
+    g.A = hd; g.B = Eout; g.C = nullptr; g.bias = bout;
+    g.M = n; g.N = V; g.K = H; g.lda = H; g.ldb = H; g.ldc = 0;
+    g.k_per_split = (H + BK - 1) / BK * BK;
+    g.accumulate = 0;
+    g.a_vec = ((reinterpret_cast<uintptr_t>(hd) & 15) == 0) && (H % 4 == 0);
+    g.b_vec = ((reinterpret_cast<uintptr_t>(Eout) & 15) == 0) && (H % 4 == 0);
+    g.epi = 1; g.tgt = tgt; g.thr = thr_workspace; g.rank = rank;
+    return launch_gemm<128, 128>(1, 1, g, 1, st);
+}

@@ -1,0 +1,456 @@
+// Bandwidth-side kernels of the hot path: row gather, softmax/CE rows, bias column sums, the
+// row-sparse gradient path (scatter-add / norm / Adagrad) and the dense optimizer, counter RNG.
+// All are HBM/L2-bound integer-index + fp32 streaming work: 16 B per lane where rows allow it,
+// one wave per table row so that a 256-float row is exactly one 1-KiB coalesced wave access.
+#include "common.h"
+#include <limits.h>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// gather: out[i,:] = table[ids[i],:] * scale[i] + bias   (algorithmic bytes: 8*width per row)
+// ---------------------------------------------------------------------------------------------
+template <bool VEC4>
+__global__ void gather_rows_kernel(const float* __restrict__ table, const int* __restrict__ ids,
+                                   float* __restrict__ out, long n, int width, const float* __restrict__ row_scale,
+                                   const float* __restrict__ bias, int accumulate) {
+    const int per = VEC4 ? width / 4 : width;
+    const long total = n * per;
+    for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long)gridDim.x * blockDim.x) {
+        const long i = c / per;
+        const int q = (int)(c % per);
+        const int id = ids[i];
+        const float s = row_scale ? row_scale[i] : 1.f;
+        if (VEC4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (id >= 0) v = reinterpret_cast<const float4*>(table + (long)id * width)[q];
+            v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+            if (bias) {
+                const float4 b = reinterpret_cast<const float4*>(bias)[q];
+                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            }
+            float4* op = reinterpret_cast<float4*>(out + i * width) + q;
+            if (accumulate) { const float4 o = *op; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *op = v;
+        } else {
+            float v = id >= 0 ? table[(long)id * width + q] : 0.f;
+            v *= s;
+            if (bias) v += bias[q];
+            if (accumulate) v += out[i * width + q];
+            out[i * width + q] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// full softmax + Keras/Theano CE, one wave per token row
+// ---------------------------------------------------------------------------------------------
+__global__ void full_softmax_ce_kernel(float* __restrict__ logits, long ld, const int* __restrict__ tgt, long n,
+                                       int V, float inv_denom, float* __restrict__ loss_rows,
+                                       float* __restrict__ probs) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float* x = logits + row * ld;
+    float m = -INFINITY;
+    for (int j = lane; j < V; j += 64) m = fmaxf(m, x[j]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int j = lane; j < V; j += 64) s += expf(x[j] - m);
+    s = wave_sum(s);
+    // Theano-backend categorical_crossentropy renormalises the softmax output once more
+    float sp = 0.f;
+    for (int j = lane; j < V; j += 64) sp += expf(x[j] - m) / s;
+    sp = wave_sum(sp);
+    float active = 0.f;
+    int t = -1;
+    if (tgt) {
+        t = tgt[row];
+        const float pt = (expf(x[t] - m) / s) / sp;
+        const float lo = 1e-7f, hi = 1.0f - 1e-7f;
+        active = (pt >= lo && pt <= hi) ? inv_denom : 0.f;
+        if (lane == 0) loss_rows[row] = -logf(fminf(fmaxf(pt, lo), hi));
+    }
+    for (int j = lane; j < V; j += 64) {
+        const float p = expf(x[j] - m) / s;
+        if (probs) probs[row * V + j] = p;
+        if (tgt) x[j] = (p - (j == t ? 1.f : 0.f)) * active;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// sampled softmax + CE over {target} U K negatives, one wave per token row
+// ---------------------------------------------------------------------------------------------
+__global__ void sampled_softmax_ce_kernel(float* __restrict__ ln, long ld, const float* __restrict__ hd, int H,
+                                          const float* __restrict__ Eout, const float* __restrict__ bout,
+                                          const float* __restrict__ logq, const int* __restrict__ tgt,
+                                          const int* __restrict__ neg, long n, int K, float inv_denom,
+                                          float* __restrict__ loss_rows, float* __restrict__ dlt) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int t = tgt[row];
+    const float* h = hd + row * H;
+    const float* et = Eout + (long)t * H;
+    float d = 0.f;
+    for (int j = lane; j < H; j += 64) d += h[j] * et[j];
+    float lt = wave_sum(d);
+    if (bout) lt += bout[t];
+    if (logq) lt -= logq[t];
+    float* x = ln + row * ld;
+    float m = lt;
+    for (int k = lane; k < K; k += 64) {
+        const int v = neg[k];
+        float l = x[k];
+        if (bout) l += bout[v];
+        if (logq) l -= logq[v];
+        if (v == t) l = -INFINITY;
+        x[k] = l;
+        m = fmaxf(m, l);
+    }
+    m = wave_max(m);
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += expf(x[k] - m);
+    const float etg = expf(lt - m);
+    s = wave_sum(s) + etg;
+    const float pt = etg / s;
+    const float lo = 1e-7f, hi = 1.0f - 1e-7f;
+    const float active = (pt >= lo && pt <= hi) ? inv_denom : 0.f;
+    if (lane == 0) {
+        loss_rows[row] = -logf(fminf(fmaxf(pt, lo), hi));
+        dlt[row] = (pt - 1.f) * active;
+    }
+    for (int k = lane; k < K; k += 64) x[k] = (expf(x[k] - m) / s) * active;
+}
+
+__global__ void reduce_sum_kernel(const float* __restrict__ x, long n, float* __restrict__ out, int accumulate) {
+    __shared__ float part[1024];
+    float s = 0.f;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) s += x[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + part[0];
+}
+
+// column sums: block (64 columns x 4 row-lanes), rows strided over gridDim.y; deterministic two-stage
+__global__ void colsum_partial_kernel(const float* __restrict__ X, long n, int width, long ld, float* __restrict__ part) {
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    __shared__ float sh[4][64];
+    float s = 0.f;
+    if (col < width)
+        for (long i = (long)blockIdx.y * 4 + rl; i < n; i += (long)gridDim.y * 4) s += X[i * ld + col];
+    sh[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && col < width) part[(long)blockIdx.y * width + col] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, int width, float* __restrict__ out, int accumulate) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= width) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(long)p * width + col];
+    out[col] = (accumulate ? out[col] : 0.f) + s;
+}
+
+__global__ void mul_kernel(const float* __restrict__ x, const float* __restrict__ m, float* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = x[i] * m[i];
+}
+__global__ void fill_f32_kernel(float* x, float v, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] = v;
+}
+__global__ void fill_i32_kernel(int* x, int v, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// row-sparse gradient path; one wave per contribution row
+// ---------------------------------------------------------------------------------------------
+__global__ void rows_scatter_add_kernel(float* __restrict__ gtab, int* __restrict__ slot, const int* __restrict__ rows,
+                                        const float* __restrict__ vals, long ldv, const float* __restrict__ row_scale,
+                                        long n, int width, int base) {
+    const int lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int r = rows[i];
+    const float s = row_scale ? row_scale[i] : 1.f;
+    float* g = gtab + (long)r * width;
+    const float* v = vals + i * ldv;
+    for (int c = lane; c < width; c += 64) atomicAdd(g + c, v[c] * s);
+    if (lane == 0) atomicMin(slot + r, base + (int)i);
+}
+
+__global__ void rows_sqnorm_kernel(const float* __restrict__ gtab, const int* __restrict__ slot,
+                                   const int* __restrict__ rows, long n, int width, int base, float* __restrict__ sq) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * (blockDim.x >> 6) + wv;
+    __shared__ float part[16];
+    float s = 0.f;
+    if (i < n) {
+        const int r = rows[i];
+        if (slot[r] == base + (int)i) {
+            const float* g = gtab + (long)r * width;
+            for (int c = lane; c < width; c += 64) s += g[c] * g[c];
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) part[wv] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += part[k];
+        if (t != 0.f) atomicAdd(sq, t);
+    }
+}
+
+__global__ void rows_adagrad_kernel(float* __restrict__ table, float* __restrict__ accum, float* __restrict__ gtab,
+                                    int* __restrict__ slot, const int* __restrict__ rows, long n, int width, int base,
+                                    float lr, float eps, const float* __restrict__ scale) {
+    const int lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int r = rows[i];
+    if (slot[r] != base + (int)i) return;          // wave-uniform: exactly one owner per touched row
+    const float sc = scale[0];
+    const long o = (long)r * width;
+    for (int c = lane; c < width; c += 64) {
+        const float g = gtab[o + c] * sc;
+        const float a = accum[o + c] + g * g;
+        accum[o + c] = a;
+        table[o + c] -= lr * g / (sqrtf(a) + eps);
+        gtab[o + c] = 0.f;
+    }
+    if (lane == 0) slot[r] = INT_MAX;
+}
+
+// dense optimizer
+__global__ void sqnorm_kernel(const float* __restrict__ g, long n, float* __restrict__ sq) {
+    __shared__ float part[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += g[i] * g[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sq, part[0] + part[1] + part[2] + part[3]);
+}
+__global__ void clip_scale_kernel(const float* __restrict__ sq, float clipnorm, float* __restrict__ scale) {
+    const float nrm = sqrtf(sq[0]);
+    scale[0] = (clipnorm > 0.f && nrm >= clipnorm) ? clipnorm / nrm : 1.f;   // Keras clip_norm
+}
+__global__ void adagrad_dense_kernel(float* __restrict__ p, float* __restrict__ a, const float* __restrict__ g, long n,
+                                     float lr, float eps, const float* __restrict__ scale) {
+    const float sc = scale[0];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gv = g[i] * sc;
+        const float av = a[i] + gv * gv;
+        a[i] = av;
+        p[i] -= lr * gv / (sqrtf(av) + eps);
+    }
+}
+
+// counter RNG (oracle/rng.py)
+__global__ void sample_negatives_kernel(uint64_t key, uint64_t step, int K, const uint32_t* __restrict__ thresh,
+                                        const int* __restrict__ alias, int V, int* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const uint64_t r = rand64(key, step * (uint64_t)K + (uint64_t)k);
+    const uint64_t hi = r >> 32;
+    const uint32_t lo = (uint32_t)(r & 0xFFFFFFFFu);
+    const int j = (int)((hi * (uint64_t)V) >> 32);
+    out[k] = lo < thresh[j] ? j : alias[j];
+}
+__global__ void dropout_mask_kernel(uint64_t key, const long* __restrict__ rowkey, long n_rows, int width, long ld,
+                                    uint32_t thr, float inv_keep, float* __restrict__ out) {
+    const long total = n_rows * width;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / width;
+        const int j = (int)(i % width);
+        const uint64_t c = (uint64_t)(rowkey ? rowkey[r] : r) * (uint64_t)width + (uint64_t)j;
+        const uint64_t v = rand64(key, c) >> 40;
+        out[r * ld + j] = v < (uint64_t)thr ? inv_keep : 0.f;
+    }
+}
+
+inline int grid_for(long work, int per_block, int cap = 4096) {
+    long b = (work + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int seqrec_abi_version(void) { return SEQREC_ABI_VERSION; }
+extern "C" const char* seqrec_build_arch(void) { return "gfx950"; }
+
+extern "C" int seqrec_gather_rows(const float* table, const int32_t* ids, float* out, int64_t n, int width,
+                                  const float* row_scale, const float* bias, int accumulate, void* stream) {
+    if (n < 0 || width <= 0) return SEQREC_E_ARG;
+    if (n == 0) return 0;
+    if (!table || !ids || !out) return SEQREC_E_ARG;
+    const bool vec = (width % 4 == 0) && ((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(out) |
+                                           reinterpret_cast<uintptr_t>(bias)) & 15) == 0;
+    const long total = (long)n * (vec ? width / 4 : width);
+    const int blocks = grid_for(total, 256, 8192);
+    if (vec) hipLaunchKernelGGL(gather_rows_kernel<true>, dim3(blocks), dim3(256), 0, as_stream(stream), table, ids, out, (long)n, width, row_scale, bias, accumulate);
+    else hipLaunchKernelGGL(gather_rows_kernel<false>, dim3(blocks), dim3(256), 0, as_stream(stream), table, ids, out, (long)n, width, row_scale, bias, accumulate);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int seqrec_full_softmax_ce(float* logits, int64_t ld, const int32_t* tgt, int64_t n, int V,
+                                      float inv_denom, float* loss_rows, float* probs, void* stream) {
+    if (n < 0 || V <= 0 || ld < V) return SEQREC_E_ARG;
+    if (n == 0) return 0;
+    if (!logits || (tgt && !loss_rows) || (!tgt && !probs)) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(full_softmax_ce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), logits,
+                       (long)ld, tgt, (long)n, V, inv_denom, loss_rows, probs);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int seqrec_sampled_softmax_ce(float* ln, int64_t ld, const float* hd, int H, const float* Eout,
+                                         const float* bout, const float* logq, const int32_t* tgt,
+                                         const int32_t* neg, int64_t n, int K, float inv_denom,
+                                         float* loss_rows, float* dlt, void* stream) {
+    if (n < 0 || K < 0 || H <= 0 || ld < K) return SEQREC_E_ARG;
+    if (n == 0) return 0;
+    if (!ln || !hd || !Eout || !tgt || (K > 0 && !neg) || !loss_rows || !dlt) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(sampled_softmax_ce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), ln,
+                       (long)ld, hd, H, Eout, bout, logq, tgt, neg, (long)n, K, inv_denom, loss_rows, dlt);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int seqrec_reduce_sum(const float* x, int64_t n, float* out, int accumulate, void* stream) {
+    if (n < 0 || !out || (n > 0 && !x)) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, as_stream(stream), x, (long)n, out, accumulate);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int seqrec_colsum(const float* X, int64_t n, int width, int64_t ld, float* out, int accumulate,
+                             float* workspace, void* stream) {
+    if (n < 0 || width <= 0 || !out || !workspace) return SEQREC_E_ARG;
+    if (n > 0 && !X) return SEQREC_E_ARG;
+    constexpr int NP = 64;
+    const int np = (int)(n < NP * 4 ? (n + 3) / 4 : NP);
+    hipStream_t st = as_stream(stream);
+    if (np > 0) {
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((width + 63) / 64, np), dim3(256), 0, st, X, (long)n, width, (long)ld, workspace);
+        SEQREC_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((width + 255) / 256), dim3(256), 0, st, workspace, np, width, out, accumulate);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int seqrec_mul(const float* x, const float* m, float* y, int64_t n, void* stream) {
+    if (n < 0) return SEQREC_E_ARG;
+    if (n == 0) return 0;
+    if (!x || !m || !y) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), x, m, y, (long)n);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int seqrec_fill_f32(float* x, float v, int64_t n, void* stream) {
+    if (n < 0) return SEQREC_E_ARG;
+    if (n == 0) return 0;
+    if (!x) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), x, v, (long)n);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int seqrec_fill_i32(int32_t* x, int32_t v, int64_t n, void* stream) {
+    if (n < 0) return SEQREC_E_ARG;
+    if (n == 0) return 0;
+    if (!x) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), x, v, (long)n);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int seqrec_rows_scatter_add(float* gtab, int32_t* slot, const int32_t* rows, const float* vals,
+                                       int64_t ldv, const float* row_scale, int64_t n, int width, int32_t base,
+                                       void* stream) {
+    if (n < 0 || width <= 0) return SEQREC_E_ARG;
+    if (n == 0) return 0;
+    if (!gtab || !slot || !rows || !vals) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(rows_scatter_add_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), gtab, slot,
+                       rows, vals, (long)ldv, row_scale, (long)n, width, base);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int seqrec_rows_sqnorm(const float* gtab, const int32_t* slot, const int32_t* rows, int64_t n,
+                                  int width, int32_t base, float* sq_accum, void* stream) {
+    if (n < 0 || width <= 0) return SEQREC_E_ARG;
+    if (n == 0) return 0;
+    if (!gtab || !slot || !rows || !sq_accum) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(rows_sqnorm_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), gtab, slot, rows,
+                       (long)n, width, base, sq_accum);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int seqrec_rows_adagrad(float* table, float* accum, float* gtab, int32_t* slot, const int32_t* rows,
+                                   int64_t n, int width, int32_t base, float lr, float eps, const float* scale,
+                                   void* stream) {
+    if (n < 0 || width <= 0) return SEQREC_E_ARG;
+    if (n == 0) return 0;
+    if (!table || !accum || !gtab || !slot || !rows || !scale) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(rows_adagrad_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), table, accum,
+                       gtab, slot, rows, (long)n, width, base, lr, eps, scale);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int seqrec_sqnorm(const float* g, int64_t n, float* sq_accum, void* stream) {
+    if (n < 0 || !sq_accum) return SEQREC_E_ARG;
+    if (n == 0) return 0;
+    if (!g) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(grid_for(n, 1024, 1024)), dim3(256), 0, as_stream(stream), g, (long)n, sq_accum);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int seqrec_clip_scale(const float* sq_accum, float clipnorm, float* scale, void* stream) {
+    if (!sq_accum || !scale) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(1), 0, as_stream(stream), sq_accum, clipnorm, scale);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int seqrec_adagrad_dense(float* p, float* a, const float* g, int64_t n, float lr, float eps,
+                                    const float* scale, void* stream) {
+    if (n < 0) return SEQREC_E_ARG;
+    if (n == 0) return 0;
+    if (!p || !a || !g || !scale) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(adagrad_dense_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), p, a, g, (long)n, lr, eps, scale);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int seqrec_sample_negatives(uint64_t seed, uint64_t step, int K, const uint32_t* thresh,
+                                       const int32_t* alias, int V, int32_t* out, void* stream) {
+    if (K < 0 || V <= 0) return SEQREC_E_ARG;
+    if (K == 0) return 0;
+    if (!thresh || !alias || !out) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(sample_negatives_kernel, dim3((K + 255) / 256), dim3(256), 0, as_stream(stream), key64(seed, 1), step, K,
+                       thresh, alias, V, out);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int seqrec_dropout_mask(uint64_t seed, uint64_t stream_id, const int64_t* rowkey, int64_t n_rows,
+                                   int width, int64_t ld, double rate, float* out, void* stream) {
+    if (n_rows < 0 || width <= 0 || ld < width || rate < 0.0 || rate >= 1.0) return SEQREC_E_ARG;
+    if (n_rows == 0) return 0;
+    if (!out) return SEQREC_E_ARG;
+    const double keep = 1.0 - rate;
+    const uint32_t thr = (uint32_t)llrint(keep * 16777216.0);
+    const float inv_keep = 1.0f / (float)keep;      // oracle: float32(1) / float32(keep)
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n_rows * width, 256)), dim3(256), 0, as_stream(stream),
+                       key64(seed, stream_id), reinterpret_cast<const long*>(rowkey), (long)n_rows, width, (long)ld, thr,
+                       inv_keep, out);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,657 @@
+// Recurrent scan (forward + BPTT) over the ragged, length-sorted, time-major packed batch.
+// Replaces Keras' masked K.rnn over SimpleRNN / LSTM (model.py:248-255,344-369) and its Theano
+// autodiff; GRU (Keras 2.0 equations, reset BEFORE the recurrent matmul) is the build's extension.
+//
+// Design (MI355X): sessions are independent, so the batch is cut into row blocks of 16 sessions
+// (one MFMA M-tile) and ONE persistent workgroup per block walks all of its time steps -- no
+// inter-workgroup synchronisation, no per-step launch.  Because sessions are sorted by length the
+// active rows of a block at step t are a prefix, and a block stops at its own longest session.
+//   * hidden state h (and the A operands r*h / dpre) live in LDS across steps ([16][K+2] floats,
+//     stride = 2 mod 32 -> conflict-free MFMA A-fragment reads);
+//   * wave w of the 4 owns hidden columns [16J*w, 16J*(w+1)) of EVERY gate (J = H/64), so all gate
+//     arithmetic of a unit is lane-local in the accumulators (C/D map of v_mfma_f32_16x16x4_f32:
+//     col = lane&15, row = 4*(lane>>4)+reg) and cell state / z / carried gradients stay in registers;
+//   * the recurrent kernel U is re-laid-out once per step ("packed": [wave][k/4][col group][lane][4])
+//     so that a wave streams its B fragments from L2 with fully coalesced 16-byte loads straight
+//     into registers (software ring, 16 loads in flight per lane); U never touches LDS.
+// Arithmetic: exact fp32 on the f32-input MFMA (bitwise an fmaf chain over k).
+//
+// Roofline: MFMA (157.3 TFLOP/s fp32); algorithmic flops fwd = 2*G*H*H per token, bwd = same for
+// dh (the dU GEMM runs separately in gemm.hip).  The scan is latency-bound by its T dependent
+// steps; per step a workgroup streams the whole of U (4*G*H*H bytes) from L2.
+#include "common.h"
+
+namespace {
+
+struct RnnArgs {
+    const int* step_off;
+    int T, B, H_real, act;
+    const float* XW;
+    float* Hout;
+    float* gates;
+    float* aux;
+    const float* pk0;
+    const float* pk1;
+    // backward
+    const float* dHout;
+    const float* HoutR;
+    const float* gatesR;
+    const float* auxR;
+    float* dPre;
+};
+
+__device__ __forceinline__ float act_f(int act, float x) {
+    if (act == SEQREC_ACT_RELU) return fmaxf(x, 0.f);
+    if (act == SEQREC_ACT_TANH) return tanhf(x);
+    return x;
+}
+__device__ __forceinline__ float act_g(int act, float y) {
+    if (act == SEQREC_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (act == SEQREC_ACT_TANH) return 1.f - y * y;
+    return 1.f;
+}
+
+template <int VEC> struct VecT;
+template <> struct VecT<1> { typedef float type; };
+template <> struct VecT<2> { typedef float2 type; };
+template <> struct VecT<4> { typedef float4 type; };
+__device__ __forceinline__ float vget(const float& v, int) { return v; }
+__device__ __forceinline__ float vget(const float2& v, int e) { return e == 0 ? v.x : v.y; }
+__device__ __forceinline__ float vget(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
+
+// acc[NCB] (16 x 16*NCB per wave) += A(16 x 4*KB, LDS, row stride lda) . Bpacked
+template <int NCB>
+struct WaveGemm {
+    static constexpr int VEC = NCB >= 4 ? 4 : NCB;
+    static constexpr int NCG = NCB / VEC;
+    static constexpr int PDK = (16 / NCG) > 0 ? (16 / NCG) : 1;   // k-blocks kept in flight
+    typedef typename VecT<VEC>::type V;
+    V ring[PDK][NCG];
+
+    __device__ __forceinline__ void preload(const float* __restrict__ pk, int lane) {
+        const V* p = reinterpret_cast<const V*>(pk) + lane;
+#pragma unroll
+        for (int i = 0; i < PDK; ++i)
+#pragma unroll
+            for (int cg = 0; cg < NCG; ++cg) ring[i][cg] = p[(i * NCG + cg) * 64];
+    }
+
+    // KB must be a multiple of PDK (host checks)
+    __device__ __forceinline__ void run(const float* __restrict__ ldsA, int lda, const float* __restrict__ pk,
+                                        int KB, int lane, f32x4 (&acc)[NCB]) {
+        const V* p = reinterpret_cast<const V*>(pk) + lane;
+        const float* ap = ldsA + (lane & 15) * lda + (lane >> 4);
+        int kb0 = 0;
+#pragma unroll 1
+        for (; kb0 + PDK < KB; kb0 += PDK) {
+#pragma unroll
+            for (int i = 0; i < PDK; ++i) {
+                const int kb = kb0 + i;
+                const float a = ap[4 * kb];
+                V b[NCG];
+#pragma unroll
+                for (int cg = 0; cg < NCG; ++cg) {
+                    b[cg] = ring[i][cg];
+                    ring[i][cg] = p[((kb + PDK) * NCG + cg) * 64];
+                }
+#pragma unroll
+                for (int cg = 0; cg < NCG; ++cg)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e)
+                        acc[cg * VEC + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vget(b[cg], e), acc[cg * VEC + e], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PDK; ++i) {
+            const float a = ap[4 * (kb0 + i)];
+#pragma unroll
+            for (int cg = 0; cg < NCG; ++cg)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    acc[cg * VEC + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vget(ring[i][cg], e), acc[cg * VEC + e], 0, 0, 0);
+        }
+    }
+};
+
+template <int N> __device__ __forceinline__ void zero_acc(f32x4 (&acc)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// ------------------------------------------------------------------------------------------
+// pack U into per-wave MFMA B-fragment order.
+//   mode 0 (forward):   B[k][(gi, hc)] = U[k*ldu + gates[gi]*H + hc],            K = H
+//   mode 1 (backward):  B[k = gi*H + jj][hc] = U[hc*ldu + gates[gi]*H + jj],     K = ng*H
+// out[(((w*KB + kb)*NCG + cg)*64 + l)*VEC + e], col block cb = cg*VEC + e, k = 4*kb + (l>>4)
+// ------------------------------------------------------------------------------------------
+__global__ void pack_u_kernel(const float* __restrict__ U, int ldu, int H, int mode, int ng, int g0, int g1, int g2,
+                              int g3, float* __restrict__ out) {
+    const int J = H / 64;
+    const int NCB = mode == 0 ? ng * J : J;
+    const int VEC = NCB >= 4 ? 4 : NCB;
+    const int NCG = NCB / VEC;
+    const int K = mode == 0 ? H : ng * H;
+    const int KB = K / 4;
+    const long total = (long)K * NCB * 16 * 4;
+    const int gl[4] = {g0, g1, g2, g3};
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+        long q = o;
+        const int e = (int)(q % VEC); q /= VEC;
+        const int l = (int)(q % 64); q /= 64;
+        const int cg = (int)(q % NCG); q /= NCG;
+        const int kb = (int)(q % KB); q /= KB;
+        const int w = (int)q;
+        const int cb = cg * VEC + e;
+        const int k = 4 * kb + (l >> 4);
+        const int cc = l & 15;
+        float v;
+        if (mode == 0) {
+            const int gi = cb / J, j = cb % J;
+            const int hc = 16 * J * w + 16 * j + cc;
+            v = U[(long)k * ldu + gl[gi] * H + hc];
+        } else {
+            const int hc = 16 * J * w + 16 * cb + cc;
+            const int gi = k / H, jj = k % H;
+            v = U[(long)hc * ldu + gl[gi] * H + jj];
+        }
+        out[o] = v;
+    }
+}
+
+#define ROWCOL_SETUP()                                         \
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6; \
+    const int cc = lane & 15, rq = lane >> 4;                  \
+    const int r0 = blockIdx.x * 16;                            \
+    const int cbase = 16 * J * w + cc;
+
+// ------------------------------------------------------------------------------------------
+// SimpleRNN:  h = act(xw + h_prev . U)
+// ------------------------------------------------------------------------------------------
+template <int J>
+__global__ __launch_bounds__(256) void srnn_fwd_kernel(RnnArgs a) {
+    constexpr int H = 64 * J, LDA = H + 2, KB = H / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    ROWCOL_SETUP();
+    float* hb0 = smem;
+    float* hb1 = smem + 16 * LDA;
+    for (int i = tid; i < 32 * LDA; i += 256) smem[i] = 0.f;
+    __syncthreads();
+    const float* pk = a.pk0 + (size_t)w * H * (16 * J);
+    WaveGemm<J> gm;
+    int cur = 0;
+    for (int t = 0; t < a.T; ++t) {
+        const int o0 = a.step_off[t], bt = a.step_off[t + 1] - o0;
+        if (bt <= r0) break;
+        const int nact = min(16, bt - r0);
+        const long p0 = (long)o0 + r0;
+        gm.preload(pk, lane);
+        float x[J][4];
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * rq + r;
+                x[j][r] = row < nact ? a.XW[(p0 + row) * H + cbase + 16 * j] : 0.f;
+            }
+        float* hc_ = cur ? hb1 : hb0;
+        float* hn_ = cur ? hb0 : hb1;
+        f32x4 acc[J];
+        zero_acc(acc);
+        gm.run(hc_, LDA, pk, KB, lane, acc);
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * rq + r, col = cbase + 16 * j;
+                float y = act_f(a.act, acc[j][r] + x[j][r]);
+                if (col >= a.H_real) y = 0.f;
+                hn_[row * LDA + col] = y;
+                if (row < nact) a.Hout[(p0 + row) * H + col] = y;
+            }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+template <int J>
+__global__ __launch_bounds__(256) void srnn_bwd_kernel(RnnArgs a) {
+    constexpr int H = 64 * J, LDP = H + 2, KB = H / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    ROWCOL_SETUP();
+    float* dp = smem;
+    const float* pk = a.pk0 + (size_t)w * H * (16 * J);
+    WaveGemm<J> gm;
+    float dhc[J][4];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dhc[j][r] = 0.f;
+    int tb = 0;
+    while (tb < a.T && a.step_off[tb + 1] - a.step_off[tb] > r0) ++tb;
+    for (int t = tb - 1; t >= 0; --t) {
+        const int o0 = a.step_off[t], bt = a.step_off[t + 1] - o0;
+        const int nact = min(16, bt - r0);
+        const long p0 = (long)o0 + r0;
+        gm.preload(pk, lane);
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * rq + r, col = cbase + 16 * j;
+                float d = 0.f;
+                if (row < nact) {
+                    const long q = (p0 + row) * H + col;
+                    const float dh = dhc[j][r] + a.dHout[q];
+                    d = dh * act_g(a.act, a.HoutR[q]);
+                    a.dPre[q] = d;
+                }
+                dp[row * LDP + col] = d;
+            }
+        __syncthreads();
+        f32x4 acc[J];
+        zero_acc(acc);
+        gm.run(dp, LDP, pk, KB, lane, acc);
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dhc[j][r] = acc[j][r];
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// LSTM (gate order i,f,c,o; hard_sigmoid gates; act on candidate and on c)
+// ------------------------------------------------------------------------------------------
+template <int J>
+__global__ __launch_bounds__(256) void lstm_fwd_kernel(RnnArgs a) {
+    constexpr int H = 64 * J, LDA = H + 2, KB = H / 4, GH = 4 * H;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    ROWCOL_SETUP();
+    float* hb0 = smem;
+    float* hb1 = smem + 16 * LDA;
+    for (int i = tid; i < 32 * LDA; i += 256) smem[i] = 0.f;
+    __syncthreads();
+    const float* pk = a.pk0 + (size_t)w * H * (64 * J);
+    WaveGemm<4 * J> gm;
+    float cst[J][4];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cst[j][r] = 0.f;
+    int cur = 0;
+    for (int t = 0; t < a.T; ++t) {
+        const int o0 = a.step_off[t], bt = a.step_off[t + 1] - o0;
+        if (bt <= r0) break;
+        const int nact = min(16, bt - r0);
+        const long p0 = (long)o0 + r0;
+        gm.preload(pk, lane);
+        float x[4][J][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * rq + r;
+                    x[g][j][r] = row < nact ? a.XW[(p0 + row) * GH + g * H + cbase + 16 * j] : 0.f;
+                }
+        float* hc_ = cur ? hb1 : hb0;
+        float* hn_ = cur ? hb0 : hb1;
+        f32x4 acc[4 * J];
+        zero_acc(acc);
+        gm.run(hc_, LDA, pk, KB, lane, acc);
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * rq + r, col = cbase + 16 * j;
+                const float gi = hard_sigmoid(acc[0 * J + j][r] + x[0][j][r]);
+                const float gf = hard_sigmoid(acc[1 * J + j][r] + x[1][j][r]);
+                const float gg = act_f(a.act, acc[2 * J + j][r] + x[2][j][r]);
+                const float go = hard_sigmoid(acc[3 * J + j][r] + x[3][j][r]);
+                float c = gf * cst[j][r] + gi * gg;
+                float h = go * act_f(a.act, c);
+                if (col >= a.H_real) { c = 0.f; h = 0.f; }
+                cst[j][r] = c;
+                hn_[row * LDA + col] = h;
+                if (row < nact) {
+                    const long q = p0 + row;
+                    a.Hout[q * H + col] = h;
+                    a.aux[q * H + col] = c;
+                    float* gp = a.gates + q * GH + col;
+                    gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
+                }
+            }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+template <int J>
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(RnnArgs a) {
+    constexpr int H = 64 * J, GH = 4 * H, LDP = GH + 2, KB = GH / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    ROWCOL_SETUP();
+    float* dp = smem;
+    const float* pk = a.pk0 + (size_t)w * GH * (16 * J);
+    WaveGemm<J> gm;
+    float dhc[J][4], dcc[J][4];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { dhc[j][r] = 0.f; dcc[j][r] = 0.f; }
+    int tb = 0;
+    while (tb < a.T && a.step_off[tb + 1] - a.step_off[tb] > r0) ++tb;
+    for (int t = tb - 1; t >= 0; --t) {
+        const int o0 = a.step_off[t], bt = a.step_off[t + 1] - o0;
+        const int nact = min(16, bt - r0);
+        const long p0 = (long)o0 + r0;
+        const long pp0 = t > 0 ? (long)a.step_off[t - 1] + r0 : -1;
+        gm.preload(pk, lane);
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * rq + r, col = cbase + 16 * j;
+                float dpi = 0.f, dpf = 0.f, dpc = 0.f, dpo = 0.f;
+                if (row < nact) {
+                    const long q = p0 + row;
+                    const float* gp = a.gatesR + q * GH + col;
+                    const float gi = gp[0], gf = gp[H], gg = gp[2 * H], go = gp[3 * H];
+                    const float cn = a.auxR[q * H + col];
+                    const float cp = pp0 >= 0 ? a.auxR[(pp0 + row) * H + col] : 0.f;
+                    const float dh = dhc[j][r] + a.dHout[q * H + col];
+                    const float ac = act_f(a.act, cn);
+                    const float dct = dcc[j][r] + dh * go * act_g(a.act, ac);
+                    dpi = dct * gg * hard_sigmoid_grad(gi);
+                    dpf = dct * cp * hard_sigmoid_grad(gf);
+                    dpc = dct * gi * act_g(a.act, gg);
+                    dpo = dh * ac * hard_sigmoid_grad(go);
+                    dcc[j][r] = dct * gf;
+                    float* o = a.dPre + q * GH + col;
+                    o[0] = dpi; o[H] = dpf; o[2 * H] = dpc; o[3 * H] = dpo;
+                } else {
+                    dcc[j][r] = 0.f;
+                }
+                float* d = dp + row * LDP + col;
+                d[0] = dpi; d[H] = dpf; d[2 * H] = dpc; d[3 * H] = dpo;
+            }
+        __syncthreads();
+        f32x4 acc[J];
+        zero_acc(acc);
+        gm.run(dp, LDP, pk, KB, lane, acc);
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dhc[j][r] = acc[j][r];
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// GRU (Keras 2.0: z,r,h; h~ = act(x_h + (r*h_prev).U_h); h = z*h_prev + (1-z)*h~)
+// ------------------------------------------------------------------------------------------
+template <int J>
+__global__ __launch_bounds__(256) void gru_fwd_kernel(RnnArgs a) {
+    constexpr int H = 64 * J, LDA = H + 2, KB = H / 4, GH = 3 * H;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    ROWCOL_SETUP();
+    float* hb = smem;
+    float* rhb = smem + 16 * LDA;
+    for (int i = tid; i < 32 * LDA; i += 256) smem[i] = 0.f;
+    __syncthreads();
+    const float* pk_zr = a.pk0 + (size_t)w * H * (32 * J);
+    const float* pk_h = a.pk1 + (size_t)w * H * (16 * J);
+    WaveGemm<2 * J> g1;
+    WaveGemm<J> g2;
+    for (int t = 0; t < a.T; ++t) {
+        const int o0 = a.step_off[t], bt = a.step_off[t + 1] - o0;
+        if (bt <= r0) break;
+        const int nact = min(16, bt - r0);
+        const long p0 = (long)o0 + r0;
+        g1.preload(pk_zr, lane);
+        float x[3][J][4];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * rq + r;
+                    x[g][j][r] = row < nact ? a.XW[(p0 + row) * GH + g * H + cbase + 16 * j] : 0.f;
+                }
+        f32x4 acc1[2 * J];
+        zero_acc(acc1);
+        g1.run(hb, LDA, pk_zr, KB, lane, acc1);
+        g2.preload(pk_h, lane);
+        float zr[J][4], hp[J][4];
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * rq + r, col = cbase + 16 * j;
+                const float z = hard_sigmoid(acc1[j][r] + x[0][j][r]);
+                const float rr = hard_sigmoid(acc1[J + j][r] + x[1][j][r]);
+                const float h0 = hb[row * LDA + col];
+                const float rh = rr * h0;
+                zr[j][r] = z;
+                hp[j][r] = h0;
+                rhb[row * LDA + col] = rh;
+                if (row < nact) {
+                    const long q = p0 + row;
+                    a.gates[q * GH + col] = z;
+                    a.gates[q * GH + H + col] = rr;
+                    a.aux[q * H + col] = rh;
+                }
+            }
+        __syncthreads();
+        f32x4 acc2[J];
+        zero_acc(acc2);
+        g2.run(rhb, LDA, pk_h, KB, lane, acc2);
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * rq + r, col = cbase + 16 * j;
+                const float hh = act_f(a.act, acc2[j][r] + x[2][j][r]);
+                float hn = zr[j][r] * hp[j][r] + (1.f - zr[j][r]) * hh;
+                if (col >= a.H_real) hn = 0.f;
+                hb[row * LDA + col] = hn;
+                if (row < nact) {
+                    const long q = p0 + row;
+                    a.Hout[q * H + col] = hn;
+                    a.gates[q * GH + 2 * H + col] = hh;
+                }
+            }
+        __syncthreads();
+    }
+}
+
+template <int J>
+__global__ __launch_bounds__(256) void gru_bwd_kernel(RnnArgs a) {
+    constexpr int H = 64 * J, GH = 3 * H, LD1 = H + 2, LD2 = 2 * H + 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    ROWCOL_SETUP();
+    float* dph = smem;                 // [16][H+2]   dpre_h           (A of GEMM 1)
+    float* dpzr = smem + 16 * LD1;     // [16][2H+2]  dpre_z | dpre_r  (A of GEMM 2)
+    const float* pk_hT = a.pk0 + (size_t)w * H * (16 * J);
+    const float* pk_zrT = a.pk1 + (size_t)w * (2 * H) * (16 * J);
+    WaveGemm<J> g1, g2;
+    float dhc[J][4];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dhc[j][r] = 0.f;
+    int tb = 0;
+    while (tb < a.T && a.step_off[tb + 1] - a.step_off[tb] > r0) ++tb;
+    for (int t = tb - 1; t >= 0; --t) {
+        const int o0 = a.step_off[t], bt = a.step_off[t + 1] - o0;
+        const int nact = min(16, bt - r0);
+        const long p0 = (long)o0 + r0;
+        const long pp0 = t > 0 ? (long)a.step_off[t - 1] + r0 : -1;
+        g1.preload(pk_hT, lane);
+        float zv[J][4], rv[J][4], hpv[J][4], dzv[J][4], dcar[J][4];
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * rq + r, col = cbase + 16 * j;
+                float z = 0.f, rr = 0.f, h0 = 0.f, dz = 0.f, dc = 0.f, d = 0.f;
+                if (row < nact) {
+                    const long q = p0 + row;
+                    z = a.gatesR[q * GH + col];
+                    rr = a.gatesR[q * GH + H + col];
+                    const float hh = a.gatesR[q * GH + 2 * H + col];
+                    h0 = pp0 >= 0 ? a.HoutR[(pp0 + row) * H + col] : 0.f;
+                    const float dh = dhc[j][r] + a.dHout[q * H + col];
+                    dz = dh * (h0 - hh);
+                    dc = dh * z;
+                    d = dh * (1.f - z) * act_g(a.act, hh);
+                    a.dPre[q * GH + 2 * H + col] = d;
+                }
+                zv[j][r] = z; rv[j][r] = rr; hpv[j][r] = h0; dzv[j][r] = dz; dcar[j][r] = dc;
+                dph[row * LD1 + col] = d;
+            }
+        __syncthreads();
+        f32x4 acc1[J];
+        zero_acc(acc1);
+        g1.run(dph, LD1, pk_hT, H / 4, lane, acc1);
+        g2.preload(pk_zrT, lane);
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * rq + r, col = cbase + 16 * j;
+                const float drh = acc1[j][r];
+                const float dr = drh * hpv[j][r];
+                dcar[j][r] += drh * rv[j][r];
+                const float dpz = dzv[j][r] * hard_sigmoid_grad(zv[j][r]);
+                const float dpr = dr * hard_sigmoid_grad(rv[j][r]);
+                dpzr[row * LD2 + col] = dpz;
+                dpzr[row * LD2 + H + col] = dpr;
+                if (row < nact) {
+                    const long q = p0 + row;
+                    a.dPre[q * GH + col] = dpz;
+                    a.dPre[q * GH + H + col] = dpr;
+                }
+            }
+        __syncthreads();
+        f32x4 acc2[J];
+        zero_acc(acc2);
+        g2.run(dpzr, LD2, pk_zrT, (2 * H) / 4, lane, acc2);
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dhc[j][r] = dcar[j][r] + acc2[j][r];
+        // the next iteration's first LDS write (dph) is fenced from this GEMM-2's reads of dpzr by
+        // its own barrier; dph itself was last read before the barrier above.
+    }
+}
+
+int set_lds(const void* fn, size_t bytes) {
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+int launch_pack(const float* U, int ldu, int H, int mode, int ng, int g0, int g1, int g2, int g3, float* out,
+                hipStream_t st) {
+    const long total = (long)(ng * H) * H;   // both modes: K * N = ng*H*H floats
+    int blocks = (int)min((long)1024, (total + 255) / 256);
+    hipLaunchKernelGGL(pack_u_kernel, dim3(blocks), dim3(256), 0, st, U, ldu, H, mode, ng, g0, g1, g2, g3, out);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+
+#define DISPATCH_J(KERNEL, LDS_BYTES)                                                                      \
+    do {                                                                                                   \
+        const size_t lds__ = (LDS_BYTES);                                                                  \
+        int rc__ = 0;                                                                                      \
+        switch (J) {                                                                                       \
+            case 1: rc__ = set_lds((const void*)KERNEL<1>, lds__); if (!rc__) hipLaunchKernelGGL(KERNEL<1>, grid, dim3(256), lds__, st, a); break; \
+            case 2: rc__ = set_lds((const void*)KERNEL<2>, lds__); if (!rc__) hipLaunchKernelGGL(KERNEL<2>, grid, dim3(256), lds__, st, a); break; \
+            case 4: rc__ = set_lds((const void*)KERNEL<4>, lds__); if (!rc__) hipLaunchKernelGGL(KERNEL<4>, grid, dim3(256), lds__, st, a); break; \
+            case 8: rc__ = set_lds((const void*)KERNEL<8>, lds__); if (!rc__) hipLaunchKernelGGL(KERNEL<8>, grid, dim3(256), lds__, st, a); break; \
+            default: return SEQREC_E_SHAPE;                                                                \
+        }                                                                                                  \
+        if (rc__) return rc__;                                                                             \
+        SEQREC_LAUNCH_CHECK();                                                                             \
+    } while (0)
+
+bool check_common(int cell, int act, int H, int H_real, int T, int B) {
+    if (cell < 0 || cell > 2 || act < 0 || act > 2) return false;
+    if (!(H == 64 || H == 128 || H == 256 || H == 512)) return false;
+    if (H_real < 1 || H_real > H || T < 0 || B < 0) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int64_t seqrec_rnn_upack_floats(int cell, int H) {
+    const int G = cell == SEQREC_CELL_LSTM ? 4 : (cell == SEQREC_CELL_GRU ? 3 : 1);
+    return (int64_t)G * H * H;
+}
+
+extern "C" int seqrec_rnn_fwd(int cell, int act, int H, int H_real, int T, int B, const int32_t* step_off,
+                              const float* XW, const float* U, float* Hout, float* gates, float* aux,
+                              float* upack, void* stream) {
+    if (!check_common(cell, act, H, H_real, T, B)) return SEQREC_E_SHAPE;
+    if (T == 0 || B == 0) return 0;
+    if (!step_off || !XW || !U || !Hout || !upack) return SEQREC_E_ARG;
+    if (cell != SEQREC_CELL_SIMPLERNN && (!gates || !aux)) return SEQREC_E_ARG;
+    hipStream_t st = as_stream(stream);
+    const int J = H / 64;
+    RnnArgs a = {};
+    a.step_off = step_off; a.T = T; a.B = B; a.H_real = H_real; a.act = act;
+    a.XW = XW; a.Hout = Hout; a.gates = gates; a.aux = aux;
+    dim3 grid((B + 15) / 16);
+    int rc;
+    if (cell == SEQREC_CELL_SIMPLERNN) {
+        if ((rc = launch_pack(U, H, H, 0, 1, 0, 0, 0, 0, upack, st))) return rc;
+        a.pk0 = upack;
+        DISPATCH_J(srnn_fwd_kernel, (size_t)32 * (H + 2) * 4);
+    } else if (cell == SEQREC_CELL_LSTM) {
+        if ((rc = launch_pack(U, 4 * H, H, 0, 4, 0, 1, 2, 3, upack, st))) return rc;
+        a.pk0 = upack;
+        DISPATCH_J(lstm_fwd_kernel, (size_t)32 * (H + 2) * 4);
+    } else {
+        if ((rc = launch_pack(U, 3 * H, H, 0, 2, 0, 1, 0, 0, upack, st))) return rc;
+        if ((rc = launch_pack(U, 3 * H, H, 0, 1, 2, 0, 0, 0, upack + (size_t)2 * H * H, st))) return rc;
+        a.pk0 = upack; a.pk1 = upack + (size_t)2 * H * H;
+        DISPATCH_J(gru_fwd_kernel, (size_t)32 * (H + 2) * 4);
+    }
+    return 0;
+}
+
+extern "C" int seqrec_rnn_bwd(int cell, int act, int H, int H_real, int T, int B, const int32_t* step_off,
+                              const float* dHout, const float* Hout, const float* gates, const float* aux,
+                              const float* U, float* dPre, float* upack, void* stream) {
+    if (!check_common(cell, act, H, H_real, T, B)) return SEQREC_E_SHAPE;
+    if (T == 0 || B == 0) return 0;
+    if (!step_off || !dHout || !Hout || !U || !dPre || !upack) return SEQREC_E_ARG;
+    if (cell != SEQREC_CELL_SIMPLERNN && (!gates || !aux)) return SEQREC_E_ARG;
+    hipStream_t st = as_stream(stream);
+    const int J = H / 64;
+    RnnArgs a = {};
+    a.step_off = step_off; a.T = T; a.B = B; a.H_real = H_real; a.act = act;
+    a.dHout = dHout; a.HoutR = Hout; a.gatesR = gates; a.auxR = aux; a.dPre = dPre;
+    dim3 grid((B + 15) / 16);
+    int rc;
+    if (cell == SEQREC_CELL_SIMPLERNN) {
+        if ((rc = launch_pack(U, H, H, 1, 1, 0, 0, 0, 0, upack, st))) return rc;
+        a.pk0 = upack;
+        DISPATCH_J(srnn_bwd_kernel, (size_t)16 * (H + 2) * 4);
+    } else if (cell == SEQREC_CELL_LSTM) {
+        if ((rc = launch_pack(U, 4 * H, H, 1, 4, 0, 1, 2, 3, upack, st))) return rc;
+        a.pk0 = upack;
+        DISPATCH_J(lstm_bwd_kernel, (size_t)16 * (4 * H + 2) * 4);
+    } else {
+        if ((rc = launch_pack(U, 3 * H, H, 1, 1, 2, 0, 0, 0, upack, st))) return rc;
+        if ((rc = launch_pack(U, 3 * H, H, 1, 2, 0, 1, 0, 0, upack + (size_t)H * H, st))) return rc;
+        a.pk0 = upack; a.pk1 = upack + (size_t)H * H;
+        DISPATCH_J(gru_bwd_kernel, (size_t)16 * (3 * H + 4) * 4);
+    }
+    return 0;
+}

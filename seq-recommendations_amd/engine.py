@@ -1,0 +1,513 @@
+"""Device engine: parameters in HBM + the kernel sequence of one training / evaluation step.
+
+Counterpart of what Keras' ``Model.train_function`` / ``test_function`` /
+``predict_function`` do for the graphs built in ``model.py:241-258`` and
+``model.py:322-403``: every arithmetic op is a call into
+libseqrec_hip.so (``include/seqrec_hip.h``); torch is used for device memory,
+streams and (in ``distributed.py``) collectives only.
+
+HBM layout
+  * hidden size is zero-padded to Hp in {64,128,256,512}; gate g of a G-gate kernel
+    occupies columns [g*Hp, g*Hp+H).  Padded units stay exactly zero (zero
+    weights -> zero pre-activations -> zero state and zero gradients).
+  * item tables (E, Eout, one-hot input kernel Wk, output bias) are row-major with
+    one row per item; each has an Adagrad accumulator AND a gradient table of the
+    same shape that is all-zero between steps, plus an int32 owner slot per row --
+    the row-sparse update touches only the rows of the batch (exactly equivalent to
+    the reference's dense Adagrad, experiments_methods.py:41).  Sized for 288 GB HBM:
+    3x table bytes per table (c3: 2 tables x 3 x 0.95 GiB).
+  * activations are token-major [N_tok, width] in the time-major packed order of
+    ``batching.RaggedBatch``.
+"""
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import CELL, ACT, N_GATES, ptr, call
+
+INT32_MAX = 2 ** 31 - 1
+
+
+def _pad_h(H):
+    for c in (64, 128, 256, 512):
+        if H <= c:
+            return c
+    raise ValueError("hidden size %d > 512 is not supported by the gfx950 scan kernels" % H)
+
+
+def _ceil4(n):
+    return (n + 3) // 4 * 4
+
+
+@dataclass
+class NetConfig:
+    cell: str = "lstm"            # 'simplernn' | 'lstm' | 'gru'
+    act: str = "relu"             # z_to_z_activation (model.py:243,324)
+    H: int = 64                   # z_dim
+    V_in: int = 17                # input width: vocabulary (ids) or feature count (dense)
+    V_out: int = 17               # n_classes
+    input: str = "onehot"         # 'onehot': XW = Wk[id] + b   'embed': (E[id]).W + b   'dense': x.Wk + b
+    D: int = 0                    # embedding width for input == 'embed'
+    output: str = "full"          # 'full' softmax | 'sampled' softmax
+    K: int = 0                    # shared negatives per step (sampled)
+    tied: bool = False            # Eout is E (needs D == H)
+    use_bias: bool = True         # z_bias
+    out_bias: bool = False        # toy_bias / Dense bias of RNNBaseline
+    drop_in: float = 0.0          # y_to_z_dropout
+    drop_rec: float = 0.0         # z_to_z_dropout (recurrent)
+    drop_out: float = 0.0         # z_to_y_dropout
+    logq: bool = False            # subtract log Q(item) from sampled logits
+    seed: int = 0                 # counter-RNG seed (negatives, dropout)
+
+    @property
+    def G(self):
+        return N_GATES[self.cell]
+
+
+class Engine:
+    def __init__(self, cfg: NetConfig, device="cuda:0"):
+        _lib.load()                                  # fail loudly without the HIP library
+        if not torch.cuda.is_available():
+            raise _lib.SeqrecError("no GPU visible: the seq-recommendations_amd engine needs an MI355X (no CPU fallback)")
+        self.cfg = cfg
+        self.dev = torch.device(device)
+        torch.cuda.set_device(self.dev)
+        c = cfg
+        if c.cell not in CELL or c.act not in ACT:
+            raise ValueError("unsupported cell/activation %r/%r" % (c.cell, c.act))
+        if c.drop_rec > 0:
+            raise NotImplementedError("recurrent (z_to_z) dropout is not implemented in the HIP scan yet")
+        self.Hp = _pad_h(c.H)
+        self.G = c.G
+        self.GHp = self.G * self.Hp
+        self.Dp = _ceil4(c.D) if c.input == "embed" else 0
+        self.Fp = _ceil4(c.V_in) if c.input == "dense" else c.V_in
+        self.Vp = _ceil4(c.V_out)
+        if c.tied:
+            if c.input != "embed" or c.output != "sampled" or c.D != c.H or c.V_in != c.V_out:
+                raise ValueError("tied tables need input='embed', output='sampled', D == H, V_in == V_out")
+            self.Dp = self.Hp
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        z = lambda *s: torch.zeros(*s, **f32)
+        P = {}
+        if c.input == "embed":
+            P["E"] = z(c.V_in, self.Dp)
+            P["W"] = z(self.Dp, self.GHp)
+        else:
+            P["Wk"] = z(self.Fp, self.GHp)
+        P["U"] = z(self.Hp, self.GHp)
+        if c.use_bias:
+            P["b"] = z(self.GHp)
+        if c.output == "full":
+            P["Wout"] = z(self.Hp, self.Vp)
+            if c.out_bias:
+                P["bout"] = z(self.Vp)
+        else:
+            if not c.tied:
+                P["Eout"] = z(c.V_out, self.Hp)
+            if c.out_bias:
+                P["bout"] = z(c.V_out)
+        self.P = P
+        self.table_params = set()
+        if c.input == "embed":
+            self.table_params.add("E")
+        if c.input == "onehot":
+            self.table_params.add("Wk")
+        if c.output == "sampled":
+            if not c.tied:
+                self.table_params.add("Eout")
+            if c.out_bias:
+                self.table_params.add("bout")
+        self.trainable = {k: True for k in P}
+        self.A = {k: torch.zeros_like(v) for k, v in P.items()}          # Adagrad accumulators
+        self.Gd = {k: torch.zeros_like(v) for k, v in P.items() if k not in self.table_params}
+        self.Gt = {k: torch.zeros_like(P[k]) for k in self.table_params}  # gradient tables (zero between steps)
+        self.slot = {k: torch.full((P[k].shape[0],), INT32_MAX, dtype=torch.int32, device=self.dev)
+                     for k in self.table_params}
+        self.ws = {}
+        self.sq = z(1)
+        self.scale = torch.ones(1, **f32)
+        self.loss_sum = z(1)
+        self.upack = torch.empty(int(_lib.load().seqrec_rnn_upack_floats(CELL[c.cell], self.Hp)), **f32)
+        self.sampler = None       # (thresh uint32-as-int32 tensor, alias int32 tensor, logq float tensor)
+        self.step_count = 0
+
+    # ------------------------------------------------------------------ utilities
+    def _stream(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def buf(self, name, *shape, dtype=torch.float32):
+        """Grow-only named workspace."""
+        n = int(np.prod(shape)) if shape else 1
+        t = self.ws.get(name)
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = torch.empty(max(n, 1), dtype=dtype, device=self.dev)
+            self.ws[name] = t
+        return t[:n].view(*shape) if shape else t[:1]
+
+    def gemm(self, a_kc, b_kc, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, accumulate=0, splitk=1):
+        wsp = None
+        if splitk > 1:
+            wsp = self.buf("gemm_ws", splitk * M * N)
+        call("seqrec_gemm_f32", int(a_kc), int(b_kc), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(Cm), ldc, ptr(bias),
+             accumulate, splitk, ptr(wsp), self._stream())
+
+    @staticmethod
+    def _splitk(M, N, K):
+        tiles = ((M + 63) // 64) * ((N + 63) // 64)
+        return int(max(1, min(32, 512 // max(tiles, 1), K // 128)))
+
+    # ------------------------------------------------------------------ parameters (Keras layouts)
+    def _gate_pad(self, w, rows_p):
+        """(rows, G*H) -> (rows_p, G*Hp) with each gate block placed at g*Hp."""
+        c = self.cfg
+        w = np.asarray(w, dtype=np.float32)
+        out = np.zeros((rows_p, self.GHp), np.float32)
+        for g in range(self.G):
+            out[: w.shape[0], g * self.Hp: g * self.Hp + c.H] = w[:, g * c.H:(g + 1) * c.H]
+        return out
+
+    def _gate_unpad(self, t, rows):
+        c = self.cfg
+        a = t.detach().cpu().numpy()
+        return np.concatenate([a[:rows, g * self.Hp: g * self.Hp + c.H] for g in range(self.G)], axis=1)
+
+    def set_param(self, name, value, accum=False):
+        """Load an UNPADDED array (Keras layout) into the padded device tensor."""
+        c = self.cfg
+        tgt = self.A if accum else self.P
+        v = np.asarray(value, dtype=np.float32)
+        if name in ("Wk", "W"):
+            rows_p = tgt[name].shape[0]
+            arr = self._gate_pad(v, rows_p)
+        elif name == "U":
+            arr = self._gate_pad(v, self.Hp)
+        elif name == "b":
+            arr = self._gate_pad(v[None, :], 1)[0]
+        elif name == "E":
+            arr = np.zeros(tuple(tgt[name].shape), np.float32)
+            arr[:, : v.shape[1]] = v
+        elif name == "Wout":
+            arr = np.zeros((self.Hp, self.Vp), np.float32)
+            arr[: c.H, : c.V_out] = v
+        elif name == "Eout":
+            arr = np.zeros((c.V_out, self.Hp), np.float32)
+            arr[:, : c.H] = v
+        elif name == "bout":
+            arr = np.zeros(tuple(tgt[name].shape), np.float32)
+            arr[: c.V_out] = v
+        else:
+            raise KeyError(name)
+        tgt[name].copy_(torch.from_numpy(arr))
+
+    def get_param(self, name, accum=False):
+        c = self.cfg
+        src = self.A if accum else self.P
+        t = src[name]
+        if name == "Wk":
+            return self._gate_unpad(t, c.V_in)
+        if name == "W":
+            return self._gate_unpad(t, c.D)
+        if name == "U":
+            return self._gate_unpad(t, c.H)
+        if name == "b":
+            return self._gate_unpad(t[None, :], 1)[0]
+        a = t.detach().cpu().numpy()
+        if name == "E":
+            return a[:, : (c.H if c.tied else c.D)].copy()
+        if name == "Wout":
+            return a[: c.H, : c.V_out].copy()
+        if name == "Eout":
+            return a[:, : c.H].copy()
+        if name == "bout":
+            return a[: c.V_out].copy()
+        raise KeyError(name)
+
+    def set_sampler(self, thresh, alias, logq=None):
+        """Alias table of the negative-sampling proposal (built on the host)."""
+        th = torch.from_numpy(np.asarray(thresh, dtype=np.uint32).view(np.int32).copy()).to(self.dev)
+        al = torch.from_numpy(np.asarray(alias, dtype=np.int32).copy()).to(self.dev)
+        lq = None if logq is None else torch.from_numpy(np.asarray(logq, dtype=np.float32).copy()).to(self.dev)
+        self.sampler = (th, al, lq)
+
+    # ------------------------------------------------------------------ batch upload
+    def upload(self, rb):
+        """Host RaggedBatch -> device index arrays (one pinned-free H2D copy of a single int32 blob)."""
+        c = self.cfg
+        n = rb.n_tok
+        parts = [rb.step_off.astype(np.int32), rb.prev.astype(np.int32)]
+        if rb.ids is not None:
+            parts.append(rb.ids.astype(np.int32))
+        if rb.tgt is not None:
+            parts.append(rb.tgt.astype(np.int32))
+        blob = torch.from_numpy(np.concatenate(parts)).to(self.dev, non_blocking=True)
+        o = 0
+        d = {"n": n, "T": rb.T, "B": rb.B, "rb": rb}
+        d["step_off"] = blob[o:o + rb.T + 1]; o += rb.T + 1
+        d["prev"] = blob[o:o + n]; o += n
+        if rb.ids is not None:
+            d["ids"] = blob[o:o + n]; o += n
+        if rb.tgt is not None:
+            d["tgt"] = blob[o:o + n]; o += n
+        if rb.x is not None:
+            x = np.zeros((n, self.Fp), np.float32)
+            x[:, : rb.x.shape[1]] = rb.x
+            d["x"] = torch.from_numpy(x).to(self.dev, non_blocking=True)
+        d["blob"] = blob
+        return d
+
+    def _drop_masks(self, d, step):
+        """Inverted-dropout multipliers for this step (counter RNG; oracle/rng.py)."""
+        c = self.cfg
+        rb = d["rb"]
+        n = d["n"]
+        st = self._stream()
+        out = {}
+        if c.drop_in > 0 or c.drop_out > 0:
+            key = (rb.tok_b.astype(np.int64) << 16) + rb.tok_s.astype(np.int64)
+        if c.drop_in > 0:
+            sid = _lib.STREAM_DROP_IN + 16 * (step + 1)
+            if c.input == "onehot":
+                rk = torch.from_numpy(key * c.V_in + rb.ids.astype(np.int64)).to(self.dev)
+                m = self.buf("in_scale", n)
+                call("seqrec_dropout_mask", c.seed, sid, ptr(rk), n, 1, 1, float(c.drop_in), ptr(m), st)
+            else:
+                w = c.D if c.input == "embed" else c.V_in
+                ld = self.Dp if c.input == "embed" else self.Fp
+                rk = torch.from_numpy(key).to(self.dev)
+                m = self.buf("in_mask", n, ld)
+                m.zero_()
+                call("seqrec_dropout_mask", c.seed, sid, ptr(rk), n, w, ld, float(c.drop_in), ptr(m), st)
+            out["in"] = m
+            out["_rk_in"] = rk
+        if c.drop_out > 0:
+            sid = _lib.STREAM_DROP_OUT + 16 * (step + 1)
+            rk = torch.from_numpy(key).to(self.dev)
+            m = self.buf("out_mask", n, self.Hp)
+            m.zero_()
+            call("seqrec_dropout_mask", c.seed, sid, ptr(rk), n, c.H, self.Hp, float(c.drop_out), ptr(m), st)
+            out["out"] = m
+            out["_rk_out"] = rk
+        return out
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, d, train=False, step=0, want_probs=False, negatives=None, stop_at_hidden=False):
+        """Runs the graph up to the loss.  Returns a dict of device tensors; in training
+        mode the gradient w.r.t. the logits is left in place of the logits."""
+        c, P = self.cfg, self.P
+        st = self._stream()
+        n, T, B = d["n"], d["T"], d["B"]
+        Hp, GHp = self.Hp, self.GHp
+        r = {}
+        if n == 0:
+            self.loss_sum.zero_()
+            return r
+        drops = self._drop_masks(d, step) if train else {}
+        r["drops"] = drops
+        XW = self.buf("XW", n, GHp)
+        bias = P.get("b")
+        if c.input == "onehot":
+            call("seqrec_gather_rows", ptr(P["Wk"]), ptr(d["ids"]), ptr(XW), n, GHp, ptr(drops.get("in")), ptr(bias), 0, st)
+        else:
+            if c.input == "embed":
+                X = self.buf("X", n, self.Dp)
+                call("seqrec_gather_rows", ptr(P["E"]), ptr(d["ids"]), ptr(X), n, self.Dp, None, None, 0, st)
+                Wm, Kd = P["W"], self.Dp
+            else:
+                X = d["x"]
+                Wm, Kd = P["Wk"], self.Fp
+            if "in" in drops:
+                Xd = self.buf("Xd", n, Kd)
+                call("seqrec_mul", ptr(X), ptr(drops["in"]), ptr(Xd), n * Kd, st)
+                X = Xd
+            r["X"] = X
+            self.gemm(1, 0, n, GHp, Kd, X, Kd, Wm, GHp, XW, GHp, bias=bias)
+        Hout = self.buf("Hout", n, Hp)
+        gates = self.buf("gates", n, GHp)
+        aux = self.buf("aux", n, Hp)
+        call("seqrec_rnn_fwd", CELL[c.cell], ACT[c.act], Hp, c.H, T, B, ptr(d["step_off"]), ptr(XW), ptr(P["U"]),
+             ptr(Hout), ptr(gates), ptr(aux), ptr(self.upack), st)
+        r.update(XW=XW, Hout=Hout, gates=gates, aux=aux)
+        Hd = Hout
+        if "out" in drops:
+            Hd = self.buf("Hd", n, Hp)
+            call("seqrec_mul", ptr(Hout), ptr(drops["out"]), ptr(Hd), n * Hp, st)
+        r["Hd"] = Hd
+        if stop_at_hidden:
+            return r
+        tgt = d.get("tgt")
+        loss_rows = self.buf("loss_rows", n)
+        inv = 1.0 / n
+        if c.output == "full":
+            Vp = self.Vp
+            logits = self.buf("logits", n, Vp)
+            self.gemm(1, 0, n, c.V_out, Hp, Hd, Hp, P["Wout"], Vp, logits, Vp, bias=P.get("bout"))
+            probs = self.buf("probs", n, c.V_out) if want_probs else None
+            call("seqrec_full_softmax_ce", ptr(logits), Vp, ptr(tgt), n, c.V_out, inv, ptr(loss_rows), ptr(probs), st)
+            r["dlogits"] = logits
+            r["probs"] = probs
+        else:
+            K = c.K
+            Et = P["E"] if c.tied else P["Eout"]
+            th, al, lq = self.sampler
+            if negatives is None:
+                neg = self.buf("neg", K, dtype=torch.int32)
+                call("seqrec_sample_negatives", int(c.seed), int(step), K, ptr(th), ptr(al), c.V_out, ptr(neg), st)
+            else:
+                neg = negatives
+            Eneg = self.buf("Eneg", K, Hp)
+            call("seqrec_gather_rows", ptr(Et), ptr(neg), ptr(Eneg), K, Hp, None, None, 0, st)
+            ln = self.buf("ln", n, K)
+            self.gemm(1, 1, n, K, Hp, Hd, Hp, Eneg, Hp, ln, K)
+            dlt = self.buf("dlt", n)
+            call("seqrec_sampled_softmax_ce", ptr(ln), K, ptr(Hd), Hp, ptr(Et), ptr(P.get("bout")),
+                 ptr(lq if c.logq else None), ptr(tgt), ptr(neg), n, K, inv, ptr(loss_rows), ptr(dlt), st)
+            r.update(neg=neg, Eneg=Eneg, dln=ln, dlt=dlt)
+        if tgt is not None:
+            call("seqrec_reduce_sum", ptr(loss_rows), n, ptr(self.loss_sum), 0, st)
+        return r
+
+    # ------------------------------------------------------------------ training step
+    def train_step(self, d, lr=0.01, eps=1e-8, clipnorm=1.0, step=None, negatives=None):
+        """One full step on an uploaded batch: forward, masked-mean CE, BPTT, global-norm clip,
+        Adagrad.  Returns the batch loss as a 1-element device tensor (no host sync)."""
+        c, P = self.cfg, self.P
+        if step is None:
+            step = self.step_count
+        self.step_count = step + 1
+        n, T, B = d["n"], d["T"], d["B"]
+        if n == 0:
+            return torch.zeros(1, device=self.dev)
+        st = self._stream()
+        Hp, GHp = self.Hp, self.GHp
+        r = self.forward(d, train=True, step=step, negatives=negatives)
+        drops = r["drops"]
+        Hd = r["Hd"]
+        Gd, Gt = self.Gd, self.Gt
+        tr = self.trainable
+        sparse_jobs = []     # (param, rows tensor, n_rows, width, base) -- scatter lists of this step
+        dHd = self.buf("dHd", n, Hp)
+        cs_ws = self.buf("colsum_ws", 64 * max(GHp, self.Vp, c.K if c.output == "sampled" else 1))
+        if c.output == "full":
+            Vp = self.Vp
+            dl = r["dlogits"]
+            if tr["Wout"]:
+                self.gemm(0, 0, Hp, c.V_out, n, Hd, Hp, dl, Vp, Gd["Wout"], Vp, splitk=self._splitk(Hp, c.V_out, n))
+            if c.out_bias and tr["bout"]:
+                call("seqrec_colsum", ptr(dl), n, c.V_out, Vp, ptr(Gd["bout"]), 0, ptr(cs_ws), st)
+            self.gemm(1, 1, n, Hp, c.V_out, dl, Vp, P["Wout"], Vp, dHd, Hp)
+        else:
+            K = c.K
+            tname = "E" if c.tied else "Eout"
+            Et = P[tname]
+            dln, dlt, neg, Eneg = r["dln"], r["dlt"], r["neg"], r["Eneg"]
+            self.gemm(1, 0, n, Hp, K, dln, K, Eneg, Hp, dHd, Hp)
+            call("seqrec_gather_rows", ptr(Et), ptr(d["tgt"]), ptr(dHd), n, Hp, ptr(dlt), None, 1, st)
+            if tr[tname]:
+                dEneg = self.buf("dEneg", K, Hp)
+                self.gemm(0, 0, K, Hp, n, dln, K, Hd, Hp, dEneg, Hp, splitk=self._splitk(K, Hp, n))
+                base_t, base_n = 0, n
+                call("seqrec_rows_scatter_add", ptr(Gt[tname]), ptr(self.slot[tname]), ptr(d["tgt"]), ptr(Hd), Hp,
+                     ptr(dlt), n, Hp, base_t, st)
+                call("seqrec_rows_scatter_add", ptr(Gt[tname]), ptr(self.slot[tname]), ptr(neg), ptr(dEneg), Hp,
+                     None, K, Hp, base_n, st)
+                sparse_jobs.append((tname, d["tgt"], n, Hp, base_t))
+                sparse_jobs.append((tname, neg, K, Hp, base_n))
+            if c.out_bias and tr["bout"]:
+                dbn = self.buf("dbn", K)
+                call("seqrec_colsum", ptr(dln), n, K, K, ptr(dbn), 0, ptr(cs_ws), st)
+                call("seqrec_rows_scatter_add", ptr(Gt["bout"]), ptr(self.slot["bout"]), ptr(d["tgt"]), ptr(dlt), 1,
+                     None, n, 1, 0, st)
+                call("seqrec_rows_scatter_add", ptr(Gt["bout"]), ptr(self.slot["bout"]), ptr(neg), ptr(dbn), 1,
+                     None, K, 1, n, st)
+                sparse_jobs.append(("bout", d["tgt"], n, 1, 0))
+                sparse_jobs.append(("bout", neg, K, 1, n))
+        dHout = dHd
+        if "out" in drops:
+            call("seqrec_mul", ptr(dHd), ptr(drops["out"]), ptr(dHd), n * Hp, st)
+        dPre = self.buf("dPre", n, GHp)
+        call("seqrec_rnn_bwd", CELL[c.cell], ACT[c.act], Hp, c.H, T, B, ptr(d["step_off"]), ptr(dHout), ptr(r["Hout"]),
+             ptr(r["gates"]), ptr(r["aux"]), ptr(P["U"]), ptr(dPre), ptr(self.upack), st)
+        if c.use_bias and tr["b"]:
+            call("seqrec_colsum", ptr(dPre), n, GHp, GHp, ptr(Gd["b"]), 0, ptr(cs_ws), st)
+        if tr["U"]:
+            Hprev = self.buf("Hprev", n, Hp)
+            call("seqrec_gather_rows", ptr(r["Hout"]), ptr(d["prev"]), ptr(Hprev), n, Hp, None, None, 0, st)
+            sk = self._splitk(Hp, GHp, n)
+            if c.cell == "gru":
+                self.gemm(0, 0, Hp, 2 * Hp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp, splitk=sk)
+                self.gemm(0, 0, Hp, Hp, n, r["aux"], Hp, dPre[:, 2 * Hp:], GHp, Gd["U"][:, 2 * Hp:], GHp, splitk=sk)
+            else:
+                self.gemm(0, 0, Hp, GHp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp, splitk=sk)
+        if c.input == "onehot":
+            if tr["Wk"]:
+                call("seqrec_rows_scatter_add", ptr(Gt["Wk"]), ptr(self.slot["Wk"]), ptr(d["ids"]), ptr(dPre), GHp,
+                     ptr(drops.get("in")), n, GHp, 0, st)
+                sparse_jobs.append(("Wk", d["ids"], n, GHp, 0))
+        else:
+            X = r["X"]
+            Kd = X.shape[1]
+            wname = "W" if c.input == "embed" else "Wk"
+            if tr[wname]:
+                self.gemm(0, 0, Kd, GHp, n, X, Kd, dPre, GHp, Gd[wname], GHp, splitk=self._splitk(Kd, GHp, n))
+            if c.input == "embed" and tr["E"]:
+                dX = self.buf("dX", n, self.Dp)
+                self.gemm(1, 1, n, self.Dp, GHp, dPre, GHp, P["W"], GHp, dX, self.Dp)
+                if "in" in drops:
+                    call("seqrec_mul", ptr(dX), ptr(drops["in"]), ptr(dX), n * self.Dp, st)
+                base_i = (n + c.K) if c.tied else 0
+                call("seqrec_rows_scatter_add", ptr(Gt["E"]), ptr(self.slot["E"]), ptr(d["ids"]), ptr(dX), self.Dp,
+                     None, n, self.Dp, base_i, st)
+                sparse_jobs.append(("E", d["ids"], n, self.Dp, base_i))
+        # ---- global-norm clip over every trainable tensor (Keras clipnorm), then Adagrad
+        self.sq.zero_()
+        for k, g in Gd.items():
+            if tr[k]:
+                call("seqrec_sqnorm", ptr(g), g.numel(), ptr(self.sq), st)
+        for (k, rows, nr, w, base) in sparse_jobs:
+            call("seqrec_rows_sqnorm", ptr(Gt[k]), ptr(self.slot[k]), ptr(rows), nr, w, base, ptr(self.sq), st)
+        call("seqrec_clip_scale", ptr(self.sq), float(clipnorm if clipnorm else 0.0), ptr(self.scale), st)
+        for k, g in Gd.items():
+            if tr[k]:
+                call("seqrec_adagrad_dense", ptr(P[k]), ptr(self.A[k]), ptr(g), g.numel(), lr, eps, ptr(self.scale), st)
+        for (k, rows, nr, w, base) in sparse_jobs:
+            call("seqrec_rows_adagrad", ptr(P[k]), ptr(self.A[k]), ptr(Gt[k]), ptr(self.slot[k]), ptr(rows), nr, w, base,
+                 lr, eps, ptr(self.scale), st)
+        return self.loss_sum / n
+
+    # ------------------------------------------------------------------ evaluation / prediction
+    def eval_loss(self, d, negatives=None, step=0):
+        """Masked-token-mean CE of one batch (Keras test_function); device tensor."""
+        if d["n"] == 0:
+            return torch.zeros(1, device=self.dev)
+        self.forward(d, train=False, step=step, negatives=negatives)
+        return self.loss_sum / d["n"]
+
+    def predict_rows(self, d):
+        """Softmax probabilities per real token, [N_tok, V_out] (full softmax only)."""
+        if self.cfg.output != "full":
+            raise ValueError("dense probabilities exist only for output='full'; use rank_counts/recall for sampled models")
+        dd = dict(d)
+        dd.pop("tgt", None)
+        r = self.forward(dd, train=False, want_probs=True)
+        return r["probs"]
+
+    def hidden_rows(self, d):
+        r = self.forward(d, train=False, stop_at_hidden=True)
+        return r["Hd"]
+
+    def rank_counts(self, d):
+        """rank[i] = number of items scoring strictly above the target of token i (sampled/tied
+        output tables; score = h . Eout[v] + bout[v]).  Recall@K = mean(rank < K)."""
+        c, P = self.cfg, self.P
+        n = d["n"]
+        Hd = self.hidden_rows(d)
+        Et = P["E"] if c.tied else P["Eout"]
+        rank = torch.zeros(n, dtype=torch.int32, device=self.dev)
+        thr = self.buf("thr", n)
+        call("seqrec_rank_count", ptr(Hd), self.Hp, ptr(Et), ptr(P.get("bout")), ptr(d["tgt"]), n, c.V_out, ptr(rank),
+             ptr(thr), self._stream())
+        return rank

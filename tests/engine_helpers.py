@@ -1,0 +1,115 @@
+"""Drive the HIP engine and the oracle through identical training steps (GPU tests, smoke)."""
+import importlib
+
+import numpy as np
+
+from oracle import nn as onn
+from oracle import rng as orng
+from helpers import pad_batch
+
+
+def lib():
+    return importlib.import_module("seq-recommendations_amd")
+
+
+def make_cfg(cell="gru", act="relu", H=64, V=50, inp="onehot", out="full", D=0, K=0, tied=False,
+             use_bias=True, out_bias=False, drop_in=0.0, drop_out=0.0, logq=False, seed=3):
+    E = importlib.import_module("seq-recommendations_amd.engine")
+    ecfg = E.NetConfig(cell=cell, act=act, H=H, V_in=V, V_out=V, input=inp, D=D, output=out, K=K, tied=tied,
+                       use_bias=use_bias, out_bias=out_bias, drop_in=drop_in, drop_out=drop_out, logq=logq, seed=seed)
+    ocfg = dict(cell=cell, act=act, input=inp, output=out, tied=tied, use_bias=use_bias, out_bias=out_bias)
+    return ecfg, ocfg
+
+
+def init_np_params(rng, ocfg, V, H, D, scale=None):
+    G = onn.N_GATES[ocfg["cell"]]
+    s = scale or 0.5 / np.sqrt(H)
+    p = {}
+    if ocfg["input"] == "embed":
+        p["E"] = rng.normal(0, 0.3, (V, D))
+        p["W"] = rng.normal(0, 0.5 / np.sqrt(D), (D, G * H))
+    else:
+        p["Wk"] = rng.normal(0, 0.4, (V, G * H))
+    p["U"] = rng.normal(0, s, (H, G * H))
+    if ocfg.get("use_bias", True):
+        p["b"] = rng.normal(0, 0.1, (G * H,))
+    if ocfg["output"] == "full":
+        p["Wout"] = rng.normal(0, 0.5 / np.sqrt(H), (H, V))
+    elif not ocfg.get("tied", False):
+        p["Eout"] = rng.normal(0, 0.3, (V, H))
+    if ocfg.get("out_bias", False):
+        p["bout"] = rng.normal(0, 0.1, (V,))
+    return {k: v.astype(np.float32) for k, v in p.items()}
+
+
+def oracle_drop(ecfg, sessions, batch, step):
+    """The explicit dropout multipliers the engine draws on the device (same counters)."""
+    if ecfg.drop_in <= 0 and ecfg.drop_out <= 0:
+        return None
+    mask = batch["mask"]
+    B, T = mask.shape
+    L = mask.sum(axis=1)
+    bi, ti = np.nonzero(mask)
+    s = ti - (T - L[bi])
+    key = orng.token_key(bi, s)
+    drop = {}
+    if ecfg.drop_in > 0:
+        sid = orng.dropout_stream(orng.STREAM_DROP_IN, step)
+        if ecfg.input == "onehot":
+            rk = key * np.uint64(ecfg.V_in) + batch["ids"][bi, ti].astype(np.uint64)
+            m = np.ones((B, T), np.float32)
+            m[bi, ti] = orng.dropout_mask(ecfg.seed, sid, rk, 1, ecfg.drop_in)[:, 0]
+        else:
+            w = ecfg.D
+            m = np.ones((B, T, w), np.float32)
+            m[bi, ti] = orng.dropout_mask(ecfg.seed, sid, key, w, ecfg.drop_in)
+        drop["in_scale"] = m
+    if ecfg.drop_out > 0:
+        sid = orng.dropout_stream(orng.STREAM_DROP_OUT, step)
+        m = np.ones((B, T, ecfg.H), np.float32)
+        m[bi, ti] = orng.dropout_mask(ecfg.seed, sid, key, ecfg.H, ecfg.drop_out)
+        drop["out_mask"] = m
+    return drop
+
+
+class Pair:
+    """An Engine and an OracleNet holding the same parameters."""
+
+    def __init__(self, ecfg, ocfg, params, device="cuda:0"):
+        E = importlib.import_module("seq-recommendations_amd.engine")
+        self.ecfg, self.ocfg = ecfg, ocfg
+        self.eng = E.Engine(ecfg, device)
+        for k, v in params.items():
+            self.eng.set_param(k, v)
+        self.op = {k: v.copy() for k, v in params.items()}
+        self.oa = {k: np.zeros_like(v) for k, v in params.items()}
+        self.net = onn.OracleNet(ocfg, self.op)
+        self.th = self.al = self.logq = None
+        if ocfg["output"] == "sampled":
+            probs = orng.log_uniform_probs(ecfg.V_out)
+            self.th, self.al = orng.build_alias_table(probs)
+            self.logq = np.log(probs).astype(np.float32)
+            self.eng.set_sampler(self.th, self.al, self.logq)
+
+    def step(self, sessions, step, lr=0.01, eps=1e-8, clipnorm=1.0):
+        B = importlib.import_module("seq-recommendations_amd.batching")
+        rb = B.pack_sessions(sessions)
+        d = self.eng.upload(rb)
+        lg = self.eng.train_step(d, lr=lr, eps=eps, clipnorm=clipnorm, step=step)
+        batch = pad_batch(sessions)
+        kw = {}
+        if self.ocfg["output"] == "sampled":
+            kw["negatives"] = orng.sample_negatives(self.ecfg.seed, step, self.ecfg.K, self.th, self.al)
+            kw["logq"] = self.logq if self.ecfg.logq else None
+        drop = oracle_drop(self.ecfg, sessions, batch, step)
+        out = self.net.forward(batch, drop=drop, **kw)
+        g = self.net.backward()
+        sc = onn.adagrad_step(self.op, self.oa, g, lr=lr, eps=eps, clipnorm=clipnorm)
+        return float(lg.item()), float(out["loss"]), sc
+
+    def max_param_diff(self):
+        out = {}
+        for k, v in self.op.items():
+            got = self.eng.get_param(k)
+            out[k] = float(np.abs(got - v).max() / max(1e-6, np.abs(v).max()))
+        return out

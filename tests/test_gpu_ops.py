@@ -1,0 +1,349 @@
+"""Op-level parity of the HIP kernels (through the C ABI) against numpy / the oracle.
+All tests need a real MI355X."""
+import ctypes
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nn as onn
+from oracle import rng as orng
+
+pytestmark = pytest.mark.gpu
+
+L = importlib.import_module("seq-recommendations_amd._lib")
+B_ = importlib.import_module("seq-recommendations_amd.batching")
+ptr, call = L.ptr, L.call
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def gemm(a_kc, b_kc, M, N, K, A, lda, Bm, ldb, Cm, ldc, bias=None, acc=0, splitk=1):
+    ws = torch.empty(max(1, splitk * M * N), device="cuda") if splitk > 1 else None
+    call("seqrec_gemm_f32", a_kc, b_kc, M, N, K, ptr(A), lda, ptr(Bm), ldb, ptr(Cm), ldc, ptr(bias), acc, splitk, ptr(ws), st())
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (64, 64, 16), (100, 17, 64), (300, 200, 70), (513, 257, 129),
+                                   (2603, 768, 256), (1500, 2000, 256)])
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 0), (1, 1), (0, 0), (0, 1)])
+def test_gemm_layouts(M, N, K, a_kc, b_kc):
+    rng = np.random.default_rng(M * 7 + N * 3 + K + a_kc * 2 + b_kc)
+    A = rng.normal(size=(M, K)).astype(np.float32)
+    Bm = rng.normal(size=(K, N)).astype(np.float32)
+    bias = rng.normal(size=N).astype(np.float32)
+    ref = A.astype(np.float64) @ Bm.astype(np.float64) + bias
+    Ad = dev(A if a_kc else A.T)
+    Bd = dev(Bm.T if b_kc else Bm)
+    C = torch.full((M, N), float("nan"), device="cuda")
+    gemm(a_kc, b_kc, M, N, K, Ad, K if a_kc else M, Bd, K if b_kc else N, C, N, bias=dev(bias))
+    err = np.abs(C.cpu().numpy() - ref).max()
+    assert err <= 2e-5 * max(1.0, np.sqrt(K)), err
+
+
+def test_gemm_is_exact_fp32_fma_chain_on_integers():
+    # small integers: every product and partial sum is exact -> bit-exact result; asymmetric B
+    # catches a transposed C write, A = I catches a wrong operand map.
+    rng = np.random.default_rng(0)
+    M, N, K = 96, 80, 48
+    A = rng.integers(-8, 9, size=(M, K)).astype(np.float32)
+    Bm = (np.arange(K)[:, None] * 3 + np.arange(N)[None, :] * 7 % 11 - 5).astype(np.float32)
+    for a_kc, b_kc in [(1, 0), (0, 1), (1, 1), (0, 0)]:
+        C = torch.zeros((M, N), device="cuda")
+        gemm(a_kc, b_kc, M, N, K, dev(A if a_kc else A.T), K if a_kc else M, dev(Bm.T if b_kc else Bm), K if b_kc else N, C, N)
+        np.testing.assert_array_equal(C.cpu().numpy(), A @ Bm)
+    I = np.eye(K, dtype=np.float32)
+    C = torch.zeros((K, N), device="cuda")
+    gemm(1, 0, K, N, K, dev(I), K, dev(Bm), N, C, N)
+    np.testing.assert_array_equal(C.cpu().numpy(), Bm)
+
+
+@pytest.mark.parametrize("splitk", [2, 7, 32])
+def test_gemm_splitk_accumulate_and_strided_views(splitk):
+    rng = np.random.default_rng(splitk)
+    M, N, K = 256, 512, 2603
+    A = rng.normal(size=(K, M)).astype(np.float32)          # stored K x M (a_kcontig = 0)
+    big = rng.normal(size=(K, 768)).astype(np.float32)
+    Bv = big[:, 256:]                                        # view: ldb = 768, N = 512
+    C0 = rng.normal(size=(M, 768)).astype(np.float32)
+    Cd = dev(C0)
+    bigd = dev(big)
+    gemm(0, 0, M, N, K, dev(A), M, bigd[:, 256:], 768, Cd[:, 256:], 768, acc=1, splitk=splitk)
+    ref = C0.copy().astype(np.float64)
+    ref[:, 256:] += A.T.astype(np.float64) @ Bv.astype(np.float64)
+    out = Cd.cpu().numpy()
+    np.testing.assert_array_equal(out[:, :256], C0[:, :256])
+    assert np.abs(out - ref).max() < 2e-3
+
+
+def test_gather_rows_bit_exact_and_variants():
+    rng = np.random.default_rng(1)
+    V, W, n = 5000, 256, 3001
+    tab = rng.normal(size=(V, W)).astype(np.float32)
+    ids = rng.integers(0, V, size=n).astype(np.int32)
+    ids[::97] = -1
+    out = torch.empty((n, W), device="cuda")
+    call("seqrec_gather_rows", ptr(dev(tab)), ptr(dev(ids)), ptr(out), n, W, None, None, 0, st())
+    ref = np.where(ids[:, None] >= 0, tab[np.maximum(ids, 0)], 0).astype(np.float32)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    sc = rng.normal(size=n).astype(np.float32)
+    bias = rng.normal(size=W).astype(np.float32)
+    call("seqrec_gather_rows", ptr(dev(tab)), ptr(dev(ids)), ptr(out), n, W, ptr(dev(sc)), ptr(dev(bias)), 1, st())
+    ref2 = ref + (ref * sc[:, None] + bias)
+    np.testing.assert_allclose(out.cpu().numpy(), ref2, rtol=1e-6, atol=1e-6)
+    # odd width (scalar path) and empty input
+    tab3 = rng.normal(size=(40, 17)).astype(np.float32)
+    ids3 = rng.integers(0, 40, size=9).astype(np.int32)
+    out3 = torch.empty((9, 17), device="cuda")
+    call("seqrec_gather_rows", ptr(dev(tab3)), ptr(dev(ids3)), ptr(out3), 9, 17, None, None, 0, st())
+    np.testing.assert_array_equal(out3.cpu().numpy(), tab3[ids3])
+    call("seqrec_gather_rows", ptr(dev(tab3)), ptr(dev(ids3)), ptr(out3), 0, 17, None, None, 0, st())
+
+
+def test_bad_arguments_are_rejected_before_launch():
+    lib = L.load()
+    assert lib.seqrec_gather_rows(None, None, None, 5, 8, None, None, 0, None) == -1
+    assert lib.seqrec_rnn_fwd(0, 0, 100, 100, 3, 4, None, None, None, None, None, None, None, None) == -2
+    assert lib.seqrec_gemm_f32(1, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, 0, 1, None, None) == -1
+
+
+def packed_scan_inputs(rng, cell, H, B, maxlen, V=50):
+    sess = [rng.integers(0, V, size=int(rng.integers(2, maxlen + 2))).tolist() for _ in range(B)]
+    rb = B_.pack_sessions(sess)
+    G = onn.N_GATES[cell]
+    XW = (rng.normal(size=(rb.n_tok, G * H)) * 0.7).astype(np.float32)
+    U = (rng.normal(size=(H, G * H)) * (0.6 / np.sqrt(H))).astype(np.float32)
+    return rb, XW, U
+
+
+def oracle_scan(cell, act, rb, XW, U, dH=None):
+    """Run oracle.nn's masked scan on the padded view of the packed batch."""
+    B, T, n = rb.B, rb.T, rb.n_tok
+    G = onn.N_GATES[cell]
+    H = U.shape[0]
+    step_off = rb.step_off
+    tok_t = rb.tok_s.astype(np.int64)
+    tok_bs = np.arange(n) - step_off[tok_t]
+    # post-padded is fine for the oracle: masked steps only carry state
+    xw = np.zeros((B, T, G * H), np.float64)
+    mask = np.zeros((B, T), bool)
+    xw[tok_bs, tok_t] = XW
+    mask[tok_bs, tok_t] = True
+    hs, caches = onn.rnn_forward(cell, act, xw, mask, U.astype(np.float64))
+    out = {"H": hs[tok_bs, tok_t]}
+    if dH is not None:
+        dhs = np.zeros((B, T, H))
+        dhs[tok_bs, tok_t] = dH
+        dxw, dU = onn.rnn_backward(cell, act, dhs, U.astype(np.float64), caches)
+        out["dPre"] = dxw[tok_bs, tok_t]
+        out["dU"] = dU
+    return out
+
+
+@pytest.mark.parametrize("cell", ["simplernn", "lstm", "gru"])
+@pytest.mark.parametrize("H,B,maxlen,act", [(64, 5, 6, "relu"), (64, 37, 12, "tanh"), (128, 100, 9, "relu"),
+                                            (256, 70, 20, "relu"), (512, 33, 7, "tanh"), (256, 512, 49, "tanh"),
+                                            (128, 40, 10, "linear")])
+def test_rnn_scan_forward_backward_vs_oracle(cell, H, B, maxlen, act):
+    rng = np.random.default_rng(H + B + maxlen)
+    rb, XW, U = packed_scan_inputs(rng, cell, H, B, maxlen)
+    n, G = rb.n_tok, onn.N_GATES[cell]
+    dH = (rng.normal(size=(n, H)) * 0.5).astype(np.float32)
+    ref = oracle_scan(cell, act, rb, XW, U, dH)
+    so = dev(rb.step_off)
+    Hout = torch.full((n, H), float("nan"), device="cuda")
+    gates = torch.full((n, G * H), float("nan"), device="cuda")
+    aux = torch.full((n, H), float("nan"), device="cuda")
+    up = torch.empty(int(L.load().seqrec_rnn_upack_floats(L.CELL[cell], H)), device="cuda")
+    XWd, Ud = dev(XW), dev(U)
+    call("seqrec_rnn_fwd", L.CELL[cell], L.ACT[act], H, H, rb.T, rb.B, ptr(so), ptr(XWd), ptr(Ud), ptr(Hout), ptr(gates),
+         ptr(aux), ptr(up), st())
+    got = Hout.cpu().numpy()
+    scale = max(1.0, np.abs(ref["H"]).max())
+    assert np.abs(got - ref["H"]).max() <= 3e-5 * scale, np.abs(got - ref["H"]).max()
+    dPre = torch.full((n, G * H), float("nan"), device="cuda")
+    call("seqrec_rnn_bwd", L.CELL[cell], L.ACT[act], H, H, rb.T, rb.B, ptr(so), ptr(dev(dH)), ptr(Hout), ptr(gates), ptr(aux),
+         ptr(Ud), ptr(dPre), ptr(up), st())
+    gp = dPre.cpu().numpy()
+    s2 = max(1.0, np.abs(ref["dPre"]).max())
+    # relu / hard_sigmoid kinks: a pre-activation within rounding of a kink may pick the other
+    # branch in fp32 -- allow a vanishing fraction of outliers, everything else tight.
+    bad = np.abs(gp - ref["dPre"]) > 1e-4 * s2
+    assert bad.mean() < 2e-4, (bad.mean(), np.abs(gp - ref["dPre"]).max())
+
+
+def test_rnn_scan_h_real_padding_keeps_padded_units_zero():
+    rng = np.random.default_rng(5)
+    H, Hr = 128, 100
+    rb, XW, U = packed_scan_inputs(rng, "lstm", H, 20, 8)
+    n = rb.n_tok
+    Hout = torch.empty((n, H), device="cuda"); gates = torch.empty((n, 4 * H), device="cuda"); aux = torch.empty((n, H), device="cuda")
+    up = torch.empty(4 * H * H, device="cuda")
+    call("seqrec_rnn_fwd", 1, 1, H, Hr, rb.T, rb.B, ptr(dev(rb.step_off)), ptr(dev(XW)), ptr(dev(U)), ptr(Hout), ptr(gates), ptr(aux), ptr(up), st())
+    h = Hout.cpu().numpy()
+    assert np.all(h[:, Hr:] == 0) and np.abs(h[:, :Hr]).max() > 0
+
+
+@pytest.mark.parametrize("n,V", [(1, 3), (77, 17), (300, 1000), (64, 4099)])
+def test_full_softmax_ce_vs_oracle(n, V):
+    rng = np.random.default_rng(n + V)
+    logits = (rng.normal(size=(n, V)) * 3).astype(np.float32)
+    logits[0, :] = 0
+    if n > 2:
+        logits[1, 0] = 60.0      # forces the clip branch when the target is another class
+    tgt = rng.integers(0, V, size=n).astype(np.int32)
+    if n > 2:
+        tgt[1] = 1 % V
+    ce, dlog, p = onn.full_softmax_ce(logits.astype(np.float64), tgt.astype(np.int64), n)
+    ce32, dlog32, _ = onn.full_softmax_ce(logits.copy(), tgt.astype(np.int64), n)
+    Vp = (V + 3) // 4 * 4
+    buf = torch.zeros((n, Vp), device="cuda"); buf[:, :V] = dev(logits)
+    lr = torch.empty(n, device="cuda"); pr = torch.empty((n, V), device="cuda")
+    call("seqrec_full_softmax_ce", ptr(buf), Vp, ptr(dev(tgt)), n, V, 1.0 / n, ptr(lr), ptr(pr), st())
+    np.testing.assert_allclose(pr.cpu().numpy(), p, atol=2e-6)
+    assert abs(lr.cpu().numpy().astype(np.float64).sum() - ce32) <= 2e-5 * max(1.0, abs(ce32))
+    np.testing.assert_allclose(buf[:, :V].cpu().numpy(), dlog32, atol=3e-6 / n + 1e-7)
+    # prediction-only mode leaves the logits alone
+    buf2 = torch.zeros((n, Vp), device="cuda"); buf2[:, :V] = dev(logits)
+    call("seqrec_full_softmax_ce", ptr(buf2), Vp, None, n, V, 0.0, None, ptr(pr), st())
+    np.testing.assert_array_equal(buf2[:, :V].cpu().numpy(), logits)
+
+
+@pytest.mark.parametrize("n,K,H,V", [(5, 7, 64, 30), (333, 2000, 256, 5000), (64, 100, 128, 100)])
+@pytest.mark.parametrize("bias,lq", [(False, False), (True, True)])
+def test_sampled_softmax_ce_vs_oracle(n, K, H, V, bias, lq):
+    rng = np.random.default_rng(n + K)
+    h = (rng.normal(size=(n, H)) * 0.5).astype(np.float32)
+    E = (rng.normal(size=(V, H)) * 0.3).astype(np.float32)
+    bout = rng.normal(size=V).astype(np.float32) if bias else None
+    logq = np.log(orng.log_uniform_probs(V)).astype(np.float32) if lq else None
+    tgt = rng.integers(0, V, size=n).astype(np.int32)
+    neg = rng.integers(0, V, size=K).astype(np.int32)
+    neg[:3] = tgt[0]           # accidental hits
+    ce, dh, dlt, dln, lt, ln = onn.sampled_softmax_ce(h, tgt.astype(np.int64), neg, E, bout, logq, n)
+    lnraw = h @ E[neg].T
+    lnd = dev(lnraw.astype(np.float32))
+    lr = torch.empty(n, device="cuda"); dltd = torch.empty(n, device="cuda")
+    call("seqrec_sampled_softmax_ce", ptr(lnd), K, ptr(dev(h)), H, ptr(dev(E)), ptr(dev(bout)) if bias else None,
+         ptr(dev(logq)) if lq else None, ptr(dev(tgt)), ptr(dev(neg)), n, K, 1.0 / n, ptr(lr), ptr(dltd), st())
+    assert abs(lr.cpu().numpy().astype(np.float64).sum() - ce) <= 3e-5 * max(1.0, abs(ce))
+    np.testing.assert_allclose(dltd.cpu().numpy(), dlt, atol=2e-6)
+    np.testing.assert_allclose(lnd.cpu().numpy(), dln, atol=2e-6)
+    assert np.all(lnd.cpu().numpy()[0, :3] == 0)
+
+
+def test_colsum_reduce_mul_fill():
+    rng = np.random.default_rng(2)
+    X = rng.normal(size=(2603, 768)).astype(np.float32)
+    out = torch.ones(768, device="cuda")
+    ws = torch.empty(64 * 768, device="cuda")
+    call("seqrec_colsum", ptr(dev(X)), 2603, 768, 768, ptr(out), 1, ptr(ws), st())
+    np.testing.assert_allclose(out.cpu().numpy(), 1 + X.astype(np.float64).sum(0), rtol=1e-5, atol=1e-4)
+    call("seqrec_colsum", ptr(dev(X)), 3, 17, 768, ptr(out), 0, ptr(ws), st())
+    np.testing.assert_allclose(out.cpu().numpy()[:17], X[:3, :17].sum(0), rtol=1e-6, atol=1e-6)
+    s = torch.zeros(1, device="cuda")
+    v = rng.normal(size=100001).astype(np.float32)
+    call("seqrec_reduce_sum", ptr(dev(v)), v.size, ptr(s), 0, st())
+    assert abs(s.item() - v.astype(np.float64).sum()) < 1e-2
+    a = torch.empty(1000, device="cuda"); call("seqrec_fill_f32", ptr(a), 2.5, 1000, st())
+    i = torch.empty(1000, dtype=torch.int32, device="cuda"); call("seqrec_fill_i32", ptr(i), 2 ** 31 - 1, 1000, st())
+    assert torch.all(a == 2.5) and torch.all(i == 2 ** 31 - 1)
+    m = dev(rng.normal(size=1000).astype(np.float32))
+    call("seqrec_mul", ptr(a), ptr(m), ptr(a), 1000, st())
+    np.testing.assert_array_equal(a.cpu().numpy(), 2.5 * m.cpu().numpy())
+
+
+def test_sparse_rows_path_equals_dense_adagrad_with_duplicates():
+    rng = np.random.default_rng(3)
+    V, W, n1, n2 = 3000, 256, 700, 300
+    P0 = rng.normal(size=(V, W)).astype(np.float32)
+    A0 = np.abs(rng.normal(size=(V, W))).astype(np.float32)
+    rows1 = rng.integers(0, 50, size=n1).astype(np.int32)        # heavy duplicates (Zipf head)
+    rows2 = rng.integers(0, V, size=n2).astype(np.int32)
+    v1 = rng.normal(size=(n1, W)).astype(np.float32); s1 = rng.normal(size=n1).astype(np.float32)
+    v2 = rng.normal(size=(n2, W)).astype(np.float32)
+    Pd, Ad = dev(P0), dev(A0)
+    gt = torch.zeros((V, W), device="cuda")
+    slot = torch.full((V,), 2 ** 31 - 1, dtype=torch.int32, device="cuda")
+    r1, r2 = dev(rows1), dev(rows2)
+    call("seqrec_rows_scatter_add", ptr(gt), ptr(slot), ptr(r1), ptr(dev(v1)), W, ptr(dev(s1)), n1, W, 0, st())
+    call("seqrec_rows_scatter_add", ptr(gt), ptr(slot), ptr(r2), ptr(dev(v2)), W, None, n2, W, n1, st())
+    gref = np.zeros((V, W), np.float64)
+    np.add.at(gref, rows1, v1.astype(np.float64) * s1[:, None])
+    np.add.at(gref, rows2, v2.astype(np.float64))
+    np.testing.assert_allclose(gt.cpu().numpy(), gref, atol=2e-4)
+    sq = torch.zeros(1, device="cuda")
+    call("seqrec_rows_sqnorm", ptr(gt), ptr(slot), ptr(r1), n1, W, 0, ptr(sq), st())
+    call("seqrec_rows_sqnorm", ptr(gt), ptr(slot), ptr(r2), n2, W, n1, ptr(sq), st())
+    assert abs(sq.item() - (gref ** 2).sum()) <= 1e-4 * (gref ** 2).sum()
+    scale = torch.empty(1, device="cuda")
+    call("seqrec_clip_scale", ptr(sq), 1.0, ptr(scale), st())
+    sc = 1.0 / np.sqrt((gref ** 2).sum())
+    assert abs(scale.item() - sc) < 1e-6 * sc + 1e-9
+    call("seqrec_rows_adagrad", ptr(Pd), ptr(Ad), ptr(gt), ptr(slot), ptr(r1), n1, W, 0, 0.01, 1e-8, ptr(scale), st())
+    call("seqrec_rows_adagrad", ptr(Pd), ptr(Ad), ptr(gt), ptr(slot), ptr(r2), n2, W, n1, 0.01, 1e-8, ptr(scale), st())
+    g = gref * sc
+    Aref = A0 + g * g
+    Pref = P0 - 0.01 * g / (np.sqrt(Aref) + 1e-8)
+    np.testing.assert_allclose(Ad.cpu().numpy(), Aref, rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(Pd.cpu().numpy(), Pref, rtol=2e-6, atol=2e-7)
+    assert torch.all(gt == 0) and torch.all(slot == 2 ** 31 - 1)     # cleared for the next step
+    untouched = np.setdiff1d(np.arange(V), np.concatenate([rows1, rows2]))
+    np.testing.assert_array_equal(Pd.cpu().numpy()[untouched], P0[untouched])
+
+
+def test_dense_adagrad_and_norm():
+    rng = np.random.default_rng(4)
+    n = 200003
+    p = rng.normal(size=n).astype(np.float32); a = np.abs(rng.normal(size=n)).astype(np.float32)
+    g = (rng.normal(size=n) * 0.001).astype(np.float32)
+    sq = torch.zeros(1, device="cuda"); scale = torch.empty(1, device="cuda")
+    gd, pd_, ad = dev(g), dev(p), dev(a)
+    call("seqrec_sqnorm", ptr(gd), n, ptr(sq), st())
+    call("seqrec_clip_scale", ptr(sq), 1.0, ptr(scale), st())
+    assert scale.item() == 1.0 and abs(sq.item() - (g.astype(np.float64) ** 2).sum()) < 1e-6
+    call("seqrec_adagrad_dense", ptr(pd_), ptr(ad), ptr(gd), n, 0.01, 1e-8, ptr(scale), st())
+    ar = a + g * g
+    np.testing.assert_allclose(ad.cpu().numpy(), ar, rtol=1e-6)
+    np.testing.assert_allclose(pd_.cpu().numpy(), p - np.float32(0.01) * g / (np.sqrt(ar) + np.float32(1e-8)), rtol=2e-6, atol=1e-7)
+
+
+def test_counter_rng_bit_exact_vs_oracle():
+    V, K = 100003, 2000
+    probs = orng.log_uniform_probs(V)
+    th, al = orng.build_alias_table(probs)
+    thd = torch.from_numpy(th.view(np.int32).copy()).cuda(); ald = dev(al)
+    out = torch.empty(K, dtype=torch.int32, device="cuda")
+    for seed, step in [(0, 0), (7, 3), (2 ** 40 + 5, 123456)]:
+        call("seqrec_sample_negatives", seed, step, K, ptr(thd), ptr(ald), V, ptr(out), st())
+        np.testing.assert_array_equal(out.cpu().numpy(), orng.sample_negatives(seed, step, K, th, al))
+    # the draws follow the proposal (head items dominate)
+    assert (out.cpu().numpy() < 1000).mean() > 0.4
+    rk = np.arange(50, dtype=np.int64) * 977 + 13
+    m = torch.zeros((50, 12), device="cuda")
+    call("seqrec_dropout_mask", 11, 35, ptr(dev(rk)), 50, 10, 12, 0.3, ptr(m), st())
+    ref = orng.dropout_mask(11, 35, rk, 10, 0.3)
+    np.testing.assert_array_equal(m.cpu().numpy()[:, :10], ref)
+    assert np.all(m.cpu().numpy()[:, 10:] == 0) and 0.55 < (ref > 0).mean() < 0.85
+
+
+def test_rank_count_vs_numpy():
+    rng = np.random.default_rng(6)
+    n, H, V = 300, 128, 7001
+    h = rng.normal(size=(n, H)).astype(np.float32)
+    E = rng.normal(size=(V, H)).astype(np.float32)
+    b = rng.normal(size=V).astype(np.float32)
+    tgt = rng.integers(0, V, size=n).astype(np.int32)
+    rank = torch.zeros(n, dtype=torch.int32, device="cuda"); thr = torch.empty(n, device="cuda")
+    call("seqrec_rank_count", ptr(dev(h)), H, ptr(dev(E)), ptr(dev(b)), ptr(dev(tgt)), n, V, ptr(rank), ptr(thr), st())
+    sc = h.astype(np.float64) @ E.T.astype(np.float64) + b
+    ts = sc[np.arange(n), tgt]
+    ref = (sc > ts[:, None]).sum(1)
+    got = rank.cpu().numpy()
+    assert np.abs(got - ref).max() <= 2 and (got == ref).mean() > 0.97     # fp32 near-ties only
