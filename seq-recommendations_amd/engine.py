@@ -26,9 +26,43 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import CELL, ACT, N_GATES, ptr, call
+from ._lib import CELL, ACT, N_GATES, ptr
+from ._lib import call as _raw_call
 
 INT32_MAX = 2 ** 31 - 1
+
+# Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg):
+# _PROF = {"events": [(name, tag, start_event, end_event), ...]} while enabled, else None.
+_PROF = None
+
+
+def profile_start():
+    global _PROF
+    _PROF = {"events": []}
+
+
+def profile_stop():
+    """-> {name: (launches, total_ms)} ; synchronises."""
+    global _PROF
+    ev, _PROF = _PROF["events"], None
+    torch.cuda.synchronize()
+    out = {}
+    for name, tag, a, b in ev:
+        key = name if not tag else "%s[%s]" % (name, tag)
+        n, ms = out.get(key, (0, 0.0))
+        out[key] = (n + 1, ms + a.elapsed_time(b))
+    return out
+
+
+def call(name, *args, tag=None):
+    if _PROF is None:
+        return _raw_call(name, *args)
+    a = torch.cuda.Event(enable_timing=True)
+    b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    _raw_call(name, *args)
+    b.record()
+    _PROF["events"].append((name, tag, a, b))
 
 
 def _pad_h(H):
@@ -148,12 +182,12 @@ class Engine:
             self.ws[name] = t
         return t[:n].view(*shape) if shape else t[:1]
 
-    def gemm(self, a_kc, b_kc, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, accumulate=0, splitk=1):
+    def gemm(self, a_kc, b_kc, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, accumulate=0, splitk=1, tag=None):
         wsp = None
         if splitk > 1:
             wsp = self.buf("gemm_ws", splitk * M * N)
         call("seqrec_gemm_f32", int(a_kc), int(b_kc), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(Cm), ldc, ptr(bias),
-             accumulate, splitk, ptr(wsp), self._stream())
+             accumulate, splitk, ptr(wsp), self._stream(), tag=tag)
 
     @staticmethod
     def _splitk(M, N, K):
@@ -203,9 +237,10 @@ class Engine:
             raise KeyError(name)
         tgt[name].copy_(torch.from_numpy(arr))
 
-    def get_param(self, name, accum=False):
+    def get_param(self, name, accum=False, src=None):
         c = self.cfg
-        src = self.A if accum else self.P
+        if src is None:
+            src = self.A if accum else self.P
         t = src[name]
         if name == "Wk":
             return self._gate_unpad(t, c.V_in)
@@ -314,7 +349,7 @@ class Engine:
         else:
             if c.input == "embed":
                 X = self.buf("X", n, self.Dp)
-                call("seqrec_gather_rows", ptr(P["E"]), ptr(d["ids"]), ptr(X), n, self.Dp, None, None, 0, st)
+                call("seqrec_gather_rows", ptr(P["E"]), ptr(d["ids"]), ptr(X), n, self.Dp, None, None, 0, st, tag="E")
                 Wm, Kd = P["W"], self.Dp
             else:
                 X = d["x"]
@@ -324,7 +359,7 @@ class Engine:
                 call("seqrec_mul", ptr(X), ptr(drops["in"]), ptr(Xd), n * Kd, st)
                 X = Xd
             r["X"] = X
-            self.gemm(1, 0, n, GHp, Kd, X, Kd, Wm, GHp, XW, GHp, bias=bias)
+            self.gemm(1, 0, n, GHp, Kd, X, Kd, Wm, GHp, XW, GHp, bias=bias, tag="xw")
         Hout = self.buf("Hout", n, Hp)
         gates = self.buf("gates", n, GHp)
         aux = self.buf("aux", n, Hp)
@@ -344,7 +379,7 @@ class Engine:
         if c.output == "full":
             Vp = self.Vp
             logits = self.buf("logits", n, Vp)
-            self.gemm(1, 0, n, c.V_out, Hp, Hd, Hp, P["Wout"], Vp, logits, Vp, bias=P.get("bout"))
+            self.gemm(1, 0, n, c.V_out, Hp, Hd, Hp, P["Wout"], Vp, logits, Vp, bias=P.get("bout"), tag="logits")
             probs = self.buf("probs", n, c.V_out) if want_probs else None
             call("seqrec_full_softmax_ce", ptr(logits), Vp, ptr(tgt), n, c.V_out, inv, ptr(loss_rows), ptr(probs), st)
             r["dlogits"] = logits
@@ -361,7 +396,7 @@ class Engine:
             Eneg = self.buf("Eneg", K, Hp)
             call("seqrec_gather_rows", ptr(Et), ptr(neg), ptr(Eneg), K, Hp, None, None, 0, st)
             ln = self.buf("ln", n, K)
-            self.gemm(1, 1, n, K, Hp, Hd, Hp, Eneg, Hp, ln, K)
+            self.gemm(1, 1, n, K, Hp, Hd, Hp, Eneg, Hp, ln, K, tag="logits")
             dlt = self.buf("dlt", n)
             call("seqrec_sampled_softmax_ce", ptr(ln), K, ptr(Hd), Hp, ptr(Et), ptr(P.get("bout")),
                  ptr(lq if c.logq else None), ptr(tgt), ptr(neg), n, K, inv, ptr(loss_rows), ptr(dlt), st)
@@ -371,7 +406,7 @@ class Engine:
         return r
 
     # ------------------------------------------------------------------ training step
-    def train_step(self, d, lr=0.01, eps=1e-8, clipnorm=1.0, step=None, negatives=None):
+    def train_step(self, d, lr=0.01, eps=1e-8, clipnorm=1.0, step=None, negatives=None, apply_update=True):
         """One full step on an uploaded batch: forward, masked-mean CE, BPTT, global-norm clip,
         Adagrad.  Returns the batch loss as a 1-element device tensor (no host sync)."""
         c, P = self.cfg, self.P
@@ -395,20 +430,20 @@ class Engine:
             Vp = self.Vp
             dl = r["dlogits"]
             if tr["Wout"]:
-                self.gemm(0, 0, Hp, c.V_out, n, Hd, Hp, dl, Vp, Gd["Wout"], Vp, splitk=self._splitk(Hp, c.V_out, n))
+                self.gemm(0, 0, Hp, c.V_out, n, Hd, Hp, dl, Vp, Gd["Wout"], Vp, splitk=self._splitk(Hp, c.V_out, n), tag="dWout")
             if c.out_bias and tr["bout"]:
                 call("seqrec_colsum", ptr(dl), n, c.V_out, Vp, ptr(Gd["bout"]), 0, ptr(cs_ws), st)
-            self.gemm(1, 1, n, Hp, c.V_out, dl, Vp, P["Wout"], Vp, dHd, Hp)
+            self.gemm(1, 1, n, Hp, c.V_out, dl, Vp, P["Wout"], Vp, dHd, Hp, tag="dH")
         else:
             K = c.K
             tname = "E" if c.tied else "Eout"
             Et = P[tname]
             dln, dlt, neg, Eneg = r["dln"], r["dlt"], r["neg"], r["Eneg"]
-            self.gemm(1, 0, n, Hp, K, dln, K, Eneg, Hp, dHd, Hp)
+            self.gemm(1, 0, n, Hp, K, dln, K, Eneg, Hp, dHd, Hp, tag="dH")
             call("seqrec_gather_rows", ptr(Et), ptr(d["tgt"]), ptr(dHd), n, Hp, ptr(dlt), None, 1, st)
             if tr[tname]:
                 dEneg = self.buf("dEneg", K, Hp)
-                self.gemm(0, 0, K, Hp, n, dln, K, Hd, Hp, dEneg, Hp, splitk=self._splitk(K, Hp, n))
+                self.gemm(0, 0, K, Hp, n, dln, K, Hd, Hp, dEneg, Hp, splitk=self._splitk(K, Hp, n), tag="dEneg")
                 base_t, base_n = 0, n
                 call("seqrec_rows_scatter_add", ptr(Gt[tname]), ptr(self.slot[tname]), ptr(d["tgt"]), ptr(Hd), Hp,
                      ptr(dlt), n, Hp, base_t, st)
@@ -438,10 +473,10 @@ class Engine:
             call("seqrec_gather_rows", ptr(r["Hout"]), ptr(d["prev"]), ptr(Hprev), n, Hp, None, None, 0, st)
             sk = self._splitk(Hp, GHp, n)
             if c.cell == "gru":
-                self.gemm(0, 0, Hp, 2 * Hp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp, splitk=sk)
-                self.gemm(0, 0, Hp, Hp, n, r["aux"], Hp, dPre[:, 2 * Hp:], GHp, Gd["U"][:, 2 * Hp:], GHp, splitk=sk)
+                self.gemm(0, 0, Hp, 2 * Hp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp, splitk=sk, tag="dU")
+                self.gemm(0, 0, Hp, Hp, n, r["aux"], Hp, dPre[:, 2 * Hp:], GHp, Gd["U"][:, 2 * Hp:], GHp, splitk=sk, tag="dU")
             else:
-                self.gemm(0, 0, Hp, GHp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp, splitk=sk)
+                self.gemm(0, 0, Hp, GHp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp, splitk=sk, tag="dU")
         if c.input == "onehot":
             if tr["Wk"]:
                 call("seqrec_rows_scatter_add", ptr(Gt["Wk"]), ptr(self.slot["Wk"]), ptr(d["ids"]), ptr(dPre), GHp,
@@ -452,16 +487,18 @@ class Engine:
             Kd = X.shape[1]
             wname = "W" if c.input == "embed" else "Wk"
             if tr[wname]:
-                self.gemm(0, 0, Kd, GHp, n, X, Kd, dPre, GHp, Gd[wname], GHp, splitk=self._splitk(Kd, GHp, n))
+                self.gemm(0, 0, Kd, GHp, n, X, Kd, dPre, GHp, Gd[wname], GHp, splitk=self._splitk(Kd, GHp, n), tag="dW")
             if c.input == "embed" and tr["E"]:
                 dX = self.buf("dX", n, self.Dp)
-                self.gemm(1, 1, n, self.Dp, GHp, dPre, GHp, P["W"], GHp, dX, self.Dp)
+                self.gemm(1, 1, n, self.Dp, GHp, dPre, GHp, P["W"], GHp, dX, self.Dp, tag="dX")
                 if "in" in drops:
                     call("seqrec_mul", ptr(dX), ptr(drops["in"]), ptr(dX), n * self.Dp, st)
                 base_i = (n + c.K) if c.tied else 0
                 call("seqrec_rows_scatter_add", ptr(Gt["E"]), ptr(self.slot["E"]), ptr(d["ids"]), ptr(dX), self.Dp,
                      None, n, self.Dp, base_i, st)
                 sparse_jobs.append(("E", d["ids"], n, self.Dp, base_i))
+        if not apply_update:
+            return sparse_jobs
         # ---- global-norm clip over every trainable tensor (Keras clipnorm), then Adagrad
         self.sq.zero_()
         for k, g in Gd.items():
@@ -477,6 +514,23 @@ class Engine:
             call("seqrec_rows_adagrad", ptr(P[k]), ptr(self.A[k]), ptr(Gt[k]), ptr(self.slot[k]), ptr(rows), nr, w, base,
                  lr, eps, ptr(self.scale), st)
         return self.loss_sum / n
+
+    def grads(self, d, step=0, negatives=None):
+        """Debug/test hook: loss and UNPADDED gradients of one batch, no update applied.
+        Table gradients come back dense (only sensible for small tables)."""
+        n = d["n"]
+        count = self.step_count
+        self.train_step(d, step=step, negatives=negatives, apply_update=False)
+        self.step_count = count
+        out = {}
+        for k in self.P:
+            if not self.trainable[k]:
+                continue
+            out[k] = self.get_param(k, src=self.Gt if k in self.table_params else self.Gd)
+        for k in self.table_params:
+            self.Gt[k].zero_()
+            self.slot[k].fill_(INT32_MAX)
+        return float((self.loss_sum / max(n, 1)).item()), out
 
     # ------------------------------------------------------------------ evaluation / prediction
     def eval_loss(self, d, negatives=None, step=0):

@@ -17,8 +17,22 @@ B_ = importlib.import_module("seq-recommendations_amd.batching")
 ptr, call = L.ptr, L.call
 
 
+_KEEP = []
+
+
 def dev(a):
-    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    """numpy -> device tensor, kept alive until the end of the test: ptr() only captures the
+    address, and a temporary freed mid-argument-list would be recycled by the caching allocator."""
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    _KEEP.append(t)
+    return t
+
+
+@pytest.fixture(autouse=True)
+def _keepalive():
+    yield
+    torch.cuda.synchronize()
+    _KEEP.clear()
 
 
 def st():
