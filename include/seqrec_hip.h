@@ -74,18 +74,21 @@ int64_t seqrec_gemm_workspace_floats(int64_t M, int64_t N, int splitk);
  *      Hout [N_tok, H]    hidden state per token (the layer output, return_sequences=True)
  *      gates[N_tok, G*H]  post-activation gate values (stash for BPTT; unused for SimpleRNN)
  *      aux  [N_tok, H]    LSTM: cell state c_t;  GRU: r_t * h_{t-1};  SimpleRNN: unused
- *      upack: workspace of seqrec_rnn_upack_floats() floats (re-laid-out copy of U)
+ *      upack: seqrec_rnn_upack_floats() floats written by seqrec_rnn_pack_u (U re-laid-out into
+ *             per-wave MFMA B-fragment order, forward layouts then transposed backward layouts);
+ *             re-pack after every update of U.
  *      step_off: DEVICE int32[T+1]; B = number of sessions (= step_off[1]) */
 int64_t seqrec_rnn_upack_floats(int cell, int H);
+int seqrec_rnn_pack_u(int cell, int H, const float* U, float* upack, void* stream);
 int seqrec_rnn_fwd(int cell, int act, int H, int H_real, int T, int B, const int32_t* step_off,
-                   const float* XW, const float* U, float* Hout, float* gates, float* aux,
-                   float* upack, void* stream);
+                   const float* XW, float* Hout, float* gates, float* aux,
+                   const float* upack, void* stream);
 /*      BPTT of the same scan (Theano autodiff through scan).
  *      dHout [N_tok,H]  in: dLoss/dHout;  dPre [N_tok,G*H] out: dLoss/d(pre-activations) = dLoss/dXW.
  *      dU, dW, db follow from dPre by seqrec_gemm_f32 / seqrec_colsum. */
 int seqrec_rnn_bwd(int cell, int act, int H, int H_real, int T, int B, const int32_t* step_off,
                    const float* dHout, const float* Hout, const float* gates, const float* aux,
-                   const float* U, float* dPre, float* upack, void* stream);
+                   float* dPre, const float* upack, void* stream);
 
 /* ---- softmax + Theano categorical_crossentropy under the Keras token-mean mask
  *      (model.py:175-177,257,397), fused with its gradient.

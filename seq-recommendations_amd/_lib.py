@@ -37,8 +37,9 @@ _SIGS = {
     "seqrec_gemm_f32": [I, I, L, L, L, P, L, P, L, P, L, P, I, I, P, P],
     "seqrec_gemm_workspace_floats": [L, L, I],
     "seqrec_rnn_upack_floats": [I, I],
-    "seqrec_rnn_fwd": [I, I, I, I, I, I, P, P, P, P, P, P, P, P],
-    "seqrec_rnn_bwd": [I, I, I, I, I, I, P, P, P, P, P, P, P, P, P],
+    "seqrec_rnn_pack_u": [I, I, P, P, P],
+    "seqrec_rnn_fwd": [I, I, I, I, I, I, P, P, P, P, P, P, P],
+    "seqrec_rnn_bwd": [I, I, I, I, I, I, P, P, P, P, P, P, P, P],
     "seqrec_full_softmax_ce": [P, L, P, L, I, F, P, P, P],
     "seqrec_sampled_softmax_ce": [P, L, P, I, P, P, P, P, P, L, I, F, P, P, P],
     "seqrec_reduce_sum": [P, L, P, I, P],

@@ -11,7 +11,8 @@
 //   * wave w of the 4 owns hidden columns [16J*w, 16J*(w+1)) of EVERY gate (J = H/64), so all gate
 //     arithmetic of a unit is lane-local in the accumulators (C/D map of v_mfma_f32_16x16x4_f32:
 //     col = lane&15, row = 4*(lane>>4)+reg) and cell state / z / carried gradients stay in registers;
-//   * the recurrent kernel U is re-laid-out once per step ("packed": [wave][k/4][col group][lane][4])
+//   * the recurrent kernel U is re-laid-out once per update (seqrec_rnn_pack_u; "packed":
+//     [wave][k/4][col group][lane][4])
 //     so that a wave streams its B fragments from L2 with fully coalesced 16-byte loads straight
 //     into registers (software ring, 16 loads in flight per lane); U never touches LDS.
 // Arithmetic: exact fp32 on the f32-input MFMA (bitwise an fmaf chain over k).
@@ -124,8 +125,14 @@ template <int N> __device__ __forceinline__ void zero_acc(f32x4 (&acc)[N]) {
 //   mode 1 (backward):  B[k = gi*H + jj][hc] = U[hc*ldu + gates[gi]*H + jj],     K = ng*H
 // out[(((w*KB + kb)*NCG + cg)*64 + l)*VEC + e], col block cb = cg*VEC + e, k = 4*kb + (l>>4)
 // ------------------------------------------------------------------------------------------
-__global__ void pack_u_kernel(const float* __restrict__ U, int ldu, int H, int mode, int ng, int g0, int g1, int g2,
-                              int g3, float* __restrict__ out) {
+struct PackJob { int mode, ng, g[4]; long out_off; };
+struct PackArgs { const float* U; float* out; int ldu, H, njobs; PackJob job[4]; };
+
+__global__ void pack_u_kernel(PackArgs pa) {
+    const PackJob jb = pa.job[blockIdx.y];
+    const float* __restrict__ U = pa.U;
+    float* __restrict__ out = pa.out + jb.out_off;
+    const int H = pa.H, ldu = pa.ldu, mode = jb.mode, ng = jb.ng;
     const int J = H / 64;
     const int NCB = mode == 0 ? ng * J : J;
     const int VEC = NCB >= 4 ? 4 : NCB;
@@ -133,7 +140,6 @@ __global__ void pack_u_kernel(const float* __restrict__ U, int ldu, int H, int m
     const int K = mode == 0 ? H : ng * H;
     const int KB = K / 4;
     const long total = (long)K * NCB * 16 * 4;
-    const int gl[4] = {g0, g1, g2, g3};
     for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
         long q = o;
         const int e = (int)(q % VEC); q /= VEC;
@@ -148,11 +154,11 @@ __global__ void pack_u_kernel(const float* __restrict__ U, int ldu, int H, int m
         if (mode == 0) {
             const int gi = cb / J, j = cb % J;
             const int hc = 16 * J * w + 16 * j + cc;
-            v = U[(long)k * ldu + gl[gi] * H + hc];
+            v = U[(long)k * ldu + jb.g[gi] * H + hc];
         } else {
             const int hc = 16 * J * w + 16 * cb + cc;
             const int gi = k / H, jj = k % H;
-            v = U[(long)hc * ldu + gl[gi] * H + jj];
+            v = U[(long)hc * ldu + jb.g[gi] * H + jj];
         }
         out[o] = v;
     }
@@ -556,15 +562,6 @@ int set_lds(const void* fn, size_t bytes) {
     return 0;
 }
 
-int launch_pack(const float* U, int ldu, int H, int mode, int ng, int g0, int g1, int g2, int g3, float* out,
-                hipStream_t st) {
-    const long total = (long)(ng * H) * H;   // both modes: K * N = ng*H*H floats
-    int blocks = (int)min((long)1024, (total + 255) / 256);
-    hipLaunchKernelGGL(pack_u_kernel, dim3(blocks), dim3(256), 0, st, U, ldu, H, mode, ng, g0, g1, g2, g3, out);
-    SEQREC_LAUNCH_CHECK();
-    return 0;
-}
-
 #define DISPATCH_J(KERNEL, LDS_BYTES)                                                                      \
     do {                                                                                                   \
         const size_t lds__ = (LDS_BYTES);                                                                  \
@@ -591,35 +588,60 @@ bool check_common(int cell, int act, int H, int H_real, int T, int B) {
 
 extern "C" int64_t seqrec_rnn_upack_floats(int cell, int H) {
     const int G = cell == SEQREC_CELL_LSTM ? 4 : (cell == SEQREC_CELL_GRU ? 3 : 1);
-    return (int64_t)G * H * H;
+    return (int64_t)2 * G * H * H;       // forward layouts, then backward (transposed) layouts
+}
+
+extern "C" int seqrec_rnn_pack_u(int cell, int H, const float* U, float* upack, void* stream) {
+    if (cell < 0 || cell > 2 || !(H == 64 || H == 128 || H == 256 || H == 512)) return SEQREC_E_SHAPE;
+    if (!U || !upack) return SEQREC_E_ARG;
+    const long HH = (long)H * H;
+    PackArgs pa = {};
+    pa.U = U; pa.out = upack; pa.H = H;
+    auto job = [&](int i, int mode, int ng, int g0, int g1, int g2, int g3, long off) {
+        pa.job[i].mode = mode; pa.job[i].ng = ng;
+        pa.job[i].g[0] = g0; pa.job[i].g[1] = g1; pa.job[i].g[2] = g2; pa.job[i].g[3] = g3;
+        pa.job[i].out_off = off;
+    };
+    if (cell == SEQREC_CELL_SIMPLERNN) {
+        pa.ldu = H; pa.njobs = 2;
+        job(0, 0, 1, 0, 0, 0, 0, 0);
+        job(1, 1, 1, 0, 0, 0, 0, HH);
+    } else if (cell == SEQREC_CELL_LSTM) {
+        pa.ldu = 4 * H; pa.njobs = 2;
+        job(0, 0, 4, 0, 1, 2, 3, 0);
+        job(1, 1, 4, 0, 1, 2, 3, 4 * HH);
+    } else {
+        pa.ldu = 3 * H; pa.njobs = 4;
+        job(0, 0, 2, 0, 1, 0, 0, 0);          // fwd  [z r]
+        job(1, 0, 1, 2, 0, 0, 0, 2 * HH);     // fwd  h
+        job(2, 1, 1, 2, 0, 0, 0, 3 * HH);     // bwd  U_h^T
+        job(3, 1, 2, 0, 1, 0, 0, 4 * HH);     // bwd  [U_z U_r]^T
+    }
+    hipLaunchKernelGGL(pack_u_kernel, dim3(256, pa.njobs), dim3(256), 0, as_stream(stream), pa);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int seqrec_rnn_fwd(int cell, int act, int H, int H_real, int T, int B, const int32_t* step_off,
-                              const float* XW, const float* U, float* Hout, float* gates, float* aux,
-                              float* upack, void* stream) {
+                              const float* XW, float* Hout, float* gates, float* aux,
+                              const float* upack, void* stream) {
     if (!check_common(cell, act, H, H_real, T, B)) return SEQREC_E_SHAPE;
     if (T == 0 || B == 0) return 0;
-    if (!step_off || !XW || !U || !Hout || !upack) return SEQREC_E_ARG;
+    if (!step_off || !XW || !Hout || !upack) return SEQREC_E_ARG;
     if (cell != SEQREC_CELL_SIMPLERNN && (!gates || !aux)) return SEQREC_E_ARG;
     hipStream_t st = as_stream(stream);
     const int J = H / 64;
     RnnArgs a = {};
     a.step_off = step_off; a.T = T; a.B = B; a.H_real = H_real; a.act = act;
     a.XW = XW; a.Hout = Hout; a.gates = gates; a.aux = aux;
+    a.pk0 = upack;
     dim3 grid((B + 15) / 16);
-    int rc;
     if (cell == SEQREC_CELL_SIMPLERNN) {
-        if ((rc = launch_pack(U, H, H, 0, 1, 0, 0, 0, 0, upack, st))) return rc;
-        a.pk0 = upack;
         DISPATCH_J(srnn_fwd_kernel, (size_t)32 * (H + 2) * 4);
     } else if (cell == SEQREC_CELL_LSTM) {
-        if ((rc = launch_pack(U, 4 * H, H, 0, 4, 0, 1, 2, 3, upack, st))) return rc;
-        a.pk0 = upack;
         DISPATCH_J(lstm_fwd_kernel, (size_t)32 * (H + 2) * 4);
     } else {
-        if ((rc = launch_pack(U, 3 * H, H, 0, 2, 0, 1, 0, 0, upack, st))) return rc;
-        if ((rc = launch_pack(U, 3 * H, H, 0, 1, 2, 0, 0, 0, upack + (size_t)2 * H * H, st))) return rc;
-        a.pk0 = upack; a.pk1 = upack + (size_t)2 * H * H;
+        a.pk1 = upack + (size_t)2 * H * H;
         DISPATCH_J(gru_fwd_kernel, (size_t)32 * (H + 2) * 4);
     }
     return 0;
@@ -627,30 +649,25 @@ extern "C" int seqrec_rnn_fwd(int cell, int act, int H, int H_real, int T, int B
 
 extern "C" int seqrec_rnn_bwd(int cell, int act, int H, int H_real, int T, int B, const int32_t* step_off,
                               const float* dHout, const float* Hout, const float* gates, const float* aux,
-                              const float* U, float* dPre, float* upack, void* stream) {
+                              float* dPre, const float* upack, void* stream) {
     if (!check_common(cell, act, H, H_real, T, B)) return SEQREC_E_SHAPE;
     if (T == 0 || B == 0) return 0;
-    if (!step_off || !dHout || !Hout || !U || !dPre || !upack) return SEQREC_E_ARG;
+    if (!step_off || !dHout || !Hout || !dPre || !upack) return SEQREC_E_ARG;
     if (cell != SEQREC_CELL_SIMPLERNN && (!gates || !aux)) return SEQREC_E_ARG;
     hipStream_t st = as_stream(stream);
     const int J = H / 64;
+    const int G = cell == SEQREC_CELL_LSTM ? 4 : (cell == SEQREC_CELL_GRU ? 3 : 1);
     RnnArgs a = {};
     a.step_off = step_off; a.T = T; a.B = B; a.H_real = H_real; a.act = act;
     a.dHout = dHout; a.HoutR = Hout; a.gatesR = gates; a.auxR = aux; a.dPre = dPre;
+    a.pk0 = upack + (size_t)G * H * H;
     dim3 grid((B + 15) / 16);
-    int rc;
     if (cell == SEQREC_CELL_SIMPLERNN) {
-        if ((rc = launch_pack(U, H, H, 1, 1, 0, 0, 0, 0, upack, st))) return rc;
-        a.pk0 = upack;
         DISPATCH_J(srnn_bwd_kernel, (size_t)16 * (H + 2) * 4);
     } else if (cell == SEQREC_CELL_LSTM) {
-        if ((rc = launch_pack(U, 4 * H, H, 1, 4, 0, 1, 2, 3, upack, st))) return rc;
-        a.pk0 = upack;
         DISPATCH_J(lstm_bwd_kernel, (size_t)16 * (4 * H + 2) * 4);
     } else {
-        if ((rc = launch_pack(U, 3 * H, H, 1, 1, 2, 0, 0, 0, upack, st))) return rc;
-        if ((rc = launch_pack(U, 3 * H, H, 1, 2, 0, 1, 0, 0, upack + (size_t)H * H, st))) return rc;
-        a.pk0 = upack; a.pk1 = upack + (size_t)H * H;
+        a.pk1 = a.pk0 + (size_t)H * H;
         DISPATCH_J(gru_bwd_kernel, (size_t)16 * (3 * H + 4) * 4);
     }
     return 0;

@@ -166,6 +166,7 @@ class Engine:
         self.scale = torch.ones(1, **f32)
         self.loss_sum = z(1)
         self.upack = torch.empty(int(_lib.load().seqrec_rnn_upack_floats(CELL[c.cell], self.Hp)), **f32)
+        self.upack_dirty = True
         self.sampler = None       # (thresh uint32-as-int32 tensor, alias int32 tensor, logq float tensor)
         self.step_count = 0
 
@@ -236,6 +237,8 @@ class Engine:
         else:
             raise KeyError(name)
         tgt[name].copy_(torch.from_numpy(arr))
+        if name == "U" and not accum:
+            self.upack_dirty = True
 
     def get_param(self, name, accum=False, src=None):
         c = self.cfg
@@ -363,7 +366,10 @@ class Engine:
         Hout = self.buf("Hout", n, Hp)
         gates = self.buf("gates", n, GHp)
         aux = self.buf("aux", n, Hp)
-        call("seqrec_rnn_fwd", CELL[c.cell], ACT[c.act], Hp, c.H, T, B, ptr(d["step_off"]), ptr(XW), ptr(P["U"]),
+        if self.upack_dirty:
+            call("seqrec_rnn_pack_u", CELL[c.cell], Hp, ptr(P["U"]), ptr(self.upack), st)
+            self.upack_dirty = False
+        call("seqrec_rnn_fwd", CELL[c.cell], ACT[c.act], Hp, c.H, T, B, ptr(d["step_off"]), ptr(XW),
              ptr(Hout), ptr(gates), ptr(aux), ptr(self.upack), st)
         r.update(XW=XW, Hout=Hout, gates=gates, aux=aux)
         Hd = Hout
@@ -465,7 +471,7 @@ class Engine:
             call("seqrec_mul", ptr(dHd), ptr(drops["out"]), ptr(dHd), n * Hp, st)
         dPre = self.buf("dPre", n, GHp)
         call("seqrec_rnn_bwd", CELL[c.cell], ACT[c.act], Hp, c.H, T, B, ptr(d["step_off"]), ptr(dHout), ptr(r["Hout"]),
-             ptr(r["gates"]), ptr(r["aux"]), ptr(P["U"]), ptr(dPre), ptr(self.upack), st)
+             ptr(r["gates"]), ptr(r["aux"]), ptr(dPre), ptr(self.upack), st)
         if c.use_bias and tr["b"]:
             call("seqrec_colsum", ptr(dPre), n, GHp, GHp, ptr(Gd["b"]), 0, ptr(cs_ws), st)
         if tr["U"]:
@@ -510,6 +516,8 @@ class Engine:
         for k, g in Gd.items():
             if tr[k]:
                 call("seqrec_adagrad_dense", ptr(P[k]), ptr(self.A[k]), ptr(g), g.numel(), lr, eps, ptr(self.scale), st)
+        if tr["U"]:
+            self.upack_dirty = True
         for (k, rows, nr, w, base) in sparse_jobs:
             call("seqrec_rows_adagrad", ptr(P[k]), ptr(self.A[k]), ptr(Gt[k]), ptr(self.slot[k]), ptr(rows), nr, w, base,
                  lr, eps, ptr(self.scale), st)

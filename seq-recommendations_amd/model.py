@@ -1,0 +1,545 @@
+"""The reference's model surface (model.py:23-45,94-258,322-403) on the HIP engine.
+
+Same class names, constructor arguments, method names and return conventions as the
+reference, so its callers (experiments_methods.py, the L5 scripts) work unchanged:
+
+  RNNBaseline(timesteps, features, n_classes, ...)                     model.py:241-258
+  RNNFullModel(timesteps, x_dim, y_dim, z_dim, ..., y_to_z=True, ...)   model.py:322-403
+      -- the "ytoz" wiring (y_to_z only) is the hot path; the x_to_y / y_to_y / x_to_z side
+         branches raise NotImplementedError
+  BaseRNNModel.compile_model / fit_model / fit_generator / predict / evaluate /
+      save_model_weights / load_model_weights / get_layer_weights / set_layer_weights_trainable /
+      set_layer_weights / get_model_weights / get_activations              model.py:170-238
+  .model        a Keras-``Model``-shaped object (fit / predict / evaluate / get_layer / ...)
+  ModelResults, ArrayInitializer, ValLossHistoryCut, MultinomialModel, MarkovModel
+
+What differs, by necessity: no Keras/Theano underneath -- ``.model`` is ``SeqModel`` below, whose
+``fit`` drives ``engine.Engine`` (HIP kernels through the C ABI).  Weight files are numpy ``.npz``
+containers (``weight0..weightN`` keys, the reference's naming, model.py:206) because h5py is not
+part of the image.
+"""
+import os
+
+import numpy as np
+
+from . import utils
+from . import batching
+from .keras_compat import Adagrad, Callback, History, initialize
+
+
+class ModelResults:
+    def __init__(self, train_loss=None, val_loss=None, epoch=None):
+        self.val_loss = val_loss
+        self.train_loss = train_loss
+        self.epoch = epoch
+
+
+class ArrayInitializer:
+    """Initializer that returns a fixed array (model.py:32-45): the hook for injecting identical
+    initial weights into the oracle and the GPU path."""
+
+    def __init__(self, values=0):
+        self.values = values
+
+    def __call__(self, shape, dtype=None):
+        return self.values
+
+    def get_config(self):
+        return {"value": self.values}
+
+
+# ------------------------------------------------------------------------------------------------
+# count baselines (model.py:127-167) -- tiny, numpy; kept so experiments_methods drops in whole
+# ------------------------------------------------------------------------------------------------
+class BaseModel:
+    def __init__(self, n_classes, model_name="test_model"):
+        self.n_classes = n_classes
+        self.model_name = model_name
+        self.model = None
+
+
+class MultinomialModel(BaseModel):
+    def __init__(self, n_classes, model_name="multinomial_model", k=1.0):
+        BaseModel.__init__(self, n_classes, model_name)
+        self.model = np.zeros((1, self.n_classes))
+        self.k = k
+
+    def fit_model(self, seqs, normalize=True):
+        self.model = utils.multinomial_probabilities(seqs, self.n_classes, self.k, normalize)
+
+    def predict(self, seqs):
+        return [[self.model[0, s] for s in seq] for seq in seqs]
+
+
+class MarkovModel(BaseModel):
+    def __init__(self, n_classes, model_name="markov_model", order=1, k=1.0):
+        BaseModel.__init__(self, n_classes, model_name)
+        assert order == 1, "ERROR: only first-order Markov chains are supported for now."
+        self.model = np.zeros((self.n_classes, self.n_classes))
+        self.initial_probs = np.zeros(self.n_classes)
+        self.order = order
+        self.k = k
+
+    def fit_model(self, seqs, freq=False):
+        self.model, self.initial_probs = utils.transition_matrix(seqs, self.n_classes, self.k, freq=freq, end_state=False)
+
+    def predict(self, seqs):
+        out = []
+        for seq in seqs:
+            p = [self.initial_probs[seq[0]]]
+            p.extend(self.model[i, j] for i, j in zip(seq[:-1], seq[1:]))
+            out.append(p)
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# the Keras-Model-shaped object behind `.model`
+# ------------------------------------------------------------------------------------------------
+class Layer:
+    """Named bundle of parameters with Keras' get_weights/set_weights/trainable protocol."""
+
+    def __init__(self, owner, name, keys):
+        self._owner, self.name, self.keys = owner, name, keys
+        self._trainable = True
+
+    @property
+    def trainable(self):
+        return self._trainable
+
+    @trainable.setter
+    def trainable(self, v):
+        self._trainable = bool(v)
+        self._owner._sync_trainable()
+
+    def get_weights(self):
+        return [self._owner._get(k) for k in self.keys]
+
+    def set_weights(self, weights):
+        if len(weights) != len(self.keys):
+            raise ValueError("layer %s expects %d arrays, got %d" % (self.name, len(self.keys), len(weights)))
+        for k, w in zip(self.keys, weights):
+            self._owner._set(k, w)
+
+
+class SeqModel:
+    """Masking -> [Dropout] -> SimpleRNN|LSTM|GRU -> Dropout -> TimeDistributed(Dense) -> softmax.
+
+    Host-side weights live in ``self.w`` (UNPADDED numpy, Keras layouts) until the first call that
+    needs the GPU creates the engine; afterwards the engine's HBM copy is authoritative."""
+
+    metrics_names = ["loss", "categorical_crossentropy"]
+
+    def __init__(self, timesteps, in_dim, n_classes, z_dim, rnn_type, activation, rnn_name, out_name, use_bias=True,
+                 out_bias=False, drop_in=0.0, drop_rec=0.0, drop_out=0.0, kernel_initializer="glorot_uniform",
+                 device="cuda:0"):
+        cell = {"simpleRNN": "simplernn", "LSTM": "lstm", "GRU": "gru"}.get(rnn_type)
+        if cell is None:
+            raise ValueError("rnn_type must be 'simpleRNN', 'LSTM' or 'GRU' (got %r)" % (rnn_type,))
+        if activation not in ("relu", "tanh", "linear"):
+            raise NotImplementedError("activation %r: the HIP scan implements relu, tanh and linear" % (activation,))
+        self.timesteps, self.in_dim, self.n_classes, self.z_dim = timesteps, in_dim, n_classes, z_dim
+        self.cell, self.activation = cell, activation
+        self.use_bias, self.out_bias = use_bias, out_bias
+        self.drop_in, self.drop_rec, self.drop_out = float(drop_in), float(drop_rec), float(drop_out)
+        self.device = device
+        G = {"simplernn": 1, "gru": 3, "lstm": 4}[cell]
+        H = z_dim
+        w = {"Wk": initialize(kernel_initializer, (in_dim, G * H)), "U": self._recurrent_init(G, H)}
+        if use_bias:
+            b = np.zeros(G * H, np.float32)
+            if cell == "lstm":
+                b[H:2 * H] = 1.0                       # unit_forget_bias=True
+            w["b"] = b
+        w["Wout"] = initialize("glorot_uniform", (H, n_classes))
+        if out_bias:
+            w["bout"] = np.zeros(n_classes, np.float32)
+        self.w = w
+        rk = ["Wk", "U"] + (["b"] if use_bias else [])
+        ok = ["Wout"] + (["bout"] if out_bias else [])
+        self.layers = [Layer(self, rnn_name, rk), Layer(self, out_name, ok)]
+        self.engine = None
+        self.input_mode = None
+        self.optimizer = None
+        self.loss = None
+        self.stop_training = False
+        self.seed = int(np.random.randint(0, 2 ** 31 - 1))     # dropout stream seed (Keras draws one too)
+        self._step = 0
+
+    @staticmethod
+    def _recurrent_init(G, H):
+        a = np.random.normal(0.0, 1.0, (H, G * H))
+        u, _, v = np.linalg.svd(a, full_matrices=False)
+        q = u if u.shape == (H, G * H) else v
+        return np.asarray(q, dtype=np.float32)
+
+    # ---- weights -------------------------------------------------------------------------------
+    def _get(self, k):
+        return self.engine.get_param(k) if self.engine is not None else self.w[k].copy()
+
+    def _set(self, k, v):
+        v = np.asarray(v, dtype=np.float32)
+        if v.shape != self.w[k].shape:
+            raise ValueError("weight %s: shape %s expected, got %s" % (k, self.w[k].shape, v.shape))
+        self.w[k] = v.copy()
+        if self.engine is not None:
+            self.engine.set_param(k, v)
+
+    def _sync_trainable(self):
+        if self.engine is not None:
+            for l in self.layers:
+                for k in l.keys:
+                    self.engine.trainable[k] = l.trainable
+
+    def get_layer(self, name=None, index=None):
+        if index is not None:
+            return self.layers[index]
+        for l in self.layers:
+            if l.name == name:
+                return l
+        raise ValueError("No such layer: %s" % name)
+
+    def get_weights(self):
+        return [a for l in self.layers for a in l.get_weights()]
+
+    def set_weights(self, weights):
+        i = 0
+        for l in self.layers:
+            l.set_weights(weights[i:i + len(l.keys)])
+            i += len(l.keys)
+
+    @property
+    def trainable_weights(self):
+        return ["%s/%s" % (l.name, k) for l in self.layers if l.trainable for k in l.keys]
+
+    @property
+    def non_trainable_weights(self):
+        return ["%s/%s" % (l.name, k) for l in self.layers if not l.trainable for k in l.keys]
+
+    def save_weights(self, filepath):
+        d = os.path.dirname(filepath)
+        if d and not os.path.exists(d):
+            os.makedirs(d)
+        with open(filepath, "wb") as f:
+            np.savez(f, **{"weight%d" % i: a for i, a in enumerate(self.get_weights())})
+
+    def load_weights(self, filepath, by_name=False):
+        with np.load(filepath, allow_pickle=False) as z:
+            self.set_weights([z["weight%d" % i] for i in range(len(z.files))])
+
+    # ---- engine --------------------------------------------------------------------------------
+    def _ensure_engine(self, input_mode):
+        from . import engine as E
+        if self.engine is not None and self.input_mode == input_mode:
+            return self.engine
+        if self.engine is not None:                 # input kind changed: carry the weights over
+            for k in list(self.w):
+                self.w[k] = self.engine.get_param(k)
+        cfg = E.NetConfig(cell=self.cell, act=self.activation, H=self.z_dim, V_in=self.in_dim, V_out=self.n_classes,
+                          input=input_mode, output="full", use_bias=self.use_bias, out_bias=self.out_bias,
+                          drop_in=self.drop_in, drop_rec=self.drop_rec, drop_out=self.drop_out, seed=self.seed)
+        self.engine = E.Engine(cfg, self.device)
+        self.input_mode = input_mode
+        for k, v in self.w.items():
+            self.engine.set_param(k, v)
+        self._sync_trainable()
+        return self.engine
+
+    # ---- data ----------------------------------------------------------------------------------
+    @staticmethod
+    def _first(x):
+        return x[0] if isinstance(x, (list, tuple)) else x
+
+    def _prepare(self, x, y=None):
+        """Reference tensors -> (mask, ids|None, feats|None, tgt|None, input_mode)."""
+        x = np.asarray(self._first(x))
+        if x.ndim != 3 or x.shape[2] != self.in_dim:
+            raise ValueError("expected input of shape (N, T, %d), got %s" % (self.in_dim, x.shape))
+        mask, ids, exact = batching.onehot_to_ids(x)
+        mode = "onehot" if exact else "dense"
+        tgt = None
+        if y is not None:
+            y = np.asarray(y)
+            tgt = y[:, :, 0].astype(np.int64) if y.shape[2] == 1 and self.n_classes != 1 else np.argmax(y, axis=2)
+        return mask, (ids if exact else None), (None if exact else x), tgt, mode
+
+    def _batch(self, prep, idx):
+        mask, ids, feats, tgt, _ = prep
+        rb, tcol = batching.pack_padded(mask[idx], None if ids is None else ids[idx], None if tgt is None else tgt[idx],
+                                        None if feats is None else feats[idx])
+        return rb, tcol
+
+    # ---- Keras Model API -----------------------------------------------------------------------
+    def compile(self, loss="categorical_crossentropy", optimizer=None, metrics=None):
+        if loss not in ("categorical_crossentropy", "sparse_categorical_crossentropy"):
+            raise NotImplementedError("loss %r" % (loss,))
+        if optimizer is None or isinstance(optimizer, str):
+            optimizer = Adagrad()
+        if not isinstance(optimizer, Adagrad):
+            raise NotImplementedError("only Adagrad (experiments_methods.py:41) is implemented on the device")
+        self.loss, self.optimizer = loss, optimizer
+
+    def _run_epoch_batches(self, prep, order, batch_size, train):
+        import torch
+        eng = self._ensure_engine(prep[4])
+        N = len(order)
+        opt = self.optimizer
+        tot = torch.zeros(1, device=eng.dev)
+        for s in range(0, N, batch_size):
+            idx = order[s:s + batch_size]
+            rb, _ = self._batch(prep, idx)
+            d = eng.upload(rb)
+            if train:
+                l = eng.train_step(d, lr=opt.lr, eps=opt.epsilon, clipnorm=opt.clipnorm, step=self._step)
+                self._step += 1
+            else:
+                l = eng.eval_loss(d)
+            tot += l * float(len(idx))
+        return float(tot.item()) / max(N, 1)
+
+    def fit(self, x, y, validation_data=None, epochs=10, batch_size=100, verbose=1, callbacks=None, shuffle=True):
+        if self.optimizer is None:
+            raise RuntimeError("You must compile a model before training/testing.")
+        prep = self._prepare(x, y)
+        vprep = None
+        if validation_data is not None:
+            vprep = self._prepare(validation_data[0], validation_data[1])
+        hist = History()
+        cbs = [hist] + list(callbacks or [])
+        for cb in cbs:
+            cb.set_model(self)
+            cb.set_params({"epochs": epochs, "batch_size": batch_size, "verbose": verbose})
+        self.stop_training = False
+        logs0 = {}
+        for cb in cbs:
+            cb.on_train_begin(logs0)
+        N = prep[0].shape[0]
+        index = np.arange(N)
+        for epoch in range(epochs):
+            for cb in cbs:
+                cb.on_epoch_begin(epoch, {})
+            if shuffle:
+                np.random.shuffle(index)
+            logs = {"loss": self._run_epoch_batches(prep, index, batch_size, True)}
+            if vprep is not None:
+                logs["val_loss"] = self._run_epoch_batches(vprep, np.arange(vprep[0].shape[0]), batch_size, False)
+            for k, v in logs0.items():          # e.g. "my_loss" seeded by ValLossHistoryCut.on_train_begin
+                logs.setdefault(k, v)
+            for cb in cbs:
+                cb.on_epoch_end(epoch, logs)
+            if verbose:
+                print("Epoch %d/%d - " % (epoch + 1, epochs) + " - ".join("%s: %.4f" % kv for kv in logs.items()))
+            if self.stop_training:
+                break
+        for cb in cbs:
+            cb.on_train_end({})
+        return hist
+
+    def fit_generator(self, generator, steps_per_epoch, epochs=1, verbose=1, callbacks=None, validation_data=None,
+                      validation_steps=None):
+        """Keras fit_generator: each step pulls ONE (x, y) batch from the generator."""
+        import torch
+        if self.optimizer is None:
+            raise RuntimeError("You must compile a model before training/testing.")
+        hist = History()
+        cbs = [hist] + list(callbacks or [])
+        for cb in cbs:
+            cb.set_model(self)
+            cb.on_train_begin({})
+        opt = self.optimizer
+        self.stop_training = False
+        for epoch in range(epochs):
+            tot = n = 0.0
+            for _ in range(steps_per_epoch):
+                xb, yb = next(generator)[:2]
+                prep = self._prepare(xb, yb)
+                eng = self._ensure_engine(prep[4])
+                nb = prep[0].shape[0]
+                rb, _ = self._batch(prep, np.arange(nb))
+                l = eng.train_step(eng.upload(rb), lr=opt.lr, eps=opt.epsilon, clipnorm=opt.clipnorm, step=self._step)
+                self._step += 1
+                tot += float(l.item()) * nb
+                n += nb
+            logs = {"loss": tot / max(n, 1)}
+            if validation_data is not None:
+                if hasattr(validation_data, "__next__"):
+                    vt = vn = 0.0
+                    for _ in range(validation_steps or 1):
+                        xv, yv = next(validation_data)[:2]
+                        vt += self.evaluate(xv, yv, batch_size=len(self._first(xv)))[0] * len(self._first(xv))
+                        vn += len(self._first(xv))
+                    logs["val_loss"] = vt / max(vn, 1)
+                else:
+                    logs["val_loss"] = self.evaluate(validation_data[0], validation_data[1])[0]
+            for cb in cbs:
+                cb.on_epoch_end(epoch, logs)
+            if self.stop_training:
+                break
+        for cb in cbs:
+            cb.on_train_end({})
+        return hist
+
+    def evaluate(self, x, y, batch_size=32, verbose=0, sample_weight=None):
+        prep = self._prepare(x, y)
+        loss = self._run_epoch_batches(prep, np.arange(prep[0].shape[0]), batch_size, False)
+        return [loss, loss]
+
+    def predict(self, x, batch_size=32, verbose=0):
+        """(N, T, n_classes) softmax outputs; masked steps repeat the previous output, steps
+        before the first real one are the softmax of the (zero-state) bias -- Keras' behaviour."""
+        prep = self._prepare(x)
+        mask = prep[0]
+        eng = self._ensure_engine(prep[4])
+        N, T = mask.shape
+        V = self.n_classes
+        out = np.zeros((N, T, V), np.float32)
+        for s in range(0, N, batch_size):
+            idx = np.arange(s, min(N, s + batch_size))
+            rb, tcol = self._batch(prep, idx)
+            if rb.n_tok == 0:
+                continue
+            pr = eng.predict_rows(eng.upload(rb)).cpu().numpy()
+            out[idx[rb.tok_b], tcol] = pr
+        b = self._get("bout") if self.out_bias else np.zeros(V, np.float32)
+        p0 = np.exp(b - b.max())
+        p0 = (p0 / p0.sum()).astype(np.float32)
+        prev = np.broadcast_to(p0, (N, V)).copy()
+        for t in range(T):
+            m = mask[:, t]
+            out[~m, t] = prev[~m]
+            prev = out[:, t].copy()
+        return out
+
+    def hidden(self, x, batch_size=32):
+        prep = self._prepare(x)
+        mask = prep[0]
+        eng = self._ensure_engine(prep[4])
+        N, T = mask.shape
+        out = np.zeros((N, T, self.z_dim), np.float32)
+        for s in range(0, N, batch_size):
+            idx = np.arange(s, min(N, s + batch_size))
+            rb, tcol = self._batch(prep, idx)
+            if rb.n_tok == 0:
+                continue
+            h = eng.hidden_rows(eng.upload(rb)).cpu().numpy()[:, :self.z_dim]
+            out[idx[rb.tok_b], tcol] = h
+        for t in range(1, T):
+            m = mask[:, t]
+            out[~m, t] = out[~m, t - 1]
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's wrappers
+# ------------------------------------------------------------------------------------------------
+class BaseRNNModel(BaseModel):
+    def __init__(self, n_classes, model_name="test_model", rnn_type="simpleRNN"):
+        BaseModel.__init__(self, n_classes, model_name)
+        self.rnn_type = rnn_type
+
+    def compile_model(self, loss="categorical_crossentropy", metrics=[], optimizer="adam"):
+        self.model.compile(loss=loss, optimizer=optimizer, metrics=[loss] + list(metrics))
+
+    def fit_model(self, x_train, y_train, validation_data=None, n_epochs=10, batch_size=100, verbose=1, callbacks=None):
+        return self.model.fit(x_train, y_train, validation_data=validation_data, epochs=n_epochs,
+                              batch_size=batch_size, verbose=verbose, callbacks=callbacks)
+
+    def fit_generator(self, train_gen, steps_per_epoch, validation_steps, epochs, verbose, callbacks, validation_data):
+        return self.model.fit_generator(train_gen, validation_data=validation_data, callbacks=callbacks,
+                                        steps_per_epoch=steps_per_epoch, validation_steps=validation_steps,
+                                        epochs=epochs, verbose=verbose)
+
+    def predict(self, x_test, batch_size=10, verbose=1):
+        return self.model.predict(x_test, batch_size=batch_size, verbose=verbose)
+
+    def evaluate(self, x_test, y_test, batch_size=10, verbose=0):
+        scores = self.model.evaluate(x_test, y_test, verbose=verbose, batch_size=batch_size)
+        return self.model.metrics_names, scores
+
+    def save_model_weights(self, directory):
+        if not os.path.exists(directory):
+            os.makedirs(directory)
+        self.model.save_weights(directory + self.model_name + ".h5")
+
+    def load_model_weights(self, filepath):
+        self.model.load_weights(filepath, by_name=False)
+
+    def get_layer_weights(self, layer):
+        if isinstance(layer, str):
+            return self.model.get_layer(layer).get_weights()
+        return self.model.layers[layer].get_weights()
+
+    def set_layer_weights_trainable(self, name, trainable=True):
+        self.model.get_layer(name).trainable = trainable
+
+    def set_layer_weights(self, name, weights):
+        self.model.get_layer(name).set_weights(weights)
+
+    def get_model_weights(self):
+        return self.model.trainable_weights, self.model.non_trainable_weights
+
+    def get_activations(self, layer, inputs, input_layers):
+        """Outputs of a named layer in test phase: the recurrent layer -> (N,T,z_dim) states,
+        the output layer -> (N,T,n_classes) probabilities."""
+        x = inputs[0] if isinstance(inputs, (list, tuple)) else inputs
+        if layer == self.model.layers[0].name:
+            return self.model.hidden(x)
+        if layer == self.model.layers[1].name:
+            return self.model.predict(x)
+        raise ValueError("No such layer: %s" % layer)
+
+
+class RNNBaseline(BaseRNNModel):
+    def __init__(self, timesteps, features, n_classes, model_name="baseline_model", rnn_type="simpleRNN",
+                 out_activation="softmax", z_activation="relu", z_dim=20, z_to_y_drop=0.0):
+        BaseRNNModel.__init__(self, n_classes, model_name=model_name, rnn_type=rnn_type)
+        if out_activation != "softmax":
+            raise NotImplementedError("out_activation %r" % (out_activation,))
+        rnn_name = {"simpleRNN": "rnn", "LSTM": "lstm", "GRU": "gru"}.get(rnn_type, "rnn")
+        self.model = SeqModel(timesteps, features, n_classes, z_dim, rnn_type, z_activation, rnn_name, "output",
+                              use_bias=True, out_bias=True, drop_out=z_to_y_drop)
+
+
+class RNNFullModel(BaseRNNModel):
+    def __init__(self, timesteps, x_dim, y_dim, z_dim=20, model_name="y_to_y_model", rnn_type="simpleRNN",
+                 z_to_z_activation="relu", y_to_y_activation="linear", xz_to_y_activation="linear",
+                 y_to_y_w_initializer=None, out_activation="softmax", ytoy_bias=False, toy_bias=False, z_bias=True,
+                 y_to_y_regularizer=None, toy_regularizer=None, y_to_z=True, y_to_z_initializer="glorot_normal",
+                 y_to_y=True, x_to_y=True, x_to_z=False, z_to_y_dropout=0.0, diag_b=True, y_to_z_dropout=0.0,
+                 z_to_z_dropout=0.0):
+        BaseRNNModel.__init__(self, y_dim, model_name=model_name, rnn_type=rnn_type)
+        if not y_to_z or y_to_y or x_to_y or x_to_z:
+            raise NotImplementedError(
+                "only the y_to_z ('ytoz') wiring of RNNFullModel runs on the HIP path; the y_to_y / x_to_y / x_to_z "
+                "side branches (dense VxV terms, model.py:375-392) are listed as next in DESIGN.md")
+        if out_activation != "softmax" or xz_to_y_activation != "linear":
+            raise NotImplementedError("output activations other than linear->softmax")
+        if toy_regularizer is not None:
+            raise NotImplementedError("toy_regularizer")
+        # the reference passes kernel_initializer only to the LSTM (model.py:345-352)
+        kinit = y_to_z_initializer if rnn_type == "LSTM" else "glorot_uniform"
+        self.model = SeqModel(timesteps, y_dim, y_dim, z_dim, rnn_type, z_to_z_activation, "z_to_z_output", "to_y_output",
+                              use_bias=z_bias, out_bias=toy_bias, drop_in=max(y_to_z_dropout, 0.0),
+                              drop_rec=z_to_z_dropout, drop_out=max(z_to_y_dropout, 0.0), kernel_initializer=kinit)
+
+
+class ValLossHistoryCut(Callback):
+    """model.py:94-117: per epoch, predict on the validation set, take the probability of the true
+    class per step, and score the last 30 % of every sequence (utils.compute_likelihood_cut)."""
+
+    def __init__(self, val_data, orig_seqs_lengths):
+        Callback.__init__(self)
+        self.val_data = val_data
+        self.orig_seqs_lengths = orig_seqs_lengths
+
+    def on_train_begin(self, logs={}):
+        self.val_lossses = []
+        if "my_loss" not in logs:
+            logs["my_loss"] = 0.0
+
+    def on_epoch_end(self, epoch, logs={}):
+        y_pred = self.model.predict(self.val_data[0])
+        pt = np.max(np.multiply(y_pred, self.val_data[1]), axis=2)
+        pt = np.clip(pt, 1e-7, 1.0 - 1e-7)
+        _, val_neg_ll = utils.compute_likelihood_cut(pt, 0.7, orig_lengths=self.orig_seqs_lengths)
+        self.val_lossses.append(val_neg_ll)
+        logs["my_loss"] = val_neg_ll

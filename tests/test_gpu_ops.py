@@ -123,7 +123,7 @@ def test_gather_rows_bit_exact_and_variants():
 def test_bad_arguments_are_rejected_before_launch():
     lib = L.load()
     assert lib.seqrec_gather_rows(None, None, None, 5, 8, None, None, 0, None) == -1
-    assert lib.seqrec_rnn_fwd(0, 0, 100, 100, 3, 4, None, None, None, None, None, None, None, None) == -2
+    assert lib.seqrec_rnn_fwd(0, 0, 100, 100, 3, 4, None, None, None, None, None, None, None) == -2
     assert lib.seqrec_gemm_f32(1, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, 0, 1, None, None) == -1
 
 
@@ -176,14 +176,15 @@ def test_rnn_scan_forward_backward_vs_oracle(cell, H, B, maxlen, act):
     aux = torch.full((n, H), float("nan"), device="cuda")
     up = torch.empty(int(L.load().seqrec_rnn_upack_floats(L.CELL[cell], H)), device="cuda")
     XWd, Ud = dev(XW), dev(U)
-    call("seqrec_rnn_fwd", L.CELL[cell], L.ACT[act], H, H, rb.T, rb.B, ptr(so), ptr(XWd), ptr(Ud), ptr(Hout), ptr(gates),
+    call("seqrec_rnn_pack_u", L.CELL[cell], H, ptr(Ud), ptr(up), st())
+    call("seqrec_rnn_fwd", L.CELL[cell], L.ACT[act], H, H, rb.T, rb.B, ptr(so), ptr(XWd), ptr(Hout), ptr(gates),
          ptr(aux), ptr(up), st())
     got = Hout.cpu().numpy()
     scale = max(1.0, np.abs(ref["H"]).max())
     assert np.abs(got - ref["H"]).max() <= 3e-5 * scale, np.abs(got - ref["H"]).max()
     dPre = torch.full((n, G * H), float("nan"), device="cuda")
     call("seqrec_rnn_bwd", L.CELL[cell], L.ACT[act], H, H, rb.T, rb.B, ptr(so), ptr(dev(dH)), ptr(Hout), ptr(gates), ptr(aux),
-         ptr(Ud), ptr(dPre), ptr(up), st())
+         ptr(dPre), ptr(up), st())
     gp = dPre.cpu().numpy()
     s2 = max(1.0, np.abs(ref["dPre"]).max())
     # relu / hard_sigmoid kinks: a pre-activation within rounding of a kink may pick the other
@@ -198,8 +199,9 @@ def test_rnn_scan_h_real_padding_keeps_padded_units_zero():
     rb, XW, U = packed_scan_inputs(rng, "lstm", H, 20, 8)
     n = rb.n_tok
     Hout = torch.empty((n, H), device="cuda"); gates = torch.empty((n, 4 * H), device="cuda"); aux = torch.empty((n, H), device="cuda")
-    up = torch.empty(4 * H * H, device="cuda")
-    call("seqrec_rnn_fwd", 1, 1, H, Hr, rb.T, rb.B, ptr(dev(rb.step_off)), ptr(dev(XW)), ptr(dev(U)), ptr(Hout), ptr(gates), ptr(aux), ptr(up), st())
+    up = torch.empty(8 * H * H, device="cuda")
+    call("seqrec_rnn_pack_u", 1, H, ptr(dev(U)), ptr(up), st())
+    call("seqrec_rnn_fwd", 1, 1, H, Hr, rb.T, rb.B, ptr(dev(rb.step_off)), ptr(dev(XW)), ptr(Hout), ptr(gates), ptr(aux), ptr(up), st())
     h = Hout.cpu().numpy()
     assert np.all(h[:, Hr:] == 0) and np.abs(h[:, :Hr]).max() > 0
 

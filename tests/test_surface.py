@@ -1,0 +1,181 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU needed)."""
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import rng as orng
+
+P = "seq-recommendations_amd."
+utils = importlib.import_module(P + "utils")
+model = importlib.import_module(P + "model")
+kc = importlib.import_module(P + "keras_compat")
+pp = importlib.import_module(P + "preprocessor")
+em = importlib.import_module(P + "experiments_methods")
+sampling = importlib.import_module(P + "sampling")
+synthetic = importlib.import_module(P + "synthetic")
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_utils_sampler.json")))["cases"]
+
+
+def test_product_metrics_match_reference_golden():
+    c = G["model_py_example"]
+    seqs, n = c["seqs"], c["n"]
+    np.testing.assert_array_equal(utils.multinomial_probabilities(seqs, n, 1.0), np.array(c["multinomial_k1"]))
+    A, g = utils.transition_matrix(seqs, n, k=10e-7, freq=False, end_state=False)
+    np.testing.assert_array_equal(A, np.array(c["transition_k1e-6"]["alpha"]))
+    A2, g2 = utils.transition_matrix(seqs, n, k=1.0, freq=True, end_state=True)
+    np.testing.assert_array_equal(A2, np.array(c["transition_counts_end_state"]["alpha"]))
+    mk = model.MarkovModel(n, k=10e-7)
+    mk.fit_model(seqs)
+    preds = mk.predict(seqs)
+    assert utils.compute_likelihood(preds) == c["compute_likelihood"]
+    assert list(utils.compute_likelihood_cut(preds, 0.7)) == c["compute_likelihood_cut_0.7"]
+    o = c["compute_likelihood_cut_orig_lengths"]
+    assert list(utils.compute_likelihood_cut(o["padded"], 0.7, orig_lengths=o["lengths"])) == o["out"]
+    mm = model.MultinomialModel(n, k=1.0)
+    mm.fit_model(seqs)
+    assert mm.predict([[0, 1]])[0] == [c["multinomial_k1"][0][0], c["multinomial_k1"][0][1]]
+    assert utils.compute_seq_max_length(seqs) == c["compute_seq_max_length"]
+    assert utils.chop_sequences(seqs, 4) == c["chop_sequences_4"]
+    m2, r2 = em.run_markov(seqs, seqs, n, k=10e-7)
+    assert r2.val_loss == c["compute_likelihood"]
+
+
+def test_preprocessor_pairing_and_pre_padding():
+    seqs = [[3, 1, 0, 2], [2, 2], [1], [0, 1, 2, 3, 0, 1]]
+    vocab = {i: i for i in range(4)}
+    xs = [[[float(i == v) for i in range(4)] for v in s] for s in seqs]
+    pre = pp.FullModelPreprocessor(vocab, 0., None)
+    x, y, c = pre.transform_data(seqs, xs)
+    assert x.shape == y.shape == c.shape == (4, 5, 4) and x.dtype == np.float64
+    assert x[0].argmax(1).tolist()[2:] == [3, 1, 0] and y[0].argmax(1).tolist()[2:] == [1, 0, 2]
+    assert x[0, :2].sum() == 0 and x[2].sum() == 0                      # pre-padding; 1-item session is all pad
+    assert x[3].argmax(1).tolist() == [0, 1, 2, 3, 0] and y[3].argmax(1).tolist() == [1, 2, 3, 0, 1]
+    np.testing.assert_array_equal(c[0, 2:], np.eye(4)[[3, 1, 0]])
+    pre2 = pp.FullModelPreprocessor(vocab, 0., 3)                       # truncating='pre' keeps the tail
+    x2, y2, _ = pre2.transform_data(seqs, xs)
+    assert x2.shape == (4, 3, 4) and x2[3].argmax(1).tolist() == [2, 3, 0] and y2[3].argmax(1).tolist() == [3, 0, 1]
+    sp = pp.FullModelPreprocessor(vocab, 0., None, sparse=True)
+    xs_, ys_, _ = sp.transform_data(seqs, xs)
+    assert xs_.shape == (4, 5, 1) and xs_[0, 2:, 0].tolist() == [3, 1, 0] and ys_[0, 2:, 0].tolist() == [1, 0, 2]
+    bp = pp.BaselinePreprocessor(vocab, 0., None)
+    xb, yb = bp.transform_data(seqs, xs=xs)
+    assert xb.shape == (3, 5, 8) and yb.shape == (3, 5, 4)              # the 1-item session is dropped
+    x_t, y_t, tx, x_v, y_v, vx = em.prepare_model_input(seqs, seqs[:2], xs, xs[:2], vocab, 5)
+    assert x_t.shape == (4, 5, 4) and x_v.shape == (2, 5, 4)
+    gen = pre.gen_data(seqs, xs, with_xs=False, with_x=True, batch_size=3)
+    a, b = next(gen)
+    a2, _ = next(gen)
+    assert a.shape[0] == 3 and not np.array_equal(a[0], a2[0])          # advances (the reference's does not)
+
+
+def test_keras_compat_helpers():
+    assert kc.to_categorical([1, 0, 2], 4).tolist() == [[0, 1, 0, 0], [1, 0, 0, 0], [0, 0, 1, 0]]
+    p = kc.pad_sequences([[1, 2, 3], [4], []], maxlen=2, value=9)
+    assert p.tolist() == [[2, 3], [9, 4], [9, 9]]
+
+    class M:
+        stop_training = False
+        saved = []
+
+        def save_weights(self, path):
+            self.saved.append(path)
+
+    es = kc.EarlyStopping(monitor="val_loss", patience=2)
+    m = M()
+    es.set_model(m)
+    es.on_train_begin()
+    stops = []
+    for e, v in enumerate([1.0, 0.9, 0.95, 0.93, 0.92, 0.91]):
+        es.on_epoch_end(e, {"val_loss": v})
+        stops.append(m.stop_training)
+        if m.stop_training:
+            break
+    assert stops == [False, False, False, False, True] and es.stopped_epoch == 4
+    ck = kc.ModelCheckpoint("d/m.{epoch:02d}-{val_loss:.2f}.hdf5", save_best_only=True, save_weights_only=True)
+    ck.set_model(m)
+    for e, v in enumerate([1.0, 1.2, 0.5]):
+        ck.on_epoch_end(e, {"val_loss": v})
+    assert m.saved == ["d/m.01-1.00.hdf5", "d/m.03-0.50.hdf5"]
+    h = kc.History()
+    h.on_train_begin()
+    h.on_epoch_end(0, {"loss": 2.0})
+    assert h.history == {"loss": [2.0]}
+    with pytest.raises(NotImplementedError):
+        kc.Adagrad(decay=0.1)
+    o = kc.initialize("orthogonal", (8, 32))
+    np.testing.assert_allclose(o @ o.T, np.eye(8), atol=1e-5)
+    assert kc.initialize(model.ArrayInitializer(np.ones((2, 3))), (2, 3)).tolist() == [[1, 1, 1], [1, 1, 1]]
+
+
+def test_model_surface_without_gpu(tmp_path):
+    np.random.seed(0)
+    m = model.RNNFullModel(timesteps=9, x_dim=17, y_dim=17, z_dim=10, model_name="ytoz", rnn_type="LSTM",
+                           y_to_y=False, x_to_y=False, z_to_y_dropout=0.3)
+    assert m.n_classes == 17 and m.rnn_type == "LSTM" and m.model_name == "ytoz"
+    k, u, b = m.get_layer_weights("z_to_z_output")
+    assert k.shape == (17, 40) and u.shape == (10, 40) and b.shape == (40,)
+    assert b[10:20].tolist() == [1.0] * 10 and b[:10].sum() == 0          # unit_forget_bias
+    np.testing.assert_allclose(u @ u.T, np.eye(10), atol=1e-5)            # orthogonal recurrent kernel
+    (w,) = m.get_layer_weights("to_y_output")
+    assert w.shape == (10, 17)                                            # toy_bias=False
+    m.set_layer_weights("to_y_output", [np.full((10, 17), 0.5)])
+    assert m.get_layer_weights(1)[0][0, 0] == 0.5
+    m.set_layer_weights_trainable("to_y_output", False)
+    tw, ntw = m.get_model_weights()
+    assert ntw == ["to_y_output/Wout"] and len(tw) == 3
+    m.save_model_weights(str(tmp_path) + "/")
+    m2 = model.RNNFullModel(9, 17, 17, z_dim=10, model_name="other", rnn_type="LSTM", y_to_y=False, x_to_y=False)
+    m2.load_model_weights(str(tmp_path) + "/ytoz.h5")
+    for a, b_ in zip(m.model.get_weights(), m2.model.get_weights()):
+        np.testing.assert_array_equal(a, b_)
+    base = model.RNNBaseline(9, 17, 17, rnn_type="simpleRNN", z_dim=5)
+    assert [l.name for l in base.model.layers] == ["rnn", "output"] and len(base.get_layer_weights("output")) == 2
+    with pytest.raises(NotImplementedError):
+        model.RNNFullModel(9, 17, 17)                                     # default flags use the side branches
+    with pytest.raises(ValueError):
+        model.RNNBaseline(9, 17, 17, rnn_type="nope")
+    with pytest.raises(RuntimeError):
+        m.fit_model(np.zeros((2, 9, 17)), np.zeros((2, 9, 17)))           # not compiled
+
+
+def test_alias_table_host_code_matches_oracle_spec_and_distribution():
+    for V in (7, 1000, 20011):
+        probs = sampling.log_uniform_probs(V)
+        np.testing.assert_array_equal(probs, orng.log_uniform_probs(V))
+        th, al = sampling.build_alias_table(probs)
+        th2, al2 = orng.build_alias_table(probs)
+        np.testing.assert_array_equal(th, th2)
+        np.testing.assert_array_equal(al, al2)
+    V = 50
+    probs = sampling.unigram_probs(np.arange(1, V + 1), 0.75)
+    th, al = sampling.build_alias_table(probs)
+    draws = orng.alias_draw(orng.rand64(5, orng.STREAM_NEG, np.arange(400000)), th, al)
+    emp = np.bincount(draws, minlength=V) / draws.size
+    assert np.abs(emp - probs).max() < 4e-3
+
+
+def test_synthetic_sessions_shape():
+    g = synthetic.SyntheticSessions(5000, seed=1234)
+    flat, starts = g.generate(4000)
+    L = np.diff(starts)
+    assert L.min() >= 2 and L.max() <= 50 and 5.0 < L.mean() < 7.0          # MSNBC-shaped (mean ~6 items)
+    assert flat.min() >= 0 and flat.max() < 5000
+    # first-order structure: the successor sets are used ~80 % of the time
+    hits = tot = 0
+    for i in range(500):
+        s = flat[starts[i]:starts[i + 1]]
+        for a, b in zip(s[:-1], s[1:]):
+            hits += b in g.succ[a]
+            tot += 1
+    assert 0.75 < hits / tot < 0.92
+    f2, s2 = synthetic.SyntheticSessions(5000, seed=1234).generate(4000)
+    np.testing.assert_array_equal(flat, f2)                                  # seeded
+    fs, ss = g.generate(10, saturated=True)
+    assert np.all(np.diff(ss) == 50)
+    # items are Zipf over the frequency ranks used by the log-uniform proposal
+    r = g.proposal_rank()[flat]
+    assert np.median(r) < 5000 / 4
