@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--recall-steps", type=int, default=1500, help="extra training steps before Recall@20 (0 = skip)")
     ap.add_argument("--recall-sessions", type=int, default=2048)
+    ap.add_argument("--force-sharded", action="store_true", help="use the row-sharded engine even on one GPU")
     return ap.parse_args()
 
 
@@ -109,10 +110,11 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
     dist = None
-    if world > 1:
+    if world > 1 or a.force_sharded:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     pkg = importlib.import_module("seq-recommendations_amd")
@@ -127,16 +129,29 @@ def main():
     dev = "cuda:%d" % local
     ncfg = E.NetConfig(cell=cd["cell"], act="relu", H=H, V_in=V, V_out=V, input="embed", D=D, output="sampled", K=K,
                        tied=False, use_bias=True, out_bias=False, logq=True, seed=1234)
-    if world > 1:
+    sharded = dist is not None
+    if sharded:
         Dm = importlib.import_module("seq-recommendations_amd.distributed")
         eng = Dm.ShardedEngine(ncfg, dev, dist)
     else:
         eng = E.Engine(ncfg, dev)
-    init_params_device(eng, cd, seed=1234)
+    init_params_device(eng, cd, seed=1234 + rank)
+    if sharded and world > 1:
+        for k in ("W", "U", "b"):                       # replicated cell weights: rank 0's values everywhere
+            dist.broadcast(eng.P[k], src=0)
+        eng.upack_dirty = True
     gen = Sy.SyntheticSessions(V, seed=1234)
-    th, al = Sm.build_alias_table(Sm.log_uniform_probs(V, gen.proposal_rank()))
-    logq = np.log(Sm.log_uniform_probs(V, gen.proposal_rank())).astype(np.float32)
-    eng.set_sampler(th, al, logq)
+    probs = Sm.log_uniform_probs(V, gen.proposal_rank())
+    th, al = Sm.build_alias_table(probs)
+    logq = np.log(probs).astype(np.float32)
+    if sharded:
+        # shard-local proposal (rows rank, rank+R, ...) and the effective Q(v) = Q_shard(v) / R
+        pl = probs[rank::world]
+        pl = pl / pl.sum()
+        thl, all_ = Sm.build_alias_table(pl)
+        eng.set_sampler(thl, all_, (np.log(pl) - np.log(world)).astype(np.float32))
+    else:
+        eng.set_sampler(th, al, logq)
 
     # ---- batches: generated once, packed on the host, index arrays resident in HBM before timing
     nb = max(1, min(a.distinct_batches, a.steps + a.warmup))
@@ -208,7 +223,7 @@ def main():
 
     # ---- Recall@20 on held-out sessions after some more training
     recall = None
-    if a.recall_steps > 0 and world == 1:
+    if a.recall_steps > 0 and not sharded:
         for i in range(a.recall_steps):
             eng.train_step(batches[step % nb], lr=0.01, eps=1e-8, clipnorm=1.0, step=step)
             step += 1
@@ -223,7 +238,7 @@ def main():
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload
     cpu = None
-    if rank == 0 and world == 1 and a.cpu_seconds > 0:
+    if rank == 0 and world == 1 and not sharded and a.cpu_seconds > 0:
         cpu = cpu_baseline(a, cd, gen, flat, starts, th, al, logq)
 
     if rank == 0:
@@ -233,7 +248,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cd["desc"] + (" (saturated: 50 items/session)" if a.saturated else " (MSNBC-shaped lengths)"),
                        "global_batch": a.batch * world, "seq_len": 50, "tokens_per_step_per_gpu": round(n_tok_mean, 1),
-                       "t_max": t_max, "parallelism": "dp%d" % world if world > 1 else "single"},
+                       "t_max": t_max, "parallelism": ("dp%d+row-sharded-tables" % world) if sharded else "single"},
             "tokens_per_s": round(tokens_per_s, 1), "final_loss": round(last_loss, 5), "recall_at_20": recall,
             "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
         }

@@ -106,6 +106,13 @@ int seqrec_sampled_softmax_ce(float* ln, int64_t ld, const float* hd, int H, con
                               const float* bout, const float* logq, const int32_t* tgt,
                               const int32_t* neg, int64_t n, int K, float inv_denom,
                               float* loss_rows, float* dlt, void* stream);
+/*      same, for row-sharded tables (multi-GPU): Etgt [n,H] holds the target rows already fetched
+ *      from their owners (row i for token i), lq_tgt [n] / lq_neg [K] the candidates' log-Q values
+ *      (nullable); tgt / neg are GLOBAL item ids, used only for accidental-hit removal. */
+int seqrec_sampled_softmax_ce_rows(float* ln, int64_t ld, const float* hd, int H, const float* Etgt,
+                                   const float* lq_tgt, const float* lq_neg, const int32_t* tgt,
+                                   const int32_t* neg, int64_t n, int K, float inv_denom,
+                                   float* loss_rows, float* dlt, void* stream);
 /* ---- out[0] (+)= sum_i x[i], one workgroup, fixed summation order (deterministic) */
 int seqrec_reduce_sum(const float* x, int64_t n, float* out, int accumulate, void* stream);
 

@@ -42,6 +42,7 @@ _SIGS = {
     "seqrec_rnn_bwd": [I, I, I, I, I, I, P, P, P, P, P, P, P, P],
     "seqrec_full_softmax_ce": [P, L, P, L, I, F, P, P, P],
     "seqrec_sampled_softmax_ce": [P, L, P, I, P, P, P, P, P, L, I, F, P, P, P],
+    "seqrec_sampled_softmax_ce_rows": [P, L, P, I, P, P, P, P, P, L, I, F, P, P, P],
     "seqrec_reduce_sum": [P, L, P, I, P],
     "seqrec_colsum": [P, L, I, L, P, I, P, P],
     "seqrec_mul": [P, P, P, L, P],

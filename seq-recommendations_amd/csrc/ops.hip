@@ -81,29 +81,41 @@ __global__ void full_softmax_ce_kernel(float* __restrict__ logits, long ld, cons
 // ---------------------------------------------------------------------------------------------
 // sampled softmax + CE over {target} U K negatives, one wave per token row
 // ---------------------------------------------------------------------------------------------
+// ROWS = false: target row = Eout[tgt[i]], bout/logq indexed by item id (single-GPU tables)
+// ROWS = true : target row = Eout[i] (rows already fetched from their owners), lq_t[i] / lq_n[k]
+//               are the per-candidate log-Q values (multi-GPU, row-sharded tables)
+template <bool ROWS>
 __global__ void sampled_softmax_ce_kernel(float* __restrict__ ln, long ld, const float* __restrict__ hd, int H,
                                           const float* __restrict__ Eout, const float* __restrict__ bout,
-                                          const float* __restrict__ logq, const int* __restrict__ tgt,
-                                          const int* __restrict__ neg, long n, int K, float inv_denom,
-                                          float* __restrict__ loss_rows, float* __restrict__ dlt) {
+                                          const float* __restrict__ logq, const float* __restrict__ lq_n,
+                                          const int* __restrict__ tgt, const int* __restrict__ neg, long n, int K,
+                                          float inv_denom, float* __restrict__ loss_rows, float* __restrict__ dlt) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= n) return;
     const int t = tgt[row];
     const float* h = hd + row * H;
-    const float* et = Eout + (long)t * H;
+    const float* et = Eout + (ROWS ? row : (long)t) * H;
     float d = 0.f;
     for (int j = lane; j < H; j += 64) d += h[j] * et[j];
     float lt = wave_sum(d);
-    if (bout) lt += bout[t];
-    if (logq) lt -= logq[t];
+    if (ROWS) {
+        if (logq) lt -= logq[row];
+    } else {
+        if (bout) lt += bout[t];
+        if (logq) lt -= logq[t];
+    }
     float* x = ln + row * ld;
     float m = lt;
     for (int k = lane; k < K; k += 64) {
         const int v = neg[k];
         float l = x[k];
-        if (bout) l += bout[v];
-        if (logq) l -= logq[v];
+        if (ROWS) {
+            if (lq_n) l -= lq_n[k];
+        } else {
+            if (bout) l += bout[v];
+            if (logq) l -= logq[v];
+        }
         if (v == t) l = -INFINITY;
         x[k] = l;
         m = fmaxf(m, l);
@@ -319,8 +331,22 @@ extern "C" int seqrec_sampled_softmax_ce(float* ln, int64_t ld, const float* hd,
     if (n < 0 || K < 0 || H <= 0 || ld < K) return SEQREC_E_ARG;
     if (n == 0) return 0;
     if (!ln || !hd || !Eout || !tgt || (K > 0 && !neg) || !loss_rows || !dlt) return SEQREC_E_ARG;
-    hipLaunchKernelGGL(sampled_softmax_ce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), ln,
-                       (long)ld, hd, H, Eout, bout, logq, tgt, neg, (long)n, K, inv_denom, loss_rows, dlt);
+    hipLaunchKernelGGL(sampled_softmax_ce_kernel<false>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), ln,
+                       (long)ld, hd, H, Eout, bout, logq, (const float*)nullptr, tgt, neg, (long)n, K, inv_denom, loss_rows, dlt);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int seqrec_sampled_softmax_ce_rows(float* ln, int64_t ld, const float* hd, int H, const float* Etgt,
+                                              const float* lq_tgt, const float* lq_neg, const int32_t* tgt,
+                                              const int32_t* neg, int64_t n, int K, float inv_denom,
+                                              float* loss_rows, float* dlt, void* stream) {
+    if (n < 0 || K < 0 || H <= 0 || ld < K) return SEQREC_E_ARG;
+    if (n == 0) return 0;
+    if (!ln || !hd || !Etgt || !tgt || (K > 0 && !neg) || !loss_rows || !dlt) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(sampled_softmax_ce_kernel<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), ln,
+                       (long)ld, hd, H, Etgt, (const float*)nullptr, lq_tgt, lq_neg, tgt, neg, (long)n, K, inv_denom,
+                       loss_rows, dlt);
     SEQREC_LAUNCH_CHECK();
     return 0;
 }

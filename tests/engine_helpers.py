@@ -75,10 +75,10 @@ def oracle_drop(ecfg, sessions, batch, step):
 class Pair:
     """An Engine and an OracleNet holding the same parameters."""
 
-    def __init__(self, ecfg, ocfg, params, device="cuda:0"):
+    def __init__(self, ecfg, ocfg, params, device="cuda:0", engine_factory=None):
         E = importlib.import_module("seq-recommendations_amd.engine")
         self.ecfg, self.ocfg = ecfg, ocfg
-        self.eng = E.Engine(ecfg, device)
+        self.eng = engine_factory(ecfg, device) if engine_factory else E.Engine(ecfg, device)
         for k, v in params.items():
             self.eng.set_param(k, v)
         self.op = {k: v.copy() for k, v in params.items()}

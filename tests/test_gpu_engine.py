@@ -126,3 +126,37 @@ def test_eval_predict_and_recall_paths():
     ref_rank = (scores > ts[:, None]).sum(1)
     assert (rank == ref_rank).mean() > 0.97 and np.abs(rank - ref_rank).max() <= 2
     assert abs(om.recall_at_k(scores, rb.tgt, 20) - float((rank < 20).mean())) < 0.05
+
+
+def test_sharded_engine_single_rank_equals_oracle():
+    """ShardedEngine over a 1-rank RCCL group: every exchange degenerates to a local copy, so losses
+    and gradients must equal the oracle exactly like the plain engine (the N>1 routing itself is
+    covered by the gloo tests in test_distributed_cpu.py)."""
+    import importlib
+    import os
+    import torch
+    import torch.distributed as dist
+    D = importlib.import_module("seq-recommendations_amd.distributed")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        rng = np.random.default_rng(9)
+        for case in (dict(cell="gru", act="relu", H=128, V=3000, inp="embed", out="sampled", D=128, K=200, logq=True),
+                     dict(cell="lstm", act="relu", H=64, V=1000, inp="embed", out="sampled", D=32, K=64),
+                     dict(cell="gru", act="tanh", H=64, V=1500, inp="embed", out="sampled", D=64, K=64, tied=True)):
+            ecfg, ocfg = make_cfg(**case)
+            pair = Pair(ecfg, ocfg, init_np_params(rng, ocfg, case["V"], case["H"], case["D"]),
+                        engine_factory=lambda c, dev: D.ShardedEngine(c, dev, dist))
+            for step in range(3):
+                lg, lo, sc = pair.step(make_sessions(rng, 40, case["V"], 2, 12), step, lr=0.01, check_grads=True)
+                assert abs(lg - lo) <= 1e-3 * max(1.0, abs(lo)), (case, step, lg, lo)
+                if step == 0:
+                    assert abs(lg - lo) <= 2e-5 * max(1.0, abs(lo))
+                    assert max(pair.grad_err.values()) < 2e-4, pair.grad_err
+    finally:
+        if created:
+            dist.destroy_process_group()
