@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libseqrec_hip.so")
+# SEQREC_LIB lets a developer point at an experimental build of the SAME library (tools/); it is
+# never a fallback: if it is set and missing, loading fails.
+LIB_PATH = os.environ.get("SEQREC_LIB") or os.path.join(HERE, "libseqrec_hip.so")
 
 CELL = {"simplernn": 0, "lstm": 1, "gru": 2}
 ACT = {"relu": 0, "tanh": 1, "linear": 2}
@@ -40,6 +42,9 @@ _SIGS = {
     "seqrec_rnn_pack_u": [I, I, P, P, P],
     "seqrec_rnn_fwd": [I, I, I, I, I, I, P, P, P, P, P, P, P],
     "seqrec_rnn_bwd": [I, I, I, I, I, I, P, P, P, P, P, P, P, P],
+    "seqrec_rnn_pack_u_stepwise": [I, I, P, P, P],
+    "seqrec_rnn_fwd_stepwise": [I, I, I, I, I, I, P, P, P, P, P, P, P],
+    "seqrec_rnn_bwd_stepwise": [I, I, I, I, I, I, P, P, P, P, P, P, P, P, P],
     "seqrec_full_softmax_ce": [P, L, P, L, I, F, P, P, P],
     "seqrec_sampled_softmax_ce": [P, L, P, I, P, P, P, P, P, L, I, F, P, P, P],
     "seqrec_sampled_softmax_ce_rows": [P, L, P, I, P, P, P, P, P, L, I, F, P, P, P],

@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libseqrec_hip.so")
-SOURCES = ["gemm.hip", "ops.hip", "rnn.hip"]
+SOURCES = ["gemm.hip", "ops.hip", "rnn.hip", "rnn_step.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]
 
 

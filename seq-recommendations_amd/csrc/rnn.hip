@@ -41,15 +41,29 @@ struct RnnArgs {
     float* dPre;
 };
 
-__device__ __forceinline__ float act_f(int act, float x) {
-    if (act == SEQREC_ACT_RELU) return fmaxf(x, 0.f);
-    if (act == SEQREC_ACT_TANH) return tanhf(x);
-    return x;
+// Branch-free guarded global access: raw buffer ops drop (stores) or zero (loads) any lane whose
+// byte offset is >= num_records, so inactive rows of a 16-row block get the INVALID offset
+// instead of an exec-mask branch around every access (hipcc would otherwise emit one
+// s_cbranch_execz per guarded load and serialise their latencies).  The per-step base goes into the
+// scalar offset.  All buffers of one launch are < 2 GiB (host check).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr int INVALID_OFF = 0x7FFFFFF0;
+__device__ __forceinline__ rsrc_t mk_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, INVALID_OFF, 0x00020000);
 }
-__device__ __forceinline__ float act_g(int act, float y) {
-    if (act == SEQREC_ACT_RELU) return y > 0.f ? 1.f : 0.f;
-    if (act == SEQREC_ACT_TANH) return 1.f - y * y;
-    return 1.f;
+__device__ __forceinline__ float bload(rsrc_t r, int voff, int soff) {
+#ifdef SEQREC_PROBE_NO_LOADS      // timing-only ablation builds (tools/), never shipped
+    return 0.5f;
+#else
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+#endif
+}
+__device__ __forceinline__ void bstore(rsrc_t r, int voff, int soff, float v) {
+#ifdef SEQREC_PROBE_NO_STORES
+    asm volatile("" ::"v"(v));
+#else
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+#endif
 }
 
 template <int VEC> struct VecT;
@@ -114,6 +128,15 @@ struct WaveGemm {
     }
 };
 
+// Workgroup barrier that orders LDS traffic only: waits for this wave's LDS ops (lgkmcnt), not
+// for its global stores/loads (vmcnt) -- the stash stores of a step and the next phase's U
+// prefetch stay in flight across it (a __syncthreads() would drain them: +~4 us per step).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 template <int N> __device__ __forceinline__ void zero_acc(f32x4 (&acc)[N]) {
 #pragma unroll
     for (int i = 0; i < N; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -170,10 +193,16 @@ __global__ void pack_u_kernel(PackArgs pa) {
     const int r0 = blockIdx.x * 16;                            \
     const int cbase = 16 * J * w + cc;
 
+// per-lane byte offsets of accumulator register r (row 4*rq + r) in a [*, ld] float buffer
+#define ROW_OFFSETS(NAME, LD)                                                      \
+    int NAME[4];                                                                   \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r)                                  \
+        NAME[r] = (4 * rq + r) < nact ? ((4 * rq + r) * (LD) + cbase) * 4 : INVALID_OFF;
+
 // ------------------------------------------------------------------------------------------
 // SimpleRNN:  h = act(xw + h_prev . U)
 // ------------------------------------------------------------------------------------------
-template <int J>
+template <int J, int ACT>
 __global__ __launch_bounds__(256) void srnn_fwd_kernel(RnnArgs a) {
     constexpr int H = 64 * J, LDA = H + 2, KB = H / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -183,22 +212,21 @@ __global__ __launch_bounds__(256) void srnn_fwd_kernel(RnnArgs a) {
     for (int i = tid; i < 32 * LDA; i += 256) smem[i] = 0.f;
     __syncthreads();
     const float* pk = a.pk0 + (size_t)w * H * (16 * J);
+    const rsrc_t rXW = mk_rsrc(a.XW), rH = mk_rsrc(a.Hout);
     WaveGemm<J> gm;
     int cur = 0;
     for (int t = 0; t < a.T; ++t) {
         const int o0 = a.step_off[t], bt = a.step_off[t + 1] - o0;
         if (bt <= r0) break;
         const int nact = min(16, bt - r0);
-        const long p0 = (long)o0 + r0;
+        const int so = (o0 + r0) * H * 4;
+        ROW_OFFSETS(vo, H);
         gm.preload(pk, lane);
         float x[J][4];
 #pragma unroll
         for (int j = 0; j < J; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 4 * rq + r;
-                x[j][r] = row < nact ? a.XW[(p0 + row) * H + cbase + 16 * j] : 0.f;
-            }
+            for (int r = 0; r < 4; ++r) x[j][r] = bload(rXW, vo[r] + 64 * j, so);
         float* hc_ = cur ? hb1 : hb0;
         float* hn_ = cur ? hb0 : hb1;
         f32x4 acc[J];
@@ -209,23 +237,24 @@ __global__ __launch_bounds__(256) void srnn_fwd_kernel(RnnArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 4 * rq + r, col = cbase + 16 * j;
-                float y = act_f(a.act, acc[j][r] + x[j][r]);
+                float y = act_fwd<ACT>(acc[j][r] + x[j][r]);
                 if (col >= a.H_real) y = 0.f;
                 hn_[row * LDA + col] = y;
-                if (row < nact) a.Hout[(p0 + row) * H + col] = y;
+                bstore(rH, vo[r] + 64 * j, so, y);
             }
-        __syncthreads();
+        lds_barrier();
         cur ^= 1;
     }
 }
 
-template <int J>
+template <int J, int ACT>
 __global__ __launch_bounds__(256) void srnn_bwd_kernel(RnnArgs a) {
     constexpr int H = 64 * J, LDP = H + 2, KB = H / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     ROWCOL_SETUP();
     float* dp = smem;
     const float* pk = a.pk0 + (size_t)w * H * (16 * J);
+    const rsrc_t rDH = mk_rsrc(a.dHout), rH = mk_rsrc(a.HoutR), rDP = mk_rsrc(a.dPre);
     WaveGemm<J> gm;
     float dhc[J][4];
 #pragma unroll
@@ -237,23 +266,20 @@ __global__ __launch_bounds__(256) void srnn_bwd_kernel(RnnArgs a) {
     for (int t = tb - 1; t >= 0; --t) {
         const int o0 = a.step_off[t], bt = a.step_off[t + 1] - o0;
         const int nact = min(16, bt - r0);
-        const long p0 = (long)o0 + r0;
+        const int so = (o0 + r0) * H * 4;
+        ROW_OFFSETS(vo, H);
         gm.preload(pk, lane);
 #pragma unroll
         for (int j = 0; j < J; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 4 * rq + r, col = cbase + 16 * j;
-                float d = 0.f;
-                if (row < nact) {
-                    const long q = (p0 + row) * H + col;
-                    const float dh = dhc[j][r] + a.dHout[q];
-                    d = dh * act_g(a.act, a.HoutR[q]);
-                    a.dPre[q] = d;
-                }
+                const float dh = dhc[j][r] + bload(rDH, vo[r] + 64 * j, so);
+                const float d = (row < nact) ? dh * act_grad<ACT>(bload(rH, vo[r] + 64 * j, so)) : 0.f;
+                bstore(rDP, vo[r] + 64 * j, so, d);
                 dp[row * LDP + col] = d;
             }
-        __syncthreads();
+        lds_barrier();
         f32x4 acc[J];
         zero_acc(acc);
         gm.run(dp, LDP, pk, KB, lane, acc);
@@ -261,14 +287,14 @@ __global__ __launch_bounds__(256) void srnn_bwd_kernel(RnnArgs a) {
         for (int j = 0; j < J; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) dhc[j][r] = acc[j][r];
-        __syncthreads();
+        lds_barrier();
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // LSTM (gate order i,f,c,o; hard_sigmoid gates; act on candidate and on c)
 // ------------------------------------------------------------------------------------------
-template <int J>
+template <int J, int ACT>
 __global__ __launch_bounds__(256) void lstm_fwd_kernel(RnnArgs a) {
     constexpr int H = 64 * J, LDA = H + 2, KB = H / 4, GH = 4 * H;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -278,6 +304,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(RnnArgs a) {
     for (int i = tid; i < 32 * LDA; i += 256) smem[i] = 0.f;
     __syncthreads();
     const float* pk = a.pk0 + (size_t)w * H * (64 * J);
+    const rsrc_t rXW = mk_rsrc(a.XW), rH = mk_rsrc(a.Hout), rG = mk_rsrc(a.gates), rC = mk_rsrc(a.aux);
     WaveGemm<4 * J> gm;
     float cst[J][4];
 #pragma unroll
@@ -289,7 +316,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(RnnArgs a) {
         const int o0 = a.step_off[t], bt = a.step_off[t + 1] - o0;
         if (bt <= r0) break;
         const int nact = min(16, bt - r0);
-        const long p0 = (long)o0 + r0;
+        const int soG = (o0 + r0) * GH * 4, soH = (o0 + r0) * H * 4;
+        ROW_OFFSETS(voG, GH);
+        ROW_OFFSETS(voH, H);
         gm.preload(pk, lane);
         float x[4][J][4];
 #pragma unroll
@@ -297,10 +326,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(RnnArgs a) {
 #pragma unroll
             for (int j = 0; j < J; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * rq + r;
-                    x[g][j][r] = row < nact ? a.XW[(p0 + row) * GH + g * H + cbase + 16 * j] : 0.f;
-                }
+                for (int r = 0; r < 4; ++r) x[g][j][r] = bload(rXW, voG[r] + (g * H + 16 * j) * 4, soG);
         float* hc_ = cur ? hb1 : hb0;
         float* hn_ = cur ? hb0 : hb1;
         f32x4 acc[4 * J];
@@ -313,33 +339,33 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(RnnArgs a) {
                 const int row = 4 * rq + r, col = cbase + 16 * j;
                 const float gi = hard_sigmoid(acc[0 * J + j][r] + x[0][j][r]);
                 const float gf = hard_sigmoid(acc[1 * J + j][r] + x[1][j][r]);
-                const float gg = act_f(a.act, acc[2 * J + j][r] + x[2][j][r]);
+                const float gg = act_fwd<ACT>(acc[2 * J + j][r] + x[2][j][r]);
                 const float go = hard_sigmoid(acc[3 * J + j][r] + x[3][j][r]);
                 float c = gf * cst[j][r] + gi * gg;
-                float h = go * act_f(a.act, c);
+                float h = go * act_fwd<ACT>(c);
                 if (col >= a.H_real) { c = 0.f; h = 0.f; }
                 cst[j][r] = c;
                 hn_[row * LDA + col] = h;
-                if (row < nact) {
-                    const long q = p0 + row;
-                    a.Hout[q * H + col] = h;
-                    a.aux[q * H + col] = c;
-                    float* gp = a.gates + q * GH + col;
-                    gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
-                }
+                bstore(rH, voH[r] + 64 * j, soH, h);
+                bstore(rC, voH[r] + 64 * j, soH, c);
+                bstore(rG, voG[r] + (0 * H + 16 * j) * 4, soG, gi);
+                bstore(rG, voG[r] + (1 * H + 16 * j) * 4, soG, gf);
+                bstore(rG, voG[r] + (2 * H + 16 * j) * 4, soG, gg);
+                bstore(rG, voG[r] + (3 * H + 16 * j) * 4, soG, go);
             }
-        __syncthreads();
+        lds_barrier();
         cur ^= 1;
     }
 }
 
-template <int J>
+template <int J, int ACT>
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(RnnArgs a) {
     constexpr int H = 64 * J, GH = 4 * H, LDP = GH + 2, KB = GH / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     ROWCOL_SETUP();
     float* dp = smem;
     const float* pk = a.pk0 + (size_t)w * GH * (16 * J);
+    const rsrc_t rDH = mk_rsrc(a.dHout), rG = mk_rsrc(a.gatesR), rC = mk_rsrc(a.auxR), rDP = mk_rsrc(a.dPre);
     WaveGemm<J> gm;
     float dhc[J][4], dcc[J][4];
 #pragma unroll
@@ -351,38 +377,38 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(RnnArgs a) {
     for (int t = tb - 1; t >= 0; --t) {
         const int o0 = a.step_off[t], bt = a.step_off[t + 1] - o0;
         const int nact = min(16, bt - r0);
-        const long p0 = (long)o0 + r0;
-        const long pp0 = t > 0 ? (long)a.step_off[t - 1] + r0 : -1;
+        const int soG = (o0 + r0) * GH * 4, soH = (o0 + r0) * H * 4;
+        const int soP = t > 0 ? (a.step_off[t - 1] + r0) * H * 4 : 0;
+        ROW_OFFSETS(voG, GH);
+        ROW_OFFSETS(voH, H);
         gm.preload(pk, lane);
 #pragma unroll
         for (int j = 0; j < J; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 4 * rq + r, col = cbase + 16 * j;
-                float dpi = 0.f, dpf = 0.f, dpc = 0.f, dpo = 0.f;
-                if (row < nact) {
-                    const long q = p0 + row;
-                    const float* gp = a.gatesR + q * GH + col;
-                    const float gi = gp[0], gf = gp[H], gg = gp[2 * H], go = gp[3 * H];
-                    const float cn = a.auxR[q * H + col];
-                    const float cp = pp0 >= 0 ? a.auxR[(pp0 + row) * H + col] : 0.f;
-                    const float dh = dhc[j][r] + a.dHout[q * H + col];
-                    const float ac = act_f(a.act, cn);
-                    const float dct = dcc[j][r] + dh * go * act_g(a.act, ac);
-                    dpi = dct * gg * hard_sigmoid_grad(gi);
-                    dpf = dct * cp * hard_sigmoid_grad(gf);
-                    dpc = dct * gi * act_g(a.act, gg);
-                    dpo = dh * ac * hard_sigmoid_grad(go);
-                    dcc[j][r] = dct * gf;
-                    float* o = a.dPre + q * GH + col;
-                    o[0] = dpi; o[H] = dpf; o[2 * H] = dpc; o[3 * H] = dpo;
-                } else {
-                    dcc[j][r] = 0.f;
-                }
+                const float gi = bload(rG, voG[r] + (0 * H + 16 * j) * 4, soG);
+                const float gf = bload(rG, voG[r] + (1 * H + 16 * j) * 4, soG);
+                const float gg = bload(rG, voG[r] + (2 * H + 16 * j) * 4, soG);
+                const float go = bload(rG, voG[r] + (3 * H + 16 * j) * 4, soG);
+                const float cn = bload(rC, voH[r] + 64 * j, soH);
+                const float cp = bload(rC, t > 0 ? voH[r] + 64 * j : INVALID_OFF, soP);
+                const float dh = dhc[j][r] + bload(rDH, voH[r] + 64 * j, soH);
+                const float ac = act_fwd<ACT>(cn);
+                const float dct = dcc[j][r] + dh * go * act_grad<ACT>(ac);
+                const float dpi = dct * gg * hard_sigmoid_grad(gi);
+                const float dpf = dct * cp * hard_sigmoid_grad(gf);
+                const float dpc = dct * gi * act_grad<ACT>(gg);
+                const float dpo = dh * ac * hard_sigmoid_grad(go);
+                dcc[j][r] = (row < nact) ? dct * gf : 0.f;
+                bstore(rDP, voG[r] + (0 * H + 16 * j) * 4, soG, dpi);
+                bstore(rDP, voG[r] + (1 * H + 16 * j) * 4, soG, dpf);
+                bstore(rDP, voG[r] + (2 * H + 16 * j) * 4, soG, dpc);
+                bstore(rDP, voG[r] + (3 * H + 16 * j) * 4, soG, dpo);
                 float* d = dp + row * LDP + col;
                 d[0] = dpi; d[H] = dpf; d[2 * H] = dpc; d[3 * H] = dpo;
             }
-        __syncthreads();
+        lds_barrier();
         f32x4 acc[J];
         zero_acc(acc);
         gm.run(dp, LDP, pk, KB, lane, acc);
@@ -390,14 +416,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(RnnArgs a) {
         for (int j = 0; j < J; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) dhc[j][r] = acc[j][r];
-        __syncthreads();
+        lds_barrier();
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // GRU (Keras 2.0: z,r,h; h~ = act(x_h + (r*h_prev).U_h); h = z*h_prev + (1-z)*h~)
 // ------------------------------------------------------------------------------------------
-template <int J>
+template <int J, int ACT>
 __global__ __launch_bounds__(256) void gru_fwd_kernel(RnnArgs a) {
     constexpr int H = 64 * J, LDA = H + 2, KB = H / 4, GH = 3 * H;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -408,24 +434,27 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(RnnArgs a) {
     __syncthreads();
     const float* pk_zr = a.pk0 + (size_t)w * H * (32 * J);
     const float* pk_h = a.pk1 + (size_t)w * H * (16 * J);
+    const rsrc_t rXW = mk_rsrc(a.XW), rH = mk_rsrc(a.Hout), rG = mk_rsrc(a.gates), rA = mk_rsrc(a.aux);
     WaveGemm<2 * J> g1;
     WaveGemm<J> g2;
+    // vmcnt retires in issue order and counts stores: a load issued BEHIND a step's stash stores
+    // cannot be waited for before those stores are acknowledged.  So each GEMM's first U fragments
+    // are requested before the preceding epilogue issues its stores.
+    g1.preload(pk_zr, lane);
     for (int t = 0; t < a.T; ++t) {
         const int o0 = a.step_off[t], bt = a.step_off[t + 1] - o0;
         if (bt <= r0) break;
         const int nact = min(16, bt - r0);
-        const long p0 = (long)o0 + r0;
-        g1.preload(pk_zr, lane);
+        const int soG = (o0 + r0) * GH * 4, soH = (o0 + r0) * H * 4;
+        ROW_OFFSETS(voG, GH);
+        ROW_OFFSETS(voH, H);
         float x[3][J][4];
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
             for (int j = 0; j < J; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * rq + r;
-                    x[g][j][r] = row < nact ? a.XW[(p0 + row) * GH + g * H + cbase + 16 * j] : 0.f;
-                }
+                for (int r = 0; r < 4; ++r) x[g][j][r] = bload(rXW, voG[r] + (g * H + 16 * j) * 4, soG);
         f32x4 acc1[2 * J];
         zero_acc(acc1);
         g1.run(hb, LDA, pk_zr, KB, lane, acc1);
@@ -443,37 +472,32 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(RnnArgs a) {
                 zr[j][r] = z;
                 hp[j][r] = h0;
                 rhb[row * LDA + col] = rh;
-                if (row < nact) {
-                    const long q = p0 + row;
-                    a.gates[q * GH + col] = z;
-                    a.gates[q * GH + H + col] = rr;
-                    a.aux[q * H + col] = rh;
-                }
+                bstore(rG, voG[r] + (16 * j) * 4, soG, z);
+                bstore(rG, voG[r] + (H + 16 * j) * 4, soG, rr);
+                bstore(rA, voH[r] + 64 * j, soH, rh);
             }
-        __syncthreads();
+        lds_barrier();
         f32x4 acc2[J];
         zero_acc(acc2);
         g2.run(rhb, LDA, pk_h, KB, lane, acc2);
+        g1.preload(pk_zr, lane);          // next step's first fragments, ahead of this step's stores
 #pragma unroll
         for (int j = 0; j < J; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 4 * rq + r, col = cbase + 16 * j;
-                const float hh = act_f(a.act, acc2[j][r] + x[2][j][r]);
+                const float hh = act_fwd<ACT>(acc2[j][r] + x[2][j][r]);
                 float hn = zr[j][r] * hp[j][r] + (1.f - zr[j][r]) * hh;
                 if (col >= a.H_real) hn = 0.f;
                 hb[row * LDA + col] = hn;
-                if (row < nact) {
-                    const long q = p0 + row;
-                    a.Hout[q * H + col] = hn;
-                    a.gates[q * GH + 2 * H + col] = hh;
-                }
+                bstore(rH, voH[r] + 64 * j, soH, hn);
+                bstore(rG, voG[r] + (2 * H + 16 * j) * 4, soG, hh);
             }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
-template <int J>
+template <int J, int ACT>
 __global__ __launch_bounds__(256) void gru_bwd_kernel(RnnArgs a) {
     constexpr int H = 64 * J, GH = 3 * H, LD1 = H + 2, LD2 = 2 * H + 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -482,6 +506,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(RnnArgs a) {
     float* dpzr = smem + 16 * LD1;     // [16][2H+2]  dpre_z | dpre_r  (A of GEMM 2)
     const float* pk_hT = a.pk0 + (size_t)w * H * (16 * J);
     const float* pk_zrT = a.pk1 + (size_t)w * (2 * H) * (16 * J);
+    const rsrc_t rDH = mk_rsrc(a.dHout), rH = mk_rsrc(a.HoutR), rG = mk_rsrc(a.gatesR), rDP = mk_rsrc(a.dPre);
     WaveGemm<J> g1, g2;
     float dhc[J][4];
 #pragma unroll
@@ -490,39 +515,54 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(RnnArgs a) {
         for (int r = 0; r < 4; ++r) dhc[j][r] = 0.f;
     int tb = 0;
     while (tb < a.T && a.step_off[tb + 1] - a.step_off[tb] > r0) ++tb;
+    // stash values of the step about to be processed (loaded one step ahead, under GEMM 2)
+    float lz[J][4], lr[J][4], lhh[J][4], lh0[J][4], ldh[J][4];
+    auto load_step = [&](int t) {
+        const int o0 = a.step_off[t], bt = a.step_off[t + 1] - o0;
+        const int nact = min(16, bt - r0);
+        const int soG = (o0 + r0) * GH * 4, soH = (o0 + r0) * H * 4;
+        const int soP = t > 0 ? (a.step_off[t - 1] + r0) * H * 4 : 0;
+        ROW_OFFSETS(voG, GH);
+        ROW_OFFSETS(voH, H);
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                lz[j][r] = bload(rG, voG[r] + (16 * j) * 4, soG);
+                lr[j][r] = bload(rG, voG[r] + (H + 16 * j) * 4, soG);
+                lhh[j][r] = bload(rG, voG[r] + (2 * H + 16 * j) * 4, soG);
+                lh0[j][r] = bload(rH, t > 0 ? voH[r] + 64 * j : INVALID_OFF, soP);
+                ldh[j][r] = bload(rDH, voH[r] + 64 * j, soH);
+            }
+    };
+    if (tb > 0) load_step(tb - 1);
+    g1.preload(pk_hT, lane);
     for (int t = tb - 1; t >= 0; --t) {
         const int o0 = a.step_off[t], bt = a.step_off[t + 1] - o0;
         const int nact = min(16, bt - r0);
-        const long p0 = (long)o0 + r0;
-        const long pp0 = t > 0 ? (long)a.step_off[t - 1] + r0 : -1;
-        g1.preload(pk_hT, lane);
+        const int soG = (o0 + r0) * GH * 4;
+        ROW_OFFSETS(voG, GH);
         float zv[J][4], rv[J][4], hpv[J][4], dzv[J][4], dcar[J][4];
 #pragma unroll
         for (int j = 0; j < J; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 4 * rq + r, col = cbase + 16 * j;
-                float z = 0.f, rr = 0.f, h0 = 0.f, dz = 0.f, dc = 0.f, d = 0.f;
-                if (row < nact) {
-                    const long q = p0 + row;
-                    z = a.gatesR[q * GH + col];
-                    rr = a.gatesR[q * GH + H + col];
-                    const float hh = a.gatesR[q * GH + 2 * H + col];
-                    h0 = pp0 >= 0 ? a.HoutR[(pp0 + row) * H + col] : 0.f;
-                    const float dh = dhc[j][r] + a.dHout[q * H + col];
-                    dz = dh * (h0 - hh);
-                    dc = dh * z;
-                    d = dh * (1.f - z) * act_g(a.act, hh);
-                    a.dPre[q * GH + 2 * H + col] = d;
-                }
-                zv[j][r] = z; rv[j][r] = rr; hpv[j][r] = h0; dzv[j][r] = dz; dcar[j][r] = dc;
+                const float z = lz[j][r], rr = lr[j][r], hh = lhh[j][r], h0 = lh0[j][r];
+                const float dh = (row < nact) ? dhc[j][r] + ldh[j][r] : 0.f;
+                const float d = dh * (1.f - z) * act_grad<ACT>(hh);
+                zv[j][r] = z; rv[j][r] = rr; hpv[j][r] = h0;
+                dzv[j][r] = dh * (h0 - hh);
+                dcar[j][r] = dh * z;
+                bstore(rDP, voG[r] + (2 * H + 16 * j) * 4, soG, d);
                 dph[row * LD1 + col] = d;
             }
-        __syncthreads();
+        lds_barrier();
         f32x4 acc1[J];
         zero_acc(acc1);
         g1.run(dph, LD1, pk_hT, H / 4, lane, acc1);
         g2.preload(pk_zrT, lane);
+        if (t > 0) load_step(t - 1);      // next step's stash, in flight under GEMM 2
 #pragma unroll
         for (int j = 0; j < J; ++j)
 #pragma unroll
@@ -535,16 +575,14 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(RnnArgs a) {
                 const float dpr = dr * hard_sigmoid_grad(rv[j][r]);
                 dpzr[row * LD2 + col] = dpz;
                 dpzr[row * LD2 + H + col] = dpr;
-                if (row < nact) {
-                    const long q = p0 + row;
-                    a.dPre[q * GH + col] = dpz;
-                    a.dPre[q * GH + H + col] = dpr;
-                }
+                bstore(rDP, voG[r] + (16 * j) * 4, soG, dpz);
+                bstore(rDP, voG[r] + (H + 16 * j) * 4, soG, dpr);
             }
-        __syncthreads();
+        lds_barrier();
         f32x4 acc2[J];
         zero_acc(acc2);
         g2.run(dpzr, LD2, pk_zrT, (2 * H) / 4, lane, acc2);
+        g1.preload(pk_hT, lane);
 #pragma unroll
         for (int j = 0; j < J; ++j)
 #pragma unroll
@@ -562,25 +600,35 @@ int set_lds(const void* fn, size_t bytes) {
     return 0;
 }
 
-#define DISPATCH_J(KERNEL, LDS_BYTES)                                                                      \
-    do {                                                                                                   \
-        const size_t lds__ = (LDS_BYTES);                                                                  \
-        int rc__ = 0;                                                                                      \
-        switch (J) {                                                                                       \
-            case 1: rc__ = set_lds((const void*)KERNEL<1>, lds__); if (!rc__) hipLaunchKernelGGL(KERNEL<1>, grid, dim3(256), lds__, st, a); break; \
-            case 2: rc__ = set_lds((const void*)KERNEL<2>, lds__); if (!rc__) hipLaunchKernelGGL(KERNEL<2>, grid, dim3(256), lds__, st, a); break; \
-            case 4: rc__ = set_lds((const void*)KERNEL<4>, lds__); if (!rc__) hipLaunchKernelGGL(KERNEL<4>, grid, dim3(256), lds__, st, a); break; \
-            case 8: rc__ = set_lds((const void*)KERNEL<8>, lds__); if (!rc__) hipLaunchKernelGGL(KERNEL<8>, grid, dim3(256), lds__, st, a); break; \
-            default: return SEQREC_E_SHAPE;                                                                \
-        }                                                                                                  \
-        if (rc__) return rc__;                                                                             \
-        SEQREC_LAUNCH_CHECK();                                                                             \
+#define LAUNCH_JA(KERNEL, JJ, AA)                                                              \
+    { rc__ = set_lds((const void*)KERNEL<JJ, AA>, lds__);                                      \
+      if (!rc__) hipLaunchKernelGGL((KERNEL<JJ, AA>), grid, dim3(256), lds__, st, a); }
+#define DISPATCH_A(KERNEL, JJ)                                                                 \
+    switch (act) {                                                                             \
+        case SEQREC_ACT_RELU: LAUNCH_JA(KERNEL, JJ, SEQREC_ACT_RELU) break;                     \
+        case SEQREC_ACT_TANH: LAUNCH_JA(KERNEL, JJ, SEQREC_ACT_TANH) break;                     \
+        default: LAUNCH_JA(KERNEL, JJ, SEQREC_ACT_LINEAR) break;                                \
+    }
+#define DISPATCH_J(KERNEL, LDS_BYTES)                                                          \
+    do {                                                                                       \
+        const size_t lds__ = (LDS_BYTES);                                                      \
+        int rc__ = 0;                                                                          \
+        switch (J) {                                                                           \
+            case 1: DISPATCH_A(KERNEL, 1) break;                                               \
+            case 2: DISPATCH_A(KERNEL, 2) break;                                               \
+            case 4: DISPATCH_A(KERNEL, 4) break;                                               \
+            case 8: DISPATCH_A(KERNEL, 8) break;                                               \
+            default: return SEQREC_E_SHAPE;                                                    \
+        }                                                                                      \
+        if (rc__) return rc__;                                                                 \
+        SEQREC_LAUNCH_CHECK();                                                                 \
     } while (0)
 
 bool check_common(int cell, int act, int H, int H_real, int T, int B) {
     if (cell < 0 || cell > 2 || act < 0 || act > 2) return false;
     if (!(H == 64 || H == 128 || H == 256 || H == 512)) return false;
     if (H_real < 1 || H_real > H || T < 0 || B < 0) return false;
+    if ((long)B * T * 4 * H * 4 >= 0x7FFFFFF0L) return false;      // every activation buffer < 2 GiB (buffer offsets)
     return true;
 }
 

@@ -1,0 +1,316 @@
+// Step-wise form of the GRU scan: one small whole-chip launch per recurrent GEMM instead of one
+// persistent workgroup per 16 sessions (rnn.hip).
+//
+// Why both exist (measured on MI355X, H = 256): the persistent form is bound by the f32 MFMA time of
+// ONE CU per 16 sessions (768 MFMAs/wave/step = 12 us) plus its epilogue traffic (17-21 us/step); the
+// critical path of an MSNBC-shaped batch is its longest session (T ~ 30-46 steps) while only the first
+// row block is still alive.  Cutting a step into launches spreads each recurrent GEMM over
+// (B_t/16) x (N/64) workgroups, so a step costs two dependent launches of ~1 us of MFMA each; the
+// kernel boundary (1.7-2.4 us) is the price, and it also gives the h / r*h exchange between column
+// slices for free (no in-kernel inter-workgroup protocol, no residency assumption).
+//
+// Workgroup = 256 threads: 16 session rows x 64 output columns; wave w owns 16 columns over the whole
+// K; A operand (h_prev / r*h / dpre rows) staged in LDS [16][K+2]; B operand (U slice) streamed
+// straight into registers from a per-(column block, wave) packed layout, all loads issued up front.
+// Exact fp32 (v_mfma_f32_16x16x4_f32).  Needs the step offsets on the HOST to size the launches.
+#include "common.h"
+
+namespace {
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr int INVALID_OFF = 0x7FFFFFF0;
+__device__ __forceinline__ rsrc_t mk_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, INVALID_OFF, 0x00020000);
+}
+__device__ __forceinline__ float bload(rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bstore(rsrc_t r, int voff, int soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
+struct StepArgs {
+    int H, H_real;
+    int p0, pprev0, bt, bnext, first;        // token offset of this step / previous step, rows, rows of step t+1
+    const float* XW; float* Hout; float* gates; float* aux;
+    const float* pk;                          // packed B for this launch
+    const float* dHout; float* dPre; float* dHc; float* tmpc;
+};
+
+// packed[((cb*4 + w)*KB4 + kb4)*64 + lane] (float4): element e <-> kb = 4*kb4 + e,
+//   value = B[4*kb + (lane>>4)][64*cb + 16*w + (lane&15)]
+// mode 0: B[k][n] = U[k*ldu + coff + n]           (forward:  K = H)
+// mode 1: B[k][n] = U[n*ldu + coff + k]           (backward: transposed; K = H or 2H)
+__global__ void pack_step_kernel(const float* __restrict__ U, int ldu, int coff, int K, int N, int mode,
+                                 float* __restrict__ out) {
+    const long total = (long)K * N;
+    const int KB4 = K / 16;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+        long q = o;
+        const int e = (int)(q & 3); q >>= 2;
+        const int l = (int)(q & 63); q >>= 6;
+        const int kb4 = (int)(q % KB4); q /= KB4;
+        const int w = (int)(q & 3); q >>= 2;
+        const int cb = (int)q;
+        const int k = 4 * (4 * kb4 + e) + (l >> 4);
+        const int n = 64 * cb + 16 * w + (l & 15);
+        out[o] = mode == 0 ? U[(long)k * ldu + coff + n] : U[(long)n * ldu + coff + k];
+    }
+}
+
+template <int J, int ACT, int PHASE>
+__global__ __launch_bounds__(256) void gru_step_fwd(StepArgs a) {
+    // PHASE 0: [z|r] = hs(xw + h_prev.U_zr), r*h_prev        grid (rows/16, 2H/64)
+    // PHASE 1: h~ = act(xw_h + (r*h_prev).U_h), h = z h_prev + (1-z) h~   grid (rows/16, H/64)
+    constexpr int H = 64 * J, LDA = H + 2, KB4 = H / 16, GH = 3 * H;
+    __shared__ float hb[16 * LDA];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r0 = blockIdx.x * 16, cb = blockIdx.y;
+    const int nact = min(16, a.bt - r0);
+    const float4* pk = reinterpret_cast<const float4*>(a.pk) + (size_t)(cb * 4 + w) * KB4 * 64 + lane;
+    float4 b[KB4];
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if (!a.first) {
+#pragma unroll
+        for (int i = 0; i < KB4; ++i) b[i] = pk[i * 64];
+        // A rows: PHASE 0 -> h_prev = Hout[prev step], PHASE 1 -> r*h_prev = aux[this step]
+        const float* src = PHASE == 0 ? a.Hout + (long)(a.pprev0 + r0) * H : a.aux + (long)(a.p0 + r0) * H;
+        for (int idx = tid; idx < 16 * (H / 4); idx += 256) {
+            const int row = idx / (H / 4), c4 = idx % (H / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < nact) v = reinterpret_cast<const float4*>(src + (long)row * H)[c4];
+            float* d = hb + row * LDA + 4 * c4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+        const float* ap = hb + (lane & 15) * LDA + (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < KB4; ++i) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 0], b[i].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 4], b[i].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 8], b[i].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 12], b[i].w, acc1, 0, 0, 0);
+        }
+    }
+    const rsrc_t rXW = mk_rsrc(a.XW), rH = mk_rsrc(a.Hout), rG = mk_rsrc(a.gates), rA = mk_rsrc(a.aux);
+    const int col = 64 * cb + 16 * w + (lane & 15);          // column within this phase's output
+    const int soG = (a.p0 + r0) * GH * 4, soH = (a.p0 + r0) * H * 4, soP = (a.pprev0 + r0) * H * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (lane >> 4) + r;
+        const bool ok = row < nact;
+        const float acc = acc0[r] + acc1[r];
+        if (PHASE == 0) {
+            const int vg = ok ? (row * GH + col) * 4 : INVALID_OFF;
+            const float g = hard_sigmoid(acc + bload(rXW, vg, soG));
+            bstore(rG, vg, soG, g);
+            if (col >= H) {                                   // reset gate: also publish r * h_prev
+                const int hc = col - H;
+                const float h0 = a.first ? 0.f : hb[row * LDA + hc];
+                bstore(rA, ok ? (row * H + hc) * 4 : INVALID_OFF, soH, g * h0);
+            }
+        } else {
+            const int vg = ok ? (row * GH + col) * 4 : INVALID_OFF;
+            const int vh = ok ? (row * H + col) * 4 : INVALID_OFF;
+            const float hh = act_fwd<ACT>(acc + bload(rXW, vg + 2 * H * 4, soG));
+            const float z = bload(rG, vg, soG);
+            const float h0 = a.first ? 0.f : bload(rH, vh, soP);
+            float hn = z * h0 + (1.f - z) * hh;
+            if (col >= a.H_real) hn = 0.f;
+            bstore(rH, vh, soH, hn);
+            bstore(rG, vg + 2 * H * 4, soG, hh);
+        }
+    }
+}
+
+template <int J, int ACT, int PHASE>
+__global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a) {
+    // PHASE 0 (grid rows/16 x H/64): d = dh (1-z) act'(h~) for the whole row -> LDS; drh = d . U_h^T (own cols);
+    //          dpre_z, dpre_r, dpre_h -> dPre;  dcar = dh z + drh r -> tmpc
+    // PHASE 1 (grid rows/16 x H/64, skipped at t = 0): dh_prev = tmpc + [dpre_z|dpre_r] . U_zr^T -> dHc[prev token]
+    constexpr int H = 64 * J, GH = 3 * H;
+    constexpr int K = PHASE == 0 ? H : 2 * H, LDA = K + 2, KB4 = K / 16;
+    __shared__ float ab[16 * LDA];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r0 = blockIdx.x * 16, cb = blockIdx.y;
+    const int nact = min(16, a.bt - r0);
+    const float4* pk = reinterpret_cast<const float4*>(a.pk) + (size_t)(cb * 4 + w) * KB4 * 64 + lane;
+    float4 b[KB4];
+#pragma unroll
+    for (int i = 0; i < KB4; ++i) b[i] = pk[i * 64];
+    const long pt = (long)a.p0 + r0;
+    if (PHASE == 0) {
+        for (int idx = tid; idx < 16 * (H / 4); idx += 256) {
+            const int row = idx / (H / 4), c4 = idx % (H / 4);
+            float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < nact) {
+                const long q = pt + row;
+                float4 dh = reinterpret_cast<const float4*>(a.dHout + q * H)[c4];
+                if (r0 + row < a.bnext) {
+                    const float4 c = reinterpret_cast<const float4*>(a.dHc + q * H)[c4];
+                    dh.x += c.x; dh.y += c.y; dh.z += c.z; dh.w += c.w;
+                }
+                const float4 z = reinterpret_cast<const float4*>(a.gates + q * GH)[c4];
+                const float4 hh = reinterpret_cast<const float4*>(a.gates + q * GH + 2 * H)[c4];
+                d.x = dh.x * (1.f - z.x) * act_grad<ACT>(hh.x);
+                d.y = dh.y * (1.f - z.y) * act_grad<ACT>(hh.y);
+                d.z = dh.z * (1.f - z.z) * act_grad<ACT>(hh.z);
+                d.w = dh.w * (1.f - z.w) * act_grad<ACT>(hh.w);
+                if (cb == 0) reinterpret_cast<float4*>(a.dPre + q * GH + 2 * H)[c4] = d;
+            }
+            float* o = ab + row * LDA + 4 * c4;
+            o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = d.w;
+        }
+    } else {
+        for (int idx = tid; idx < 16 * (K / 4); idx += 256) {
+            const int row = idx / (K / 4), c4 = idx % (K / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < nact) v = reinterpret_cast<const float4*>(a.dPre + (pt + row) * GH)[c4];
+            float* o = ab + row * LDA + 4 * c4;
+            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        }
+    }
+    __syncthreads();
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const float* ap = ab + (lane & 15) * LDA + (lane >> 4);
+#pragma unroll
+    for (int i = 0; i < KB4; ++i) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 0], b[i].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 4], b[i].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 8], b[i].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 12], b[i].w, acc1, 0, 0, 0);
+    }
+    const int col = 64 * cb + 16 * w + (lane & 15);
+    const rsrc_t rDH = mk_rsrc(a.dHout), rH = mk_rsrc(a.Hout), rG = mk_rsrc(a.gates), rDP = mk_rsrc(a.dPre),
+                 rC = mk_rsrc(a.dHc), rT = mk_rsrc(a.tmpc);
+    const int soG = (a.p0 + r0) * GH * 4, soH = (a.p0 + r0) * H * 4, soP = (a.pprev0 + r0) * H * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (lane >> 4) + r;
+        const bool ok = row < nact;
+        const float acc = acc0[r] + acc1[r];
+        const int vg = ok ? (row * GH + col) * 4 : INVALID_OFF;
+        const int vh = ok ? (row * H + col) * 4 : INVALID_OFF;
+        if (PHASE == 0) {
+            float dh = bload(rDH, vh, soH);
+            dh += bload(rC, (ok && r0 + row < a.bnext) ? vh : INVALID_OFF, soH);
+            const float z = bload(rG, vg, soG), rr = bload(rG, vg + H * 4, soG), hh = bload(rG, vg + 2 * H * 4, soG);
+            const float h0 = bload(rH, a.first ? INVALID_OFF : vh, soP);
+            const float drh = acc;
+            bstore(rDP, vg, soG, dh * (h0 - hh) * hard_sigmoid_grad(z));
+            bstore(rDP, vg + H * 4, soG, drh * h0 * hard_sigmoid_grad(rr));
+            bstore(rT, vh, soH, dh * z + drh * rr);
+        } else {
+            bstore(rC, vh, soP, bload(rT, vh, soH) + acc);
+        }
+    }
+}
+
+template <typename KF> int launch_step(KF kern, dim3 grid, const StepArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, a);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+
+#define STEP_DISPATCH(KERN, PHASE, GRID)                                                        \
+    do {                                                                                        \
+        int rc__ = SEQREC_E_SHAPE;                                                              \
+        switch (J * 4 + act) {                                                                  \
+            case 4 * 1 + 0: rc__ = launch_step(KERN<1, 0, PHASE>, GRID, a, st); break;          \
+            case 4 * 1 + 1: rc__ = launch_step(KERN<1, 1, PHASE>, GRID, a, st); break;          \
+            case 4 * 1 + 2: rc__ = launch_step(KERN<1, 2, PHASE>, GRID, a, st); break;          \
+            case 4 * 2 + 0: rc__ = launch_step(KERN<2, 0, PHASE>, GRID, a, st); break;          \
+            case 4 * 2 + 1: rc__ = launch_step(KERN<2, 1, PHASE>, GRID, a, st); break;          \
+            case 4 * 2 + 2: rc__ = launch_step(KERN<2, 2, PHASE>, GRID, a, st); break;          \
+            case 4 * 4 + 0: rc__ = launch_step(KERN<4, 0, PHASE>, GRID, a, st); break;          \
+            case 4 * 4 + 1: rc__ = launch_step(KERN<4, 1, PHASE>, GRID, a, st); break;          \
+            case 4 * 4 + 2: rc__ = launch_step(KERN<4, 2, PHASE>, GRID, a, st); break;          \
+            case 4 * 8 + 0: rc__ = launch_step(KERN<8, 0, PHASE>, GRID, a, st); break;          \
+            case 4 * 8 + 1: rc__ = launch_step(KERN<8, 1, PHASE>, GRID, a, st); break;          \
+            case 4 * 8 + 2: rc__ = launch_step(KERN<8, 2, PHASE>, GRID, a, st); break;          \
+        }                                                                                       \
+        if (rc__) return rc__;                                                                  \
+    } while (0)
+
+bool ok_shape(int cell, int act, int H, int H_real, int T, int B) {
+    if (cell != SEQREC_CELL_GRU || act < 0 || act > 2) return false;
+    if (!(H == 64 || H == 128 || H == 256 || H == 512)) return false;
+    if (H_real < 1 || H_real > H || T < 0 || B < 0) return false;
+    if ((long)B * T * 3 * H * 4 >= 0x7FFFFFF0L) return false;
+    return true;
+}
+
+}  // namespace
+
+// layouts, in this order inside upack: fwd [z|r] (H x 2H), fwd h (H x H), bwd U_h^T (H x H), bwd [U_z U_r]^T (2H x H)
+extern "C" int seqrec_rnn_pack_u_stepwise(int cell, int H, const float* U, float* upack, void* stream) {
+    if (cell != SEQREC_CELL_GRU) return SEQREC_E_UNSUPPORTED;
+    if (!(H == 64 || H == 128 || H == 256 || H == 512)) return SEQREC_E_SHAPE;
+    if (!U || !upack) return SEQREC_E_ARG;
+    hipStream_t st = as_stream(stream);
+    const long HH = (long)H * H;
+    hipLaunchKernelGGL(pack_step_kernel, dim3(256), dim3(256), 0, st, U, 3 * H, 0, H, 2 * H, 0, upack);
+    hipLaunchKernelGGL(pack_step_kernel, dim3(256), dim3(256), 0, st, U, 3 * H, 2 * H, H, H, 0, upack + 2 * HH);
+    hipLaunchKernelGGL(pack_step_kernel, dim3(256), dim3(256), 0, st, U, 3 * H, 2 * H, H, H, 1, upack + 3 * HH);
+    hipLaunchKernelGGL(pack_step_kernel, dim3(256), dim3(256), 0, st, U, 3 * H, 0, 2 * H, H, 1, upack + 4 * HH);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int seqrec_rnn_fwd_stepwise(int cell, int act, int H, int H_real, int T, int B,
+                                       const int32_t* step_off_host, const float* XW, float* Hout,
+                                       float* gates, float* aux, const float* upack, void* stream) {
+    if (!ok_shape(cell, act, H, H_real, T, B)) return cell == SEQREC_CELL_GRU ? SEQREC_E_SHAPE : SEQREC_E_UNSUPPORTED;
+    if (T == 0 || B == 0) return 0;
+    if (!step_off_host || !XW || !Hout || !gates || !aux || !upack) return SEQREC_E_ARG;
+    hipStream_t st = as_stream(stream);
+    const int J = H / 64;
+    const long HH = (long)H * H;
+    StepArgs a = {};
+    a.H = H; a.H_real = H_real; a.XW = XW; a.Hout = Hout; a.gates = gates; a.aux = aux;
+    for (int t = 0; t < T; ++t) {
+        a.p0 = step_off_host[t]; a.bt = step_off_host[t + 1] - a.p0;
+        a.pprev0 = t > 0 ? step_off_host[t - 1] : 0;
+        a.first = t == 0;
+        if (a.bt <= 0) break;
+        const unsigned rb = (unsigned)((a.bt + 15) / 16);
+        a.pk = upack;
+        STEP_DISPATCH(gru_step_fwd, 0, dim3(rb, 2 * H / 64));
+        a.pk = upack + 2 * HH;
+        STEP_DISPATCH(gru_step_fwd, 1, dim3(rb, H / 64));
+    }
+    return 0;
+}
+
+// workspace: 2 * N_tok * H floats (carried dh per token, dcar per token)
+extern "C" int seqrec_rnn_bwd_stepwise(int cell, int act, int H, int H_real, int T, int B,
+                                       const int32_t* step_off_host, const float* dHout, const float* Hout,
+                                       const float* gates, const float* aux, float* dPre, const float* upack,
+                                       float* workspace, void* stream) {
+    if (!ok_shape(cell, act, H, H_real, T, B)) return cell == SEQREC_CELL_GRU ? SEQREC_E_SHAPE : SEQREC_E_UNSUPPORTED;
+    if (T == 0 || B == 0) return 0;
+    if (!step_off_host || !dHout || !Hout || !gates || !dPre || !upack || !workspace) return SEQREC_E_ARG;
+    hipStream_t st = as_stream(stream);
+    const int J = H / 64;
+    const long HH = (long)H * H;
+    const long ntok = step_off_host[T];
+    StepArgs a = {};
+    a.H = H; a.H_real = H_real; a.Hout = const_cast<float*>(Hout); a.gates = const_cast<float*>(gates);
+    a.aux = const_cast<float*>(aux); a.dHout = dHout; a.dPre = dPre;
+    a.dHc = workspace; a.tmpc = workspace + ntok * H;
+    for (int t = T - 1; t >= 0; --t) {
+        a.p0 = step_off_host[t]; a.bt = step_off_host[t + 1] - a.p0;
+        if (a.bt <= 0) continue;
+        a.bnext = t + 1 < T ? step_off_host[t + 2] - step_off_host[t + 1] : 0;
+        a.pprev0 = t > 0 ? step_off_host[t - 1] : 0;
+        a.first = t == 0;
+        const unsigned rb = (unsigned)((a.bt + 15) / 16);
+        a.pk = upack + 3 * HH;
+        STEP_DISPATCH(gru_step_bwd, 0, dim3(rb, H / 64));
+        if (t > 0) {
+            a.pk = upack + 4 * HH;
+            STEP_DISPATCH(gru_step_bwd, 1, dim3(rb, H / 64));
+        }
+    }
+    return 0;
+}

@@ -175,11 +175,7 @@ class ShardedEngine(Engine):
         XW = self.buf("XW", n, GHp)
         self.gemm(1, 0, n, GHp, Dp, X, Dp, P["W"], GHp, XW, GHp, bias=P.get("b"), tag="xw")
         Hout = self.buf("Hout", n, Hp); gates = self.buf("gates", n, GHp); aux = self.buf("aux", n, Hp)
-        if self.upack_dirty:
-            call("seqrec_rnn_pack_u", CELL[c.cell], Hp, ptr(P["U"]), ptr(self.upack), st)
-            self.upack_dirty = False
-        call("seqrec_rnn_fwd", CELL[c.cell], ACT[c.act], Hp, c.H, T, B, ptr(d["step_off"]), ptr(XW), ptr(Hout), ptr(gates),
-             ptr(aux), ptr(self.upack), st)
+        self._scan_fwd(d, XW, Hout, gates, aux)
         Hd = Hout
         ln = self.buf("ln", n, K)
         self.gemm(1, 1, n, K, Hp, Hd, Hp, Eneg, Hp, ln, K, tag="logits")
@@ -205,8 +201,7 @@ class ShardedEngine(Engine):
         call("seqrec_fill_f32", ptr(dEtgt), 0.0, n * Hp, st)
         call("seqrec_gather_rows", ptr(Hd), ptr(ar), ptr(dEtgt), n, Hp, ptr(dlt), None, 0, st)
         dPre = self.buf("dPre", n, GHp)
-        call("seqrec_rnn_bwd", CELL[c.cell], ACT[c.act], Hp, c.H, T, B, ptr(d["step_off"]), ptr(dHd), ptr(Hout), ptr(gates),
-             ptr(aux), ptr(dPre), ptr(self.upack), st)
+        self._scan_bwd(d, dHd, Hout, gates, aux, dPre)
         Gd, Gt = self.Gd, self.Gt
         cs_ws = self.buf("colsum_ws", 64 * GHp)
         call("seqrec_colsum", ptr(dPre), n, GHp, GHp, ptr(Gd["b"]), 0, ptr(cs_ws), st)

@@ -95,6 +95,7 @@ class NetConfig:
     drop_out: float = 0.0         # z_to_y_dropout
     logq: bool = False            # subtract log Q(item) from sampled logits
     seed: int = 0                 # counter-RNG seed (negatives, dropout)
+    scan: str = "auto"            # 'persistent' (rnn.hip) | 'stepwise' (rnn_step.hip, GRU) | 'auto'
 
     @property
     def G(self):
@@ -167,6 +168,9 @@ class Engine:
         self.loss_sum = z(1)
         self.upack = torch.empty(int(_lib.load().seqrec_rnn_upack_floats(CELL[c.cell], self.Hp)), **f32)
         self.upack_dirty = True
+        self.stepwise = (c.scan == "stepwise") or (c.scan == "auto" and c.cell == "gru" and self.Hp <= 256)
+        if self.stepwise and c.cell != "gru":
+            raise ValueError("scan='stepwise' exists for the GRU only")
         self.sampler = None       # (thresh uint32-as-int32 tensor, alias int32 tensor, logq float tensor)
         self.step_count = 0
 
@@ -331,6 +335,34 @@ class Engine:
             out["_rk_out"] = rk
         return out
 
+    # ------------------------------------------------------------------ recurrent scan
+    def _scan_fwd(self, d, XW, Hout, gates, aux):
+        c, st = self.cfg, self._stream()
+        Hp = self.Hp
+        if self.upack_dirty:
+            call("seqrec_rnn_pack_u_stepwise" if self.stepwise else "seqrec_rnn_pack_u", CELL[c.cell], Hp, ptr(self.P["U"]),
+                 ptr(self.upack), st)
+            self.upack_dirty = False
+        if self.stepwise:
+            so = d["rb"].step_off
+            call("seqrec_rnn_fwd_stepwise", CELL[c.cell], ACT[c.act], Hp, c.H, d["T"], d["B"], so.ctypes.data, ptr(XW), ptr(Hout),
+                 ptr(gates), ptr(aux), ptr(self.upack), st)
+        else:
+            call("seqrec_rnn_fwd", CELL[c.cell], ACT[c.act], Hp, c.H, d["T"], d["B"], ptr(d["step_off"]), ptr(XW),
+                 ptr(Hout), ptr(gates), ptr(aux), ptr(self.upack), st)
+
+    def _scan_bwd(self, d, dHout, Hout, gates, aux, dPre):
+        c, st = self.cfg, self._stream()
+        Hp = self.Hp
+        if self.stepwise:
+            so = d["rb"].step_off
+            wsp = self.buf("scan_ws", 2 * d["n"] * Hp)
+            call("seqrec_rnn_bwd_stepwise", CELL[c.cell], ACT[c.act], Hp, c.H, d["T"], d["B"], so.ctypes.data, ptr(dHout),
+                 ptr(Hout), ptr(gates), ptr(aux), ptr(dPre), ptr(self.upack), ptr(wsp), st)
+        else:
+            call("seqrec_rnn_bwd", CELL[c.cell], ACT[c.act], Hp, c.H, d["T"], d["B"], ptr(d["step_off"]), ptr(dHout), ptr(Hout),
+                 ptr(gates), ptr(aux), ptr(dPre), ptr(self.upack), st)
+
     # ------------------------------------------------------------------ forward
     def forward(self, d, train=False, step=0, want_probs=False, negatives=None, stop_at_hidden=False):
         """Runs the graph up to the loss.  Returns a dict of device tensors; in training
@@ -366,11 +398,7 @@ class Engine:
         Hout = self.buf("Hout", n, Hp)
         gates = self.buf("gates", n, GHp)
         aux = self.buf("aux", n, Hp)
-        if self.upack_dirty:
-            call("seqrec_rnn_pack_u", CELL[c.cell], Hp, ptr(P["U"]), ptr(self.upack), st)
-            self.upack_dirty = False
-        call("seqrec_rnn_fwd", CELL[c.cell], ACT[c.act], Hp, c.H, T, B, ptr(d["step_off"]), ptr(XW),
-             ptr(Hout), ptr(gates), ptr(aux), ptr(self.upack), st)
+        self._scan_fwd(d, XW, Hout, gates, aux)
         r.update(XW=XW, Hout=Hout, gates=gates, aux=aux)
         Hd = Hout
         if "out" in drops:
@@ -470,8 +498,7 @@ class Engine:
         if "out" in drops:
             call("seqrec_mul", ptr(dHd), ptr(drops["out"]), ptr(dHd), n * Hp, st)
         dPre = self.buf("dPre", n, GHp)
-        call("seqrec_rnn_bwd", CELL[c.cell], ACT[c.act], Hp, c.H, T, B, ptr(d["step_off"]), ptr(dHout), ptr(r["Hout"]),
-             ptr(r["gates"]), ptr(r["aux"]), ptr(dPre), ptr(self.upack), st)
+        self._scan_bwd(d, dHout, r["Hout"], r["gates"], r["aux"], dPre)
         if c.use_bias and tr["b"]:
             call("seqrec_colsum", ptr(dPre), n, GHp, GHp, ptr(Gd["b"]), 0, ptr(cs_ws), st)
         if tr["U"]:

@@ -363,3 +363,47 @@ def test_rank_count_vs_numpy():
     ref = (sc > ts[:, None]).sum(1)
     got = rank.cpu().numpy()
     assert np.abs(got - ref).max() <= 2 and (got == ref).mean() > 0.97     # fp32 near-ties only
+
+
+@pytest.mark.parametrize("H,B,maxlen,act", [(64, 5, 6, "relu"), (64, 37, 12, "tanh"), (128, 100, 9, "relu"),
+                                            (256, 70, 20, "relu"), (256, 512, 49, "tanh"), (128, 40, 10, "linear"),
+                                            (512, 33, 7, "relu")])
+def test_gru_stepwise_scan_vs_oracle_and_persistent(H, B, maxlen, act):
+    """The launch-per-step GRU scan (rnn_step.hip) against the oracle, and bit-for-bit-close to the
+    persistent scan (same fp32 MFMA chains, only the accumulator pairing differs)."""
+    cell = "gru"
+    rng = np.random.default_rng(H * 3 + B + maxlen)
+    rb, XW, U = packed_scan_inputs(rng, cell, H, B, maxlen)
+    n, G = rb.n_tok, 3
+    dH = (rng.normal(size=(n, H)) * 0.5).astype(np.float32)
+    ref = oracle_scan(cell, act, rb, XW, U, dH)
+    Hout = torch.full((n, H), float("nan"), device="cuda"); gates = torch.full((n, G * H), float("nan"), device="cuda")
+    aux = torch.full((n, H), float("nan"), device="cuda")
+    up = torch.empty(int(L.load().seqrec_rnn_upack_floats(2, H)), device="cuda")
+    XWd, Ud = dev(XW), dev(U)
+    call("seqrec_rnn_pack_u_stepwise", 2, H, ptr(Ud), ptr(up), st())
+    so = rb.step_off
+    call("seqrec_rnn_fwd_stepwise", 2, L.ACT[act], H, H, rb.T, rb.B, so.ctypes.data, ptr(XWd), ptr(Hout), ptr(gates), ptr(aux),
+         ptr(up), st())
+    got = Hout.cpu().numpy()
+    scale = max(1.0, np.abs(ref["H"]).max())
+    assert np.abs(got - ref["H"]).max() <= 3e-5 * scale
+    dPre = torch.full((n, G * H), float("nan"), device="cuda")
+    ws = torch.full((2 * n * H,), float("nan"), device="cuda")
+    call("seqrec_rnn_bwd_stepwise", 2, L.ACT[act], H, H, rb.T, rb.B, so.ctypes.data, ptr(dev(dH)), ptr(Hout), ptr(gates), ptr(aux),
+         ptr(dPre), ptr(up), ptr(ws), st())
+    gp = dPre.cpu().numpy()
+    s2 = max(1.0, np.abs(ref["dPre"]).max())
+    bad = np.abs(gp - ref["dPre"]) > 1e-4 * s2
+    assert np.isfinite(gp).all() and bad.mean() < 2e-4, (bad.mean(), np.abs(gp - ref["dPre"]).max())
+    # persistent scan on the same inputs
+    H2 = torch.empty((n, H), device="cuda"); g2 = torch.empty((n, G * H), device="cuda"); a2 = torch.empty((n, H), device="cuda")
+    call("seqrec_rnn_pack_u", 2, H, ptr(Ud), ptr(up), st())
+    call("seqrec_rnn_fwd", 2, L.ACT[act], H, H, rb.T, rb.B, ptr(dev(rb.step_off)), ptr(XWd), ptr(H2), ptr(g2), ptr(a2), ptr(up), st())
+    assert np.abs(H2.cpu().numpy() - got).max() <= 2e-5 * scale
+    assert lib_rc("seqrec_rnn_fwd_stepwise", 1) == -3
+
+
+def lib_rc(name, cell):
+    lib = L.load()
+    return getattr(lib, name)(cell, 0, 64, 64, 1, 1, None, None, None, None, None, None, None)
