@@ -88,6 +88,9 @@ def kernel_model(cfgd, n_tok, K, B):
     m = {
         "seqrec_rnn_fwd": ("mfma", 2.0 * G * H * H * n_tok),
         "seqrec_rnn_bwd": ("mfma", 2.0 * G * H * H * n_tok),
+        # step-wise scan: one C-ABI call = 2 launches per time step; work and time are per CALL
+        "seqrec_rnn_fwd_stepwise": ("mfma", 2.0 * G * H * H * n_tok),
+        "seqrec_rnn_bwd_stepwise": ("mfma", 2.0 * G * H * H * n_tok),
         "seqrec_gemm_f32[xw]": ("mfma", 2.0 * n_tok * D * G * H),
         "seqrec_gemm_f32[logits]": ("mfma", 2.0 * n_tok * K * H),
         "seqrec_gemm_f32[dH]": ("mfma", 2.0 * n_tok * K * H),

@@ -9,9 +9,9 @@
 // kernel boundary (1.7-2.4 us) is the price, and it also gives the h / r*h exchange between column
 // slices for free (no in-kernel inter-workgroup protocol, no residency assumption).
 //
-// Workgroup = 256 threads: 16 session rows x 64 output columns; wave w owns 16 columns over the whole
-// K; A operand (h_prev / r*h / dpre rows) staged in LDS [16][K+2]; B operand (U slice) streamed
-// straight into registers from a per-(column block, wave) packed layout, all loads issued up front.
+// Workgroup = 256 threads: 16 session rows x 16 output columns with K split over the 4 waves;
+// A operand (h_prev / r*h / dpre rows) staged in LDS [16][K+2]; B operand (U slice) loaded straight
+// into registers from a per-(column block, wave) packed layout, all loads issued up front.
 // Exact fp32 (v_mfma_f32_16x16x4_f32).  Needs the step offsets on the HOST to size the launches.
 #include "common.h"
 
@@ -37,116 +37,159 @@ struct StepArgs {
     const float* dHout; float* dPre; float* dHc; float* tmpc;
 };
 
-// packed[((cb*4 + w)*KB4 + kb4)*64 + lane] (float4): element e <-> kb = 4*kb4 + e,
-//   value = B[4*kb + (lane>>4)][64*cb + 16*w + (lane&15)]
+// Workgroup = 16 session rows x 16 output columns; the 4 waves split K (wave w owns k-blocks
+// [w*K/16, (w+1)*K/16)), partial 16x16 tiles are summed through LDS and every thread finishes ONE
+// output element (row = tid>>4, col = tid&15), whose epilogue inputs were requested at kernel entry.
+// Per launch the dependent chain is: loads (one L2 round trip) -> 16..32 MFMAs -> LDS reduce -> store.
+//
+// packed[((cb*4 + w)*(K/64) + i)*64 + lane] (float4): element e <-> kb = w*(K/16) + 4*i + e,
+//   value = B[4*kb + (lane>>4)][16*cb + (lane&15)]
 // mode 0: B[k][n] = U[k*ldu + coff + n]           (forward:  K = H)
 // mode 1: B[k][n] = U[n*ldu + coff + k]           (backward: transposed; K = H or 2H)
 __global__ void pack_step_kernel(const float* __restrict__ U, int ldu, int coff, int K, int N, int mode,
                                  float* __restrict__ out) {
     const long total = (long)K * N;
-    const int KB4 = K / 16;
+    const int G4 = K / 64;                 // float4 groups per wave
     for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
         long q = o;
         const int e = (int)(q & 3); q >>= 2;
         const int l = (int)(q & 63); q >>= 6;
-        const int kb4 = (int)(q % KB4); q /= KB4;
+        const int i = (int)(q % G4); q /= G4;
         const int w = (int)(q & 3); q >>= 2;
         const int cb = (int)q;
-        const int k = 4 * (4 * kb4 + e) + (l >> 4);
-        const int n = 64 * cb + 16 * w + (l & 15);
+        const int kb = w * (K / 16) + 4 * i + e;
+        const int k = 4 * kb + (l >> 4);
+        const int n = 16 * cb + (l & 15);
         out[o] = mode == 0 ? U[(long)k * ldu + coff + n] : U[(long)n * ldu + coff + k];
     }
 }
 
+// split-K tile product; returns this thread's element C[tid>>4][tid&15].  `ab` must be filled and
+// fenced by the caller's barrier; `red` is [4][256] floats.
+template <int K>
+__device__ __forceinline__ float tile_16x16(const float* __restrict__ ab, float* __restrict__ red, const float4 (&b)[K / 64],
+                                            int tid) {
+    constexpr int LDA = K + 2, G4 = K / 64;
+    const int lane = tid & 63, w = tid >> 6;
+    const float* ap = ab + (lane & 15) * LDA + (lane >> 4) + w * (K / 4);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < G4; ++i) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 0], b[i].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 4], b[i].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 8], b[i].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 12], b[i].w, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[w * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc0[r] + acc1[r];
+    __syncthreads();
+    return (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+}
+
 template <int J, int ACT, int PHASE>
 __global__ __launch_bounds__(256) void gru_step_fwd(StepArgs a) {
-    // PHASE 0: [z|r] = hs(xw + h_prev.U_zr), r*h_prev        grid (rows/16, 2H/64)
-    // PHASE 1: h~ = act(xw_h + (r*h_prev).U_h), h = z h_prev + (1-z) h~   grid (rows/16, H/64)
-    constexpr int H = 64 * J, LDA = H + 2, KB4 = H / 16, GH = 3 * H;
-    __shared__ float hb[16 * LDA];
+    // PHASE 0: [z|r] = hs(xw + h_prev.U_zr), r*h_prev        grid (rows/16, 2H/16)
+    // PHASE 1: h~ = act(xw_h + (r*h_prev).U_h), h = z h_prev + (1-z) h~   grid (rows/16, H/16)
+    constexpr int H = 64 * J, LDA = H + 2, GH = 3 * H;
+    __shared__ float ab[16 * LDA];
+    __shared__ float red[4 * 256];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r0 = blockIdx.x * 16, cb = blockIdx.y;
     const int nact = min(16, a.bt - r0);
-    const float4* pk = reinterpret_cast<const float4*>(a.pk) + (size_t)(cb * 4 + w) * KB4 * 64 + lane;
-    float4 b[KB4];
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const int row = tid >> 4, col = 16 * cb + (tid & 15);     // this thread's output element
+    const bool ok = row < nact;
+    const rsrc_t rXW = mk_rsrc(a.XW), rH = mk_rsrc(a.Hout), rG = mk_rsrc(a.gates), rA = mk_rsrc(a.aux);
+    const int soG = (a.p0 + r0) * GH * 4, soH = (a.p0 + r0) * H * 4, soP = (a.pprev0 + r0) * H * 4;
+    const int vg = ok ? (row * GH + col) * 4 : INVALID_OFF;
+    const int vh = ok ? (row * H + col) * 4 : INVALID_OFF;
+    // epilogue operands first: their latency hides under the tile product
+    const float xw = bload(rXW, PHASE == 0 ? vg : vg + 2 * H * 4, soG);
+    float zg = 0.f, h0 = 0.f;
+    if (PHASE == 1) {
+        zg = bload(rG, vg, soG);
+        h0 = bload(rH, a.first ? INVALID_OFF : vh, soP);
+    }
+    float acc = 0.f;
     if (!a.first) {
+        float4 b[H / 64];
+        const float4* pk = reinterpret_cast<const float4*>(a.pk) + (size_t)(cb * 4 + w) * (H / 64) * 64 + lane;
 #pragma unroll
-        for (int i = 0; i < KB4; ++i) b[i] = pk[i * 64];
+        for (int i = 0; i < H / 64; ++i) b[i] = pk[i * 64];
         // A rows: PHASE 0 -> h_prev = Hout[prev step], PHASE 1 -> r*h_prev = aux[this step]
         const float* src = PHASE == 0 ? a.Hout + (long)(a.pprev0 + r0) * H : a.aux + (long)(a.p0 + r0) * H;
-        for (int idx = tid; idx < 16 * (H / 4); idx += 256) {
-            const int row = idx / (H / 4), c4 = idx % (H / 4);
+#pragma unroll
+        for (int it = 0; it < (16 * (H / 4)) / 256; ++it) {
+            const int idx = tid + 256 * it;
+            const int rr = idx / (H / 4), c4 = idx % (H / 4);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < nact) v = reinterpret_cast<const float4*>(src + (long)row * H)[c4];
-            float* d = hb + row * LDA + 4 * c4;
+            if (rr < nact) v = reinterpret_cast<const float4*>(src + (long)rr * H)[c4];
+            float* d = ab + rr * LDA + 4 * c4;
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
         __syncthreads();
-        const float* ap = hb + (lane & 15) * LDA + (lane >> 4);
-#pragma unroll
-        for (int i = 0; i < KB4; ++i) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 0], b[i].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 4], b[i].y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 8], b[i].z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 12], b[i].w, acc1, 0, 0, 0);
-        }
+        acc = tile_16x16<H>(ab, red, b, tid);
     }
-    const rsrc_t rXW = mk_rsrc(a.XW), rH = mk_rsrc(a.Hout), rG = mk_rsrc(a.gates), rA = mk_rsrc(a.aux);
-    const int col = 64 * cb + 16 * w + (lane & 15);          // column within this phase's output
-    const int soG = (a.p0 + r0) * GH * 4, soH = (a.p0 + r0) * H * 4, soP = (a.pprev0 + r0) * H * 4;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = 4 * (lane >> 4) + r;
-        const bool ok = row < nact;
-        const float acc = acc0[r] + acc1[r];
-        if (PHASE == 0) {
-            const int vg = ok ? (row * GH + col) * 4 : INVALID_OFF;
-            const float g = hard_sigmoid(acc + bload(rXW, vg, soG));
-            bstore(rG, vg, soG, g);
-            if (col >= H) {                                   // reset gate: also publish r * h_prev
-                const int hc = col - H;
-                const float h0 = a.first ? 0.f : hb[row * LDA + hc];
-                bstore(rA, ok ? (row * H + hc) * 4 : INVALID_OFF, soH, g * h0);
-            }
-        } else {
-            const int vg = ok ? (row * GH + col) * 4 : INVALID_OFF;
-            const int vh = ok ? (row * H + col) * 4 : INVALID_OFF;
-            const float hh = act_fwd<ACT>(acc + bload(rXW, vg + 2 * H * 4, soG));
-            const float z = bload(rG, vg, soG);
-            const float h0 = a.first ? 0.f : bload(rH, vh, soP);
-            float hn = z * h0 + (1.f - z) * hh;
-            if (col >= a.H_real) hn = 0.f;
-            bstore(rH, vh, soH, hn);
-            bstore(rG, vg + 2 * H * 4, soG, hh);
+    if (PHASE == 0) {
+        const float g = hard_sigmoid(acc + xw);
+        bstore(rG, vg, soG, g);
+        if (col >= H) {                                       // reset gate: also publish r * h_prev
+            const int hc = col - H;
+            const float hp = a.first ? 0.f : ab[row * LDA + hc];
+            bstore(rA, ok ? (row * H + hc) * 4 : INVALID_OFF, soH, g * hp);
         }
+    } else {
+        const float hh = act_fwd<ACT>(acc + xw);
+        float hn = zg * h0 + (1.f - zg) * hh;
+        if (col >= a.H_real) hn = 0.f;
+        bstore(rH, vh, soH, hn);
+        bstore(rG, vg + 2 * H * 4, soG, hh);
     }
 }
 
 template <int J, int ACT, int PHASE>
 __global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a) {
-    // PHASE 0 (grid rows/16 x H/64): d = dh (1-z) act'(h~) for the whole row -> LDS; drh = d . U_h^T (own cols);
+    // PHASE 0 (grid rows/16 x H/16): d = dh (1-z) act'(h~) for the whole row -> LDS; drh = d . U_h^T (own cols);
     //          dpre_z, dpre_r, dpre_h -> dPre;  dcar = dh z + drh r -> tmpc
-    // PHASE 1 (grid rows/16 x H/64, skipped at t = 0): dh_prev = tmpc + [dpre_z|dpre_r] . U_zr^T -> dHc[prev token]
+    // PHASE 1 (grid rows/16 x H/16, skipped at t = 0): dh_prev = tmpc + [dpre_z|dpre_r] . U_zr^T -> dHc[prev token]
     constexpr int H = 64 * J, GH = 3 * H;
-    constexpr int K = PHASE == 0 ? H : 2 * H, LDA = K + 2, KB4 = K / 16;
+    constexpr int K = PHASE == 0 ? H : 2 * H, LDA = K + 2;
     __shared__ float ab[16 * LDA];
+    __shared__ float red[4 * 256];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r0 = blockIdx.x * 16, cb = blockIdx.y;
     const int nact = min(16, a.bt - r0);
-    const float4* pk = reinterpret_cast<const float4*>(a.pk) + (size_t)(cb * 4 + w) * KB4 * 64 + lane;
-    float4 b[KB4];
-#pragma unroll
-    for (int i = 0; i < KB4; ++i) b[i] = pk[i * 64];
-    const long pt = (long)a.p0 + r0;
+    const int row = tid >> 4, col = 16 * cb + (tid & 15);
+    const bool ok = row < nact;
+    const rsrc_t rDH = mk_rsrc(a.dHout), rH = mk_rsrc(a.Hout), rG = mk_rsrc(a.gates), rDP = mk_rsrc(a.dPre),
+                 rC = mk_rsrc(a.dHc), rT = mk_rsrc(a.tmpc);
+    const int soG = (a.p0 + r0) * GH * 4, soH = (a.p0 + r0) * H * 4, soP = (a.pprev0 + r0) * H * 4;
+    const int vg = ok ? (row * GH + col) * 4 : INVALID_OFF;
+    const int vh = ok ? (row * H + col) * 4 : INVALID_OFF;
+    float e_dh = 0.f, e_z = 0.f, e_r = 0.f, e_hh = 0.f, e_h0 = 0.f, e_t = 0.f;
     if (PHASE == 0) {
-        for (int idx = tid; idx < 16 * (H / 4); idx += 256) {
-            const int row = idx / (H / 4), c4 = idx % (H / 4);
-            float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < nact) {
-                const long q = pt + row;
+        e_dh = bload(rDH, vh, soH) + bload(rC, (ok && r0 + row < a.bnext) ? vh : INVALID_OFF, soH);
+        e_z = bload(rG, vg, soG);
+        e_r = bload(rG, vg + H * 4, soG);
+        e_hh = bload(rG, vg + 2 * H * 4, soG);
+        e_h0 = bload(rH, a.first ? INVALID_OFF : vh, soP);
+    } else {
+        e_t = bload(rT, vh, soH);
+    }
+    float4 b[K / 64];
+    const float4* pk = reinterpret_cast<const float4*>(a.pk) + (size_t)(cb * 4 + w) * (K / 64) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < K / 64; ++i) b[i] = pk[i * 64];
+    const long pt = (long)a.p0 + r0;
+#pragma unroll
+    for (int it = 0; it < (16 * (K / 4)) / 256; ++it) {
+        const int idx = tid + 256 * it;
+        const int rr = idx / (K / 4), c4 = idx % (K / 4);
+        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rr < nact) {
+            const long q = pt + rr;
+            if (PHASE == 0) {
                 float4 dh = reinterpret_cast<const float4*>(a.dHout + q * H)[c4];
-                if (r0 + row < a.bnext) {
+                if (r0 + rr < a.bnext) {
                     const float4 c = reinterpret_cast<const float4*>(a.dHc + q * H)[c4];
                     dh.x += c.x; dh.y += c.y; dh.z += c.z; dh.w += c.w;
                 }
@@ -157,52 +200,21 @@ __global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a) {
                 d.z = dh.z * (1.f - z.z) * act_grad<ACT>(hh.z);
                 d.w = dh.w * (1.f - z.w) * act_grad<ACT>(hh.w);
                 if (cb == 0) reinterpret_cast<float4*>(a.dPre + q * GH + 2 * H)[c4] = d;
+            } else {
+                d = reinterpret_cast<const float4*>(a.dPre + q * GH)[c4];
             }
-            float* o = ab + row * LDA + 4 * c4;
-            o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = d.w;
         }
-    } else {
-        for (int idx = tid; idx < 16 * (K / 4); idx += 256) {
-            const int row = idx / (K / 4), c4 = idx % (K / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < nact) v = reinterpret_cast<const float4*>(a.dPre + (pt + row) * GH)[c4];
-            float* o = ab + row * LDA + 4 * c4;
-            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-        }
+        float* o = ab + rr * LDA + 4 * c4;
+        o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = d.w;
     }
     __syncthreads();
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const float* ap = ab + (lane & 15) * LDA + (lane >> 4);
-#pragma unroll
-    for (int i = 0; i < KB4; ++i) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 0], b[i].x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 4], b[i].y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 8], b[i].z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 12], b[i].w, acc1, 0, 0, 0);
-    }
-    const int col = 64 * cb + 16 * w + (lane & 15);
-    const rsrc_t rDH = mk_rsrc(a.dHout), rH = mk_rsrc(a.Hout), rG = mk_rsrc(a.gates), rDP = mk_rsrc(a.dPre),
-                 rC = mk_rsrc(a.dHc), rT = mk_rsrc(a.tmpc);
-    const int soG = (a.p0 + r0) * GH * 4, soH = (a.p0 + r0) * H * 4, soP = (a.pprev0 + r0) * H * 4;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = 4 * (lane >> 4) + r;
-        const bool ok = row < nact;
-        const float acc = acc0[r] + acc1[r];
-        const int vg = ok ? (row * GH + col) * 4 : INVALID_OFF;
-        const int vh = ok ? (row * H + col) * 4 : INVALID_OFF;
-        if (PHASE == 0) {
-            float dh = bload(rDH, vh, soH);
-            dh += bload(rC, (ok && r0 + row < a.bnext) ? vh : INVALID_OFF, soH);
-            const float z = bload(rG, vg, soG), rr = bload(rG, vg + H * 4, soG), hh = bload(rG, vg + 2 * H * 4, soG);
-            const float h0 = bload(rH, a.first ? INVALID_OFF : vh, soP);
-            const float drh = acc;
-            bstore(rDP, vg, soG, dh * (h0 - hh) * hard_sigmoid_grad(z));
-            bstore(rDP, vg + H * 4, soG, drh * h0 * hard_sigmoid_grad(rr));
-            bstore(rT, vh, soH, dh * z + drh * rr);
-        } else {
-            bstore(rC, vh, soP, bload(rT, vh, soH) + acc);
-        }
+    const float acc = tile_16x16<K>(ab, red, b, tid);
+    if (PHASE == 0) {
+        bstore(rDP, vg, soG, e_dh * (e_h0 - e_hh) * hard_sigmoid_grad(e_z));
+        bstore(rDP, vg + H * 4, soG, acc * e_h0 * hard_sigmoid_grad(e_r));
+        bstore(rT, vh, soH, e_dh * e_z + acc * e_r);
+    } else {
+        bstore(rC, vh, soP, e_t + acc);
     }
 }
 
@@ -275,9 +287,9 @@ extern "C" int seqrec_rnn_fwd_stepwise(int cell, int act, int H, int H_real, int
         if (a.bt <= 0) break;
         const unsigned rb = (unsigned)((a.bt + 15) / 16);
         a.pk = upack;
-        STEP_DISPATCH(gru_step_fwd, 0, dim3(rb, 2 * H / 64));
+        STEP_DISPATCH(gru_step_fwd, 0, dim3(rb, 2 * H / 16));
         a.pk = upack + 2 * HH;
-        STEP_DISPATCH(gru_step_fwd, 1, dim3(rb, H / 64));
+        STEP_DISPATCH(gru_step_fwd, 1, dim3(rb, H / 16));
     }
     return 0;
 }
@@ -306,10 +318,10 @@ extern "C" int seqrec_rnn_bwd_stepwise(int cell, int act, int H, int H_real, int
         a.first = t == 0;
         const unsigned rb = (unsigned)((a.bt + 15) / 16);
         a.pk = upack + 3 * HH;
-        STEP_DISPATCH(gru_step_bwd, 0, dim3(rb, H / 64));
+        STEP_DISPATCH(gru_step_bwd, 0, dim3(rb, H / 16));
         if (t > 0) {
             a.pk = upack + 4 * HH;
-            STEP_DISPATCH(gru_step_bwd, 1, dim3(rb, H / 64));
+            STEP_DISPATCH(gru_step_bwd, 1, dim3(rb, H / 16));
         }
     }
     return 0;
