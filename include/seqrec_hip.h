@@ -160,12 +160,28 @@ int seqrec_rows_adagrad(float* table, float* accum, float* gtab, int32_t* slot, 
                         int64_t n, int width, int32_t base, float lr, float eps, const float* scale,
                         void* stream);
 
+/*      multi-list forms: up to 4 scatter lists (possibly of different tables) per launch */
+typedef struct seqrec_rows_job {
+    float* table; float* accum; float* gtab; int32_t* slot;
+    const int32_t* rows; const float* vals; int64_t ldv; const float* row_scale;
+    int64_t n; int32_t width; int32_t base;
+} seqrec_rows_job;
+int seqrec_rows_scatter_add_multi(const seqrec_rows_job* jobs_host, int count, void* stream);
+int seqrec_rows_sqnorm_multi(const seqrec_rows_job* jobs_host, int count, float* sq_accum, void* stream);
+int seqrec_rows_adagrad_multi(const seqrec_rows_job* jobs_host, int count, float lr, float eps,
+                              const float* scale, void* stream);
+
 /* ---- dense tensors: sq_accum += |g|^2 ; scale = (norm >= clipnorm) ? clipnorm/norm : 1 (Keras
  *      clip_norm); Adagrad update (Keras optimizers.Adagrad, epsilon=1e-8, decay=0). */
 int seqrec_sqnorm(const float* g, int64_t n, float* sq_accum, void* stream);
 int seqrec_clip_scale(const float* sq_accum, float clipnorm, float* scale, void* stream);
 int seqrec_adagrad_dense(float* p, float* a, const float* g, int64_t n, float lr, float eps,
                          const float* scale, void* stream);
+
+/*      multi-tensor forms (<= 8 tensors per launch; host arrays of device pointers / sizes) */
+int seqrec_sqnorm_multi(int count, const float* const* g, const int64_t* n, float* sq_accum, void* stream);
+int seqrec_adagrad_dense_multi(int count, float* const* p, float* const* a, const float* const* g,
+                               const int64_t* n, float lr, float eps, const float* scale, void* stream);
 
 /* ---- counter RNG (specification: oracle/rng.py).  Alias-method draw of K negatives for
  *      training step `step`; inverted-dropout multipliers out[r*ld + j] (j < width) drawn with

@@ -56,6 +56,11 @@ _SIGS = {
     "seqrec_rows_scatter_add": [P, P, P, P, L, P, L, I, I, P],
     "seqrec_rows_sqnorm": [P, P, P, L, I, I, P, P],
     "seqrec_rows_adagrad": [P, P, P, P, P, L, I, I, F, F, P, P],
+    "seqrec_rows_scatter_add_multi": [P, I, P],
+    "seqrec_rows_sqnorm_multi": [P, I, P, P],
+    "seqrec_rows_adagrad_multi": [P, I, F, F, P, P],
+    "seqrec_sqnorm_multi": [I, P, P, P, P],
+    "seqrec_adagrad_dense_multi": [I, P, P, P, P, F, F, P, P],
     "seqrec_sqnorm": [P, L, P, P],
     "seqrec_clip_scale": [P, F, P, P],
     "seqrec_adagrad_dense": [P, P, P, L, F, F, P, P],
@@ -69,6 +74,32 @@ _RESTYPES = {
     "seqrec_rnn_upack_floats": L,
 }
 EXPORTS = sorted(_SIGS)
+
+
+class RowsJob(C.Structure):
+    """seqrec_rows_job (include/seqrec_hip.h)."""
+    _fields_ = [("table", P), ("accum", P), ("gtab", P), ("slot", P), ("rows", P), ("vals", P), ("ldv", L),
+                ("row_scale", P), ("n", L), ("width", C.c_int32), ("base", C.c_int32)]
+
+
+def rows_jobs(jobs):
+    """list of dicts(table, accum, gtab, slot, rows, vals, ldv, row_scale, n, width, base) of torch tensors / ints
+    -> (ctypes array, count).  Keep the tensors alive until the launches are enqueued."""
+    arr = (RowsJob * len(jobs))()
+    for i, j in enumerate(jobs):
+        for k in ("table", "accum", "gtab", "slot", "rows", "vals", "row_scale"):
+            t = j.get(k)
+            setattr(arr[i], k, None if t is None else t.data_ptr())
+        arr[i].ldv, arr[i].n, arr[i].width, arr[i].base = int(j["ldv"]), int(j["n"]), int(j["width"]), int(j["base"])
+    return arr, len(jobs)
+
+
+def ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def i64_array(vals):
+    return (C.c_int64 * len(vals))(*[int(v) for v in vals])
 
 _lib = None
 

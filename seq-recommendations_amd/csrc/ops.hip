@@ -164,7 +164,8 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, 
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= width) return;
     float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += part[(long)p * width + col];
+#pragma unroll 8
+    for (int p = 0; p < nparts; ++p) s += part[(long)p * width + col];   // fixed order: deterministic
     out[col] = (accumulate ? out[col] : 0.f) + s;
 }
 
@@ -263,6 +264,89 @@ __global__ void adagrad_dense_kernel(float* __restrict__ p, float* __restrict__ 
     }
 }
 
+// multi-tensor forms: one launch for all dense tensors / all scatter lists of a step
+struct DenseMulti { float* p[8]; float* a[8]; const float* g[8]; long n[8]; };
+__global__ void sqnorm_multi_kernel(DenseMulti m, float* __restrict__ sq) {
+    const float* g = m.g[blockIdx.y];
+    const long n = m.n[blockIdx.y];
+    __shared__ float part[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += g[i] * g[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = part[0] + part[1] + part[2] + part[3];
+        if (t != 0.f) atomicAdd(sq, t);
+    }
+}
+__global__ void adagrad_multi_kernel(DenseMulti m, float lr, float eps, const float* __restrict__ scale) {
+    float* p = m.p[blockIdx.y];
+    float* a = m.a[blockIdx.y];
+    const float* g = m.g[blockIdx.y];
+    const long n = m.n[blockIdx.y];
+    const float sc = scale[0];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gv = g[i] * sc;
+        const float av = a[i] + gv * gv;
+        a[i] = av;
+        p[i] -= lr * gv / (sqrtf(av) + eps);
+    }
+}
+
+struct RowsMulti { seqrec_rows_job j[4]; };
+__global__ void rows_scatter_add_multi_kernel(RowsMulti m) {
+    const seqrec_rows_job& J = m.j[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= J.n) return;
+    const int r = J.rows[i];
+    const float s = J.row_scale ? J.row_scale[i] : 1.f;
+    float* g = J.gtab + (long)r * J.width;
+    const float* v = J.vals + i * J.ldv;
+    for (int c = lane; c < J.width; c += 64) atomicAdd(g + c, v[c] * s);
+    if (lane == 0) atomicMin(J.slot + r, J.base + (int)i);
+}
+__global__ void rows_sqnorm_multi_kernel(RowsMulti m, float* __restrict__ sq) {
+    const seqrec_rows_job& J = m.j[blockIdx.y];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * (blockDim.x >> 6) + wv;
+    __shared__ float part[4];
+    float s = 0.f;
+    if (i < J.n) {
+        const int r = J.rows[i];
+        if (J.slot[r] == J.base + (int)i) {
+            const float* g = J.gtab + (long)r * J.width;
+            for (int c = lane; c < J.width; c += 64) s += g[c] * g[c];
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) part[wv] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = part[0] + part[1] + part[2] + part[3];
+        if (t != 0.f) atomicAdd(sq, t);
+    }
+}
+__global__ void rows_adagrad_multi_kernel(RowsMulti m, float lr, float eps, const float* __restrict__ scale) {
+    const seqrec_rows_job& J = m.j[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= J.n) return;
+    const int r = J.rows[i];
+    if (J.slot[r] != J.base + (int)i) return;
+    const float sc = scale[0];
+    const long o = (long)r * J.width;
+    for (int c = lane; c < J.width; c += 64) {
+        const float g = J.gtab[o + c] * sc;
+        const float a = J.accum[o + c] + g * g;
+        J.accum[o + c] = a;
+        J.table[o + c] -= lr * g / (sqrtf(a) + eps);
+        J.gtab[o + c] = 0.f;
+    }
+    if (lane == 0) J.slot[r] = INT_MAX;
+}
+
 // counter RNG (oracle/rng.py)
 __global__ void sample_negatives_kernel(uint64_t key, uint64_t step, int K, const uint32_t* __restrict__ thresh,
                                         const int* __restrict__ alias, int V, int* __restrict__ out) {
@@ -324,6 +408,89 @@ extern "C" int seqrec_full_softmax_ce(float* logits, int64_t ld, const int32_t* 
     return 0;
 }
 
+namespace {
+// single-pass variant: the row (K <= 64*KR logits) is held in registers -- one read, one write
+template <bool ROWS, int KR>
+__global__ void sampled_softmax_ce_reg_kernel(float* __restrict__ ln, long ld, const float* __restrict__ hd, int H,
+                                              const float* __restrict__ Eout, const float* __restrict__ bout,
+                                              const float* __restrict__ logq, const float* __restrict__ lq_n,
+                                              const int* __restrict__ tgt, const int* __restrict__ neg, long n, int K,
+                                              float inv_denom, float* __restrict__ loss_rows, float* __restrict__ dlt) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int t = tgt[row];
+    float* x = ln + row * ld;
+    float v[KR];
+#pragma unroll
+    for (int i = 0; i < KR; ++i) {
+        const int k = lane + 64 * i;
+        float l = -INFINITY;
+        if (k < K) {
+            const int id = neg[k];
+            l = x[k];
+            if (ROWS) {
+                if (lq_n) l -= lq_n[k];
+            } else {
+                if (bout) l += bout[id];
+                if (logq) l -= logq[id];
+            }
+            if (id == t) l = -INFINITY;
+        }
+        v[i] = l;
+    }
+    const float* h = hd + row * H;
+    const float* et = Eout + (ROWS ? row : (long)t) * H;
+    float d = 0.f;
+    for (int j = lane; j < H; j += 64) d += h[j] * et[j];
+    float lt = wave_sum(d);
+    if (ROWS) {
+        if (logq) lt -= logq[row];
+    } else {
+        if (bout) lt += bout[t];
+        if (logq) lt -= logq[t];
+    }
+    float m = lt;
+#pragma unroll
+    for (int i = 0; i < KR; ++i) m = fmaxf(m, v[i]);
+    m = wave_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < KR; ++i) { v[i] = expf(v[i] - m); s += v[i]; }
+    const float etg = expf(lt - m);
+    s = wave_sum(s) + etg;
+    const float pt = etg / s;
+    const float lo = 1e-7f, hi = 1.0f - 1e-7f;
+    const float active = (pt >= lo && pt <= hi) ? inv_denom : 0.f;
+    if (lane == 0) {
+        loss_rows[row] = -logf(fminf(fmaxf(pt, lo), hi));
+        dlt[row] = (pt - 1.f) * active;
+    }
+    const float sc = active / s;
+#pragma unroll
+    for (int i = 0; i < KR; ++i) {
+        const int k = lane + 64 * i;
+        if (k < K) x[k] = v[i] * sc;
+    }
+}
+
+template <bool ROWS>
+int launch_sampled(float* ln, long ld, const float* hd, int H, const float* Eout, const float* bout, const float* logq,
+                   const float* lq_n, const int* tgt, const int* neg, long n, int K, float inv_denom, float* loss_rows,
+                   float* dlt, hipStream_t st) {
+    const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+#define SS_ARGS ln, ld, hd, H, Eout, bout, logq, lq_n, tgt, neg, n, K, inv_denom, loss_rows, dlt
+    if (K <= 64 * 8) hipLaunchKernelGGL((sampled_softmax_ce_reg_kernel<ROWS, 8>), grid, block, 0, st, SS_ARGS);
+    else if (K <= 64 * 16) hipLaunchKernelGGL((sampled_softmax_ce_reg_kernel<ROWS, 16>), grid, block, 0, st, SS_ARGS);
+    else if (K <= 64 * 32) hipLaunchKernelGGL((sampled_softmax_ce_reg_kernel<ROWS, 32>), grid, block, 0, st, SS_ARGS);
+    else if (K <= 64 * 64) hipLaunchKernelGGL((sampled_softmax_ce_reg_kernel<ROWS, 64>), grid, block, 0, st, SS_ARGS);
+    else hipLaunchKernelGGL(sampled_softmax_ce_kernel<ROWS>, grid, block, 0, st, SS_ARGS);
+#undef SS_ARGS
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace
+
 extern "C" int seqrec_sampled_softmax_ce(float* ln, int64_t ld, const float* hd, int H, const float* Eout,
                                          const float* bout, const float* logq, const int32_t* tgt,
                                          const int32_t* neg, int64_t n, int K, float inv_denom,
@@ -331,10 +498,8 @@ extern "C" int seqrec_sampled_softmax_ce(float* ln, int64_t ld, const float* hd,
     if (n < 0 || K < 0 || H <= 0 || ld < K) return SEQREC_E_ARG;
     if (n == 0) return 0;
     if (!ln || !hd || !Eout || !tgt || (K > 0 && !neg) || !loss_rows || !dlt) return SEQREC_E_ARG;
-    hipLaunchKernelGGL(sampled_softmax_ce_kernel<false>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), ln,
-                       (long)ld, hd, H, Eout, bout, logq, (const float*)nullptr, tgt, neg, (long)n, K, inv_denom, loss_rows, dlt);
-    SEQREC_LAUNCH_CHECK();
-    return 0;
+    return launch_sampled<false>(ln, (long)ld, hd, H, Eout, bout, logq, nullptr, tgt, neg, (long)n, K, inv_denom, loss_rows,
+                                 dlt, as_stream(stream));
 }
 
 extern "C" int seqrec_sampled_softmax_ce_rows(float* ln, int64_t ld, const float* hd, int H, const float* Etgt,
@@ -344,11 +509,8 @@ extern "C" int seqrec_sampled_softmax_ce_rows(float* ln, int64_t ld, const float
     if (n < 0 || K < 0 || H <= 0 || ld < K) return SEQREC_E_ARG;
     if (n == 0) return 0;
     if (!ln || !hd || !Etgt || !tgt || (K > 0 && !neg) || !loss_rows || !dlt) return SEQREC_E_ARG;
-    hipLaunchKernelGGL(sampled_softmax_ce_kernel<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), ln,
-                       (long)ld, hd, H, Etgt, (const float*)nullptr, lq_tgt, lq_neg, tgt, neg, (long)n, K, inv_denom,
-                       loss_rows, dlt);
-    SEQREC_LAUNCH_CHECK();
-    return 0;
+    return launch_sampled<true>(ln, (long)ld, hd, H, Etgt, nullptr, lq_tgt, lq_neg, tgt, neg, (long)n, K, inv_denom,
+                                loss_rows, dlt, as_stream(stream));
 }
 
 extern "C" int seqrec_reduce_sum(const float* x, int64_t n, float* out, int accumulate, void* stream) {
@@ -362,14 +524,14 @@ extern "C" int seqrec_colsum(const float* X, int64_t n, int width, int64_t ld, f
                              float* workspace, void* stream) {
     if (n < 0 || width <= 0 || !out || !workspace) return SEQREC_E_ARG;
     if (n > 0 && !X) return SEQREC_E_ARG;
-    constexpr int NP = 64;
+    constexpr int NP = 32;                       // partial rows (workspace holds up to 64)
     const int np = (int)(n < NP * 4 ? (n + 3) / 4 : NP);
     hipStream_t st = as_stream(stream);
     if (np > 0) {
         hipLaunchKernelGGL(colsum_partial_kernel, dim3((width + 63) / 64, np), dim3(256), 0, st, X, (long)n, width, (long)ld, workspace);
         SEQREC_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((width + 255) / 256), dim3(256), 0, st, workspace, np, width, out, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((width + 63) / 64), dim3(64), 0, st, workspace, np, width, out, accumulate);
     SEQREC_LAUNCH_CHECK();
     return 0;
 }
@@ -477,6 +639,73 @@ extern "C" int seqrec_dropout_mask(uint64_t seed, uint64_t stream_id, const int6
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n_rows * width, 256)), dim3(256), 0, as_stream(stream),
                        key64(seed, stream_id), reinterpret_cast<const long*>(rowkey), (long)n_rows, width, (long)ld, thr,
                        inv_keep, out);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int seqrec_sqnorm_multi(int count, const float* const* g, const int64_t* n, float* sq_accum, void* stream) {
+    if (count < 0 || count > 8 || !sq_accum || (count > 0 && (!g || !n))) return SEQREC_E_ARG;
+    if (count == 0) return 0;
+    DenseMulti m = {};
+    for (int i = 0; i < count; ++i) { if (n[i] < 0 || (n[i] > 0 && !g[i])) return SEQREC_E_ARG; m.g[i] = g[i]; m.n[i] = n[i]; }
+    hipLaunchKernelGGL(sqnorm_multi_kernel, dim3(128, count), dim3(256), 0, as_stream(stream), m, sq_accum);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int seqrec_adagrad_dense_multi(int count, float* const* p, float* const* a, const float* const* g,
+                                          const int64_t* n, float lr, float eps, const float* scale, void* stream) {
+    if (count < 0 || count > 8 || !scale || (count > 0 && (!p || !a || !g || !n))) return SEQREC_E_ARG;
+    if (count == 0) return 0;
+    DenseMulti m = {};
+    for (int i = 0; i < count; ++i) {
+        if (n[i] < 0 || (n[i] > 0 && (!p[i] || !a[i] || !g[i]))) return SEQREC_E_ARG;
+        m.p[i] = p[i]; m.a[i] = a[i]; m.g[i] = g[i]; m.n[i] = n[i];
+    }
+    hipLaunchKernelGGL(adagrad_multi_kernel, dim3(256, count), dim3(256), 0, as_stream(stream), m, lr, eps, scale);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+static int fill_rows_multi(const seqrec_rows_job* jobs, int count, RowsMulti& m, long& maxn) {
+    if (count < 0 || count > 4 || (count > 0 && !jobs)) return SEQREC_E_ARG;
+    maxn = 0;
+    for (int i = 0; i < count; ++i) {
+        const seqrec_rows_job& j = jobs[i];
+        if (j.n < 0 || j.width <= 0) return SEQREC_E_ARG;
+        if (j.n > 0 && (!j.gtab || !j.slot || !j.rows)) return SEQREC_E_ARG;
+        m.j[i] = j;
+        if (j.n > maxn) maxn = j.n;
+    }
+    return 0;
+}
+extern "C" int seqrec_rows_scatter_add_multi(const seqrec_rows_job* jobs, int count, void* stream) {
+    RowsMulti m = {};
+    long maxn;
+    int rc = fill_rows_multi(jobs, count, m, maxn);
+    if (rc || maxn == 0) return rc;
+    for (int i = 0; i < count; ++i) if (jobs[i].n > 0 && !jobs[i].vals) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(rows_scatter_add_multi_kernel, dim3((unsigned)((maxn + 3) / 4), count), dim3(256), 0, as_stream(stream), m);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int seqrec_rows_sqnorm_multi(const seqrec_rows_job* jobs, int count, float* sq_accum, void* stream) {
+    RowsMulti m = {};
+    long maxn;
+    int rc = fill_rows_multi(jobs, count, m, maxn);
+    if (rc || maxn == 0) return rc;
+    if (!sq_accum) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(rows_sqnorm_multi_kernel, dim3((unsigned)((maxn + 3) / 4), count), dim3(256), 0, as_stream(stream), m, sq_accum);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int seqrec_rows_adagrad_multi(const seqrec_rows_job* jobs, int count, float lr, float eps, const float* scale,
+                                         void* stream) {
+    RowsMulti m = {};
+    long maxn;
+    int rc = fill_rows_multi(jobs, count, m, maxn);
+    if (rc || maxn == 0) return rc;
+    if (!scale) return SEQREC_E_ARG;
+    for (int i = 0; i < count; ++i) if (jobs[i].n > 0 && (!jobs[i].table || !jobs[i].accum)) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(rows_adagrad_multi_kernel, dim3((unsigned)((maxn + 3) / 4), count), dim3(256), 0, as_stream(stream), m, lr, eps, scale);
     SEQREC_LAUNCH_CHECK();
     return 0;
 }

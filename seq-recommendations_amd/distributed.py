@@ -193,7 +193,7 @@ class ShardedEngine(Engine):
         call("seqrec_reduce_sum", ptr(loss_rows), n, ptr(self.loss_sum), 0, st)
         # -- backward
         dHd = self.buf("dHd", n, Hp)
-        self.gemm(1, 0, n, Hp, K, ln, K, Eneg, Hp, dHd, Hp, tag="dH")
+        self.gemm(1, 0, n, Hp, K, ln, K, Eneg, Hp, dHd, Hp, splitk=self._splitk(n, Hp, K), tag="dH")
         call("seqrec_gather_rows", ptr(Etgt), ptr(ar), ptr(dHd), n, Hp, ptr(dlt), None, 1, st)
         dEneg = self.buf("dEneg", K, Hp)
         self.gemm(0, 0, K, Hp, n, ln, K, Hd, Hp, dEneg, Hp, splitk=self._splitk(K, Hp, n), tag="dEneg")
@@ -215,7 +215,7 @@ class ShardedEngine(Engine):
             self.gemm(0, 0, Hp, GHp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp, splitk=sk, tag="dU")
         self.gemm(0, 0, Dp, GHp, n, X, Dp, dPre, GHp, Gd["W"], GHp, splitk=self._splitk(Dp, GHp, n), tag="dW")
         dX = self.buf("dX", n, Dp)
-        self.gemm(1, 1, n, Dp, GHp, dPre, GHp, P["W"], GHp, dX, Dp, tag="dX")
+        self.gemm(1, 1, n, Dp, GHp, dPre, GHp, P["W"], GHp, dX, Dp, splitk=self._splitk(n, Dp, GHp), tag="dX")
         # -- row gradients back to their owners, scatter-add into the local gradient tables
         jobs = []
         g_in, r_in = self.ex.push(d["plan_in"], dX, self._take)

@@ -196,8 +196,9 @@ class Engine:
 
     @staticmethod
     def _splitk(M, N, K):
+        """Split K until ~512 workgroups (2 per CU) are in flight; slabs are reduced deterministically."""
         tiles = ((M + 63) // 64) * ((N + 63) // 64)
-        return int(max(1, min(32, 512 // max(tiles, 1), K // 128)))
+        return int(max(1, min(32, -(-512 // max(tiles, 1)), K // 128)))
 
     # ------------------------------------------------------------------ parameters (Keras layouts)
     def _gate_pad(self, w, rows_p):
@@ -335,6 +336,11 @@ class Engine:
             out["_rk_out"] = rk
         return out
 
+    def _job(self, name, rows, vals, ldv, row_scale, n, width, base):
+        """One scatter list of this step for table `name` (see seqrec_rows_job)."""
+        return dict(table=self.P[name], accum=self.A[name], gtab=self.Gt[name], slot=self.slot[name], rows=rows, vals=vals,
+                    ldv=ldv, row_scale=row_scale, n=n, width=width, base=base, name=name)
+
     # ------------------------------------------------------------------ recurrent scan
     def _scan_fwd(self, d, XW, Hout, gates, aux):
         c, st = self.cfg, self._stream()
@@ -467,33 +473,24 @@ class Engine:
                 self.gemm(0, 0, Hp, c.V_out, n, Hd, Hp, dl, Vp, Gd["Wout"], Vp, splitk=self._splitk(Hp, c.V_out, n), tag="dWout")
             if c.out_bias and tr["bout"]:
                 call("seqrec_colsum", ptr(dl), n, c.V_out, Vp, ptr(Gd["bout"]), 0, ptr(cs_ws), st)
-            self.gemm(1, 1, n, Hp, c.V_out, dl, Vp, P["Wout"], Vp, dHd, Hp, tag="dH")
+            self.gemm(1, 1, n, Hp, c.V_out, dl, Vp, P["Wout"], Vp, dHd, Hp, splitk=self._splitk(n, Hp, c.V_out), tag="dH")
         else:
             K = c.K
             tname = "E" if c.tied else "Eout"
             Et = P[tname]
             dln, dlt, neg, Eneg = r["dln"], r["dlt"], r["neg"], r["Eneg"]
-            self.gemm(1, 0, n, Hp, K, dln, K, Eneg, Hp, dHd, Hp, tag="dH")
+            self.gemm(1, 0, n, Hp, K, dln, K, Eneg, Hp, dHd, Hp, splitk=self._splitk(n, Hp, K), tag="dH")
             call("seqrec_gather_rows", ptr(Et), ptr(d["tgt"]), ptr(dHd), n, Hp, ptr(dlt), None, 1, st)
             if tr[tname]:
                 dEneg = self.buf("dEneg", K, Hp)
                 self.gemm(0, 0, K, Hp, n, dln, K, Hd, Hp, dEneg, Hp, splitk=self._splitk(K, Hp, n), tag="dEneg")
-                base_t, base_n = 0, n
-                call("seqrec_rows_scatter_add", ptr(Gt[tname]), ptr(self.slot[tname]), ptr(d["tgt"]), ptr(Hd), Hp,
-                     ptr(dlt), n, Hp, base_t, st)
-                call("seqrec_rows_scatter_add", ptr(Gt[tname]), ptr(self.slot[tname]), ptr(neg), ptr(dEneg), Hp,
-                     None, K, Hp, base_n, st)
-                sparse_jobs.append((tname, d["tgt"], n, Hp, base_t))
-                sparse_jobs.append((tname, neg, K, Hp, base_n))
+                sparse_jobs.append(self._job(tname, d["tgt"], Hd, Hp, dlt, n, Hp, 0))
+                sparse_jobs.append(self._job(tname, neg, dEneg, Hp, None, K, Hp, n))
             if c.out_bias and tr["bout"]:
                 dbn = self.buf("dbn", K)
                 call("seqrec_colsum", ptr(dln), n, K, K, ptr(dbn), 0, ptr(cs_ws), st)
-                call("seqrec_rows_scatter_add", ptr(Gt["bout"]), ptr(self.slot["bout"]), ptr(d["tgt"]), ptr(dlt), 1,
-                     None, n, 1, 0, st)
-                call("seqrec_rows_scatter_add", ptr(Gt["bout"]), ptr(self.slot["bout"]), ptr(neg), ptr(dbn), 1,
-                     None, K, 1, n, st)
-                sparse_jobs.append(("bout", d["tgt"], n, 1, 0))
-                sparse_jobs.append(("bout", neg, K, 1, n))
+                sparse_jobs.append(self._job("bout", d["tgt"], dlt, 1, None, n, 1, 0))
+                sparse_jobs.append(self._job("bout", neg, dbn, 1, None, K, 1, n))
         dHout = dHd
         if "out" in drops:
             call("seqrec_mul", ptr(dHd), ptr(drops["out"]), ptr(dHd), n * Hp, st)
@@ -512,9 +509,7 @@ class Engine:
                 self.gemm(0, 0, Hp, GHp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp, splitk=sk, tag="dU")
         if c.input == "onehot":
             if tr["Wk"]:
-                call("seqrec_rows_scatter_add", ptr(Gt["Wk"]), ptr(self.slot["Wk"]), ptr(d["ids"]), ptr(dPre), GHp,
-                     ptr(drops.get("in")), n, GHp, 0, st)
-                sparse_jobs.append(("Wk", d["ids"], n, GHp, 0))
+                sparse_jobs.append(self._job("Wk", d["ids"], dPre, GHp, drops.get("in"), n, GHp, 0))
         else:
             X = r["X"]
             Kd = X.shape[1]
@@ -523,31 +518,35 @@ class Engine:
                 self.gemm(0, 0, Kd, GHp, n, X, Kd, dPre, GHp, Gd[wname], GHp, splitk=self._splitk(Kd, GHp, n), tag="dW")
             if c.input == "embed" and tr["E"]:
                 dX = self.buf("dX", n, self.Dp)
-                self.gemm(1, 1, n, self.Dp, GHp, dPre, GHp, P["W"], GHp, dX, self.Dp, tag="dX")
+                self.gemm(1, 1, n, self.Dp, GHp, dPre, GHp, P["W"], GHp, dX, self.Dp, splitk=self._splitk(n, self.Dp, GHp), tag="dX")
                 if "in" in drops:
                     call("seqrec_mul", ptr(dX), ptr(drops["in"]), ptr(dX), n * self.Dp, st)
                 base_i = (n + c.K) if c.tied else 0
-                call("seqrec_rows_scatter_add", ptr(Gt["E"]), ptr(self.slot["E"]), ptr(d["ids"]), ptr(dX), self.Dp,
-                     None, n, self.Dp, base_i, st)
-                sparse_jobs.append(("E", d["ids"], n, self.Dp, base_i))
+                sparse_jobs.append(self._job("E", d["ids"], dX, self.Dp, None, n, self.Dp, base_i))
+        # ---- row-sparse contributions: one launch for (up to 4) scatter lists
+        groups = [sparse_jobs[i:i + 4] for i in range(0, len(sparse_jobs), 4)]
+        packed = [_lib.rows_jobs(g) for g in groups]
+        for arr, cnt in packed:
+            call("seqrec_rows_scatter_add_multi", arr, cnt, st)
         if not apply_update:
             return sparse_jobs
         # ---- global-norm clip over every trainable tensor (Keras clipnorm), then Adagrad
         self.sq.zero_()
-        for k, g in Gd.items():
-            if tr[k]:
-                call("seqrec_sqnorm", ptr(g), g.numel(), ptr(self.sq), st)
-        for (k, rows, nr, w, base) in sparse_jobs:
-            call("seqrec_rows_sqnorm", ptr(Gt[k]), ptr(self.slot[k]), ptr(rows), nr, w, base, ptr(self.sq), st)
+        dk = [k for k in Gd if tr[k]]
+        if dk:
+            gp = _lib.ptr_array([Gd[k] for k in dk])
+            nn = _lib.i64_array([Gd[k].numel() for k in dk])
+            call("seqrec_sqnorm_multi", len(dk), gp, nn, ptr(self.sq), st)
+        for arr, cnt in packed:
+            call("seqrec_rows_sqnorm_multi", arr, cnt, ptr(self.sq), st)
         call("seqrec_clip_scale", ptr(self.sq), float(clipnorm if clipnorm else 0.0), ptr(self.scale), st)
-        for k, g in Gd.items():
-            if tr[k]:
-                call("seqrec_adagrad_dense", ptr(P[k]), ptr(self.A[k]), ptr(g), g.numel(), lr, eps, ptr(self.scale), st)
+        if dk:
+            call("seqrec_adagrad_dense_multi", len(dk), _lib.ptr_array([P[k] for k in dk]),
+                 _lib.ptr_array([self.A[k] for k in dk]), gp, nn, lr, eps, ptr(self.scale), st)
+        for arr, cnt in packed:
+            call("seqrec_rows_adagrad_multi", arr, cnt, lr, eps, ptr(self.scale), st)
         if tr["U"]:
             self.upack_dirty = True
-        for (k, rows, nr, w, base) in sparse_jobs:
-            call("seqrec_rows_adagrad", ptr(P[k]), ptr(self.A[k]), ptr(Gt[k]), ptr(self.slot[k]), ptr(rows), nr, w, base,
-                 lr, eps, ptr(self.scale), st)
         return self.loss_sum / n
 
     def grads(self, d, step=0, negatives=None):

@@ -231,7 +231,8 @@ def test_full_softmax_ce_vs_oracle(n, V):
     np.testing.assert_array_equal(buf2[:, :V].cpu().numpy(), logits)
 
 
-@pytest.mark.parametrize("n,K,H,V", [(5, 7, 64, 30), (333, 2000, 256, 5000), (64, 100, 128, 100)])
+@pytest.mark.parametrize("n,K,H,V", [(5, 7, 64, 30), (333, 2000, 256, 5000), (64, 100, 128, 100), (40, 600, 64, 900),
+                                     (33, 3000, 64, 4000), (17, 5000, 64, 6000)])
 @pytest.mark.parametrize("bias,lq", [(False, False), (True, True)])
 def test_sampled_softmax_ce_vs_oracle(n, K, H, V, bias, lq):
     rng = np.random.default_rng(n + K)
@@ -407,3 +408,56 @@ def test_gru_stepwise_scan_vs_oracle_and_persistent(H, B, maxlen, act):
 def lib_rc(name, cell):
     lib = L.load()
     return getattr(lib, name)(cell, 0, 64, 64, 1, 1, None, None, None, None, None, None, None)
+
+
+def test_multi_launch_forms_equal_single_forms():
+    rng = np.random.default_rng(12)
+    # dense
+    shapes = [(256, 768), (768,), (300, 5)]
+    g = [rng.normal(size=sh).astype(np.float32) * 0.01 for sh in shapes]
+    p = [rng.normal(size=sh).astype(np.float32) for sh in shapes]
+    a = [np.abs(rng.normal(size=sh)).astype(np.float32) for sh in shapes]
+    gd, pd_, ad = [dev(x) for x in g], [dev(x) for x in p], [dev(x) for x in a]
+    sq = torch.zeros(1, device="cuda"); scale = torch.empty(1, device="cuda")
+    nn = L.i64_array([x.numel() for x in gd])
+    call("seqrec_sqnorm_multi", 3, L.ptr_array(gd), nn, ptr(sq), st())
+    ref = sum((x.astype(np.float64) ** 2).sum() for x in g)
+    assert abs(sq.item() - ref) <= 1e-5 * ref
+    call("seqrec_clip_scale", ptr(sq), 0.05, ptr(scale), st())
+    sc = min(1.0, 0.05 / np.sqrt(ref))
+    call("seqrec_adagrad_dense_multi", 3, L.ptr_array(pd_), L.ptr_array(ad), L.ptr_array(gd), nn, 0.01, 1e-8, ptr(scale), st())
+    for i in range(3):
+        gv = g[i] * np.float32(sc)
+        ar = a[i] + gv * gv
+        np.testing.assert_allclose(ad[i].cpu().numpy(), ar, rtol=2e-6)
+        np.testing.assert_allclose(pd_[i].cpu().numpy(), p[i] - np.float32(0.01) * gv / (np.sqrt(ar) + np.float32(1e-8)), rtol=3e-6, atol=1e-7)
+    # rows: two tables, three lists, shared bases on the first table
+    V1, W1, V2, W2 = 500, 256, 300, 1
+    T1, A1 = rng.normal(size=(V1, W1)).astype(np.float32), np.abs(rng.normal(size=(V1, W1))).astype(np.float32)
+    T2, A2 = rng.normal(size=(V2, W2)).astype(np.float32), np.abs(rng.normal(size=(V2, W2))).astype(np.float32)
+    r1 = rng.integers(0, 40, 200).astype(np.int32); v1 = rng.normal(size=(200, W1)).astype(np.float32); s1 = rng.normal(size=200).astype(np.float32)
+    r2 = rng.integers(0, V1, 90).astype(np.int32); v2 = rng.normal(size=(90, W1)).astype(np.float32)
+    r3 = rng.integers(0, V2, 70).astype(np.int32); v3 = rng.normal(size=(70, 1)).astype(np.float32)
+    d = {k: dev(v) for k, v in dict(T1=T1, A1=A1, T2=T2, A2=A2, r1=r1, v1=v1, s1=s1, r2=r2, v2=v2, r3=r3, v3=v3).items()}
+    G1 = torch.zeros((V1, W1), device="cuda"); G2 = torch.zeros((V2, W2), device="cuda")
+    S1 = torch.full((V1,), 2 ** 31 - 1, dtype=torch.int32, device="cuda"); S2 = torch.full((V2,), 2 ** 31 - 1, dtype=torch.int32, device="cuda")
+    jobs = [dict(table=d["T1"], accum=d["A1"], gtab=G1, slot=S1, rows=d["r1"], vals=d["v1"], ldv=W1, row_scale=d["s1"], n=200, width=W1, base=0),
+            dict(table=d["T1"], accum=d["A1"], gtab=G1, slot=S1, rows=d["r2"], vals=d["v2"], ldv=W1, row_scale=None, n=90, width=W1, base=200),
+            dict(table=d["T2"], accum=d["A2"], gtab=G2, slot=S2, rows=d["r3"], vals=d["v3"], ldv=1, row_scale=None, n=70, width=1, base=0)]
+    arr, cnt = L.rows_jobs(jobs)
+    call("seqrec_rows_scatter_add_multi", arr, cnt, st())
+    g1 = np.zeros((V1, W1)); np.add.at(g1, r1, v1.astype(np.float64) * s1[:, None]); np.add.at(g1, r2, v2.astype(np.float64))
+    g2 = np.zeros((V2, 1)); np.add.at(g2, r3, v3.astype(np.float64))
+    np.testing.assert_allclose(G1.cpu().numpy(), g1, atol=2e-4)
+    sq.zero_()
+    call("seqrec_rows_sqnorm_multi", arr, cnt, ptr(sq), st())
+    tot = (g1 ** 2).sum() + (g2 ** 2).sum()
+    assert abs(sq.item() - tot) <= 1e-4 * tot
+    scale.fill_(0.5)
+    call("seqrec_rows_adagrad_multi", arr, cnt, 0.01, 1e-8, ptr(scale), st())
+    for (T, A, gg, Td, Ad) in ((T1, A1, g1, d["T1"], d["A1"]), (T2, A2, g2, d["T2"], d["A2"])):
+        gv = gg * 0.5
+        ar = A + gv * gv
+        np.testing.assert_allclose(Ad.cpu().numpy(), ar, rtol=3e-6, atol=1e-7)
+        np.testing.assert_allclose(Td.cpu().numpy(), T - 0.01 * gv / (np.sqrt(ar) + 1e-8), rtol=3e-6, atol=3e-7)
+    assert torch.all(G1 == 0) and torch.all(G2 == 0) and torch.all(S1 == 2 ** 31 - 1) and torch.all(S2 == 2 ** 31 - 1)
