@@ -9,6 +9,7 @@
 //
 // Roofline: MFMA-bound, 157.3 TFLOP/s fp32; algorithmic flops = 2*M*N*K.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -24,15 +25,15 @@ struct GemmArgs {
     const int* tgt; const float* thr; int* rank;
 };
 
-constexpr int BK = 16;
+constexpr int BK = 16;          // K granule of split-K bookkeeping; kernels use BKT = 16 or 32
 
 // Load the 4 consecutive-k (KCONTIG) or consecutive-r (!KCONTIG) elements that thread `idx` owns.
-template <int BR, bool KCONTIG>
+template <int BR, int BKT, bool KCONTIG>
 __device__ __forceinline__ float4 load_tile4(const float* __restrict__ X, long ld, long r0, long k0,
                                              long R, long Kend, int idx, bool vec_ok) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (KCONTIG) {
-        const int r = idx >> 2, kq = idx & 3;
+        const int r = idx / (BKT / 4), kq = idx % (BKT / 4);
         const long gr = r0 + r, gk = k0 + 4 * kq;
         if (gr < R) {
             const float* p = X + gr * ld + gk;
@@ -63,11 +64,11 @@ __device__ __forceinline__ float4 load_tile4(const float* __restrict__ X, long l
     return v;
 }
 
-template <int BR, bool KCONTIG>
+template <int BR, int BKT, bool KCONTIG>
 __device__ __forceinline__ void store_tile4(float* __restrict__ S, int idx, float4 v) {
     constexpr int LD = BR + 2;
     if (KCONTIG) {
-        const int r = idx >> 2, kq = idx & 3;
+        const int r = idx / (BKT / 4), kq = idx % (BKT / 4);
         S[(4 * kq + 0) * LD + r] = v.x;
         S[(4 * kq + 1) * LD + r] = v.y;
         S[(4 * kq + 2) * LD + r] = v.z;
@@ -79,13 +80,13 @@ __device__ __forceinline__ void store_tile4(float* __restrict__ S, int idx, floa
     }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC>
+template <int BM, int BN, int BKT, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     constexpr int LDA = BM + 2, LDB = BN + 2;
     constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 MFMA tiles per wave
-    constexpr int NA = BM / 64, NB = BN / 64;     // float4 loads per thread per operand
-    __shared__ float As[2][BK * LDA];
-    __shared__ float Bs[2][BK * LDB];
+    constexpr int NA = BM * BKT / 1024, NB = BN * BKT / 1024;     // float4 loads per thread per operand
+    __shared__ float As[2][BKT * LDA];
+    __shared__ float Bs[2][BKT * LDB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     const long m0 = (long)(tile / g.tiles_n) * BM, n0 = (long)(tile % g.tiles_n) * BN;
     const long kbeg = (long)blockIdx.z * g.k_per_split;
     const long kend = min(g.K, kbeg + g.k_per_split);
-    const int nk = (int)((kend - kbeg + BK - 1) / BK);
+    const int nk = (int)((kend - kbeg + BKT - 1) / BKT);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -105,17 +106,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 
     float4 ra[NA], rb[NB];
     auto gload = [&](int kt) {
-        const long k0 = kbeg + (long)kt * BK;
+        const long k0 = kbeg + (long)kt * BKT;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) ra[i] = load_tile4<BM, A_KC>(g.A, g.lda, m0, k0, g.M, kend, tid + 256 * i, g.a_vec);
+        for (int i = 0; i < NA; ++i) ra[i] = load_tile4<BM, BKT, A_KC>(g.A, g.lda, m0, k0, g.M, kend, tid + 256 * i, g.a_vec);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) rb[i] = load_tile4<BN, B_KC>(g.B, g.ldb, n0, k0, g.N, kend, tid + 256 * i, g.b_vec);
+        for (int i = 0; i < NB; ++i) rb[i] = load_tile4<BN, BKT, B_KC>(g.B, g.ldb, n0, k0, g.N, kend, tid + 256 * i, g.b_vec);
     };
     auto sstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) store_tile4<BM, A_KC>(As[buf], tid + 256 * i, ra[i]);
+        for (int i = 0; i < NA; ++i) store_tile4<BM, BKT, A_KC>(As[buf], tid + 256 * i, ra[i]);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) store_tile4<BN, B_KC>(Bs[buf], tid + 256 * i, rb[i]);
+        for (int i = 0; i < NB; ++i) store_tile4<BN, BKT, B_KC>(Bs[buf], tid + 256 * i, rb[i]);
     };
 
     if (nk > 0) {
@@ -128,20 +129,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         if (kt + 1 < nk) gload(kt + 1);
         const float* as = As[cur] + wm * (BM / 2) + (lane & 31);
         const float* bs = Bs[cur] + wn * (BN / 2) + (lane & 31);
+        // all MFMA operand fragments of this K tile first (one ds_read_b32 each), then the MFMAs
+        // back to back: hipcc otherwise pairs every read with its use and exposes the LDS latency
+        // in front of each MFMA (lgkmcnt(0) per pair).
+        float a[BKT / 2][TM], b[BKT / 2][TN];
 #pragma unroll
-        for (int ks = 0; ks < BK / 2; ++ks) {
+        for (int ks = 0; ks < BKT / 2; ++ks) {
             const int kk = 2 * ks + (lane >> 5);
-            float a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = as[kk * LDA + 32 * i];
+            for (int i = 0; i < TM; ++i) a[ks][i] = as[kk * LDA + 32 * i];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = bs[kk * LDB + 32 * j];
+            for (int j = 0; j < TN; ++j) b[ks][j] = bs[kk * LDB + 32 * j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < BKT / 2; ++ks)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < nk) sstore(cur ^ 1);
         __syncthreads();
         cur ^= 1;
@@ -204,17 +212,26 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, l
     }
 }
 
-template <int BM, int BN>
-int launch_gemm(int a_kc, int b_kc, GemmArgs& g, int splits, hipStream_t st) {
+template <int BM, int BN, int BKT>
+int launch_gemm_bk(int a_kc, int b_kc, GemmArgs& g, int splits, hipStream_t st) {
     const long tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
     g.tiles_n = (int)tiles_n;
     dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)splits), block(256);
-    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, block, 0, st, g);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, st, g);
-    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, block, 0, st, g);
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BKT, true, true>), grid, block, 0, st, g);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BKT, true, false>), grid, block, 0, st, g);
+    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BKT, false, true>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BKT, false, false>), grid, block, 0, st, g);
     SEQREC_LAUNCH_CHECK();
     return 0;
+}
+// one barrier per 32-deep K tile when the per-split K is long enough (halves the barrier count);
+// 128x128 stays at 16 (LDS: 2 x 2 x 32 x 130 x 4 B would cost occupancy)
+template <int BM, int BN>
+int launch_gemm(int a_kc, int b_kc, GemmArgs& g, int splits, hipStream_t st) {
+    static const bool bk32 = getenv("SEQREC_GEMM_BK32") && atoi(getenv("SEQREC_GEMM_BK32")) != 0;   // tuning switch
+    if (bk32 && BM * BN < 128 * 128 && g.k_per_split >= 64 && g.k_per_split % 32 == 0)
+        return launch_gemm_bk<BM, BN, (BM * BN < 128 * 128 ? 32 : 16)>(a_kc, b_kc, g, splits, st);
+    return launch_gemm_bk<BM, BN, 16>(a_kc, b_kc, g, splits, st);
 }
 
 }  // namespace
@@ -240,7 +257,7 @@ extern "C" int seqrec_gemm_f32(int a_kcontig, int b_kcontig, int64_t M, int64_t 
     g.a_vec = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 4 == 0);
     g.b_vec = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 4 == 0);
     long kps = (K + splitk - 1) / splitk;
-    kps = (kps + BK - 1) / BK * BK;
+    kps = (kps + 31) / 32 * 32;                       // multiple of both K-tile depths
     if (kps == 0) kps = BK;
     int splits = (int)((K + kps - 1) / kps);
     if (splits < 1) splits = 1;
@@ -295,7 +312,7 @@ extern "C" int seqrec_rank_count(const float* hd, int H, const float* Eout, cons
     GemmArgs g;
     g.A = hd; g.B = Eout; g.C = nullptr; g.bias = bout;
     g.M = n; g.N = V; g.K = H; g.lda = H; g.ldb = H; g.ldc = 0;
-    g.k_per_split = (H + BK - 1) / BK * BK;
+    g.k_per_split = (H + 31) / 32 * 32;
     g.accumulate = 0;
     g.a_vec = ((reinterpret_cast<uintptr_t>(hd) & 15) == 0) && (H % 4 == 0);
     g.b_vec = ((reinterpret_cast<uintptr_t>(Eout) & 15) == 0) && (H % 4 == 0);

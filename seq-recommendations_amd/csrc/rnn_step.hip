@@ -46,8 +46,13 @@ struct StepArgs {
 //   value = B[4*kb + (lane>>4)][16*cb + (lane&15)]
 // mode 0: B[k][n] = U[k*ldu + coff + n]           (forward:  K = H)
 // mode 1: B[k][n] = U[n*ldu + coff + k]           (backward: transposed; K = H or 2H)
-__global__ void pack_step_kernel(const float* __restrict__ U, int ldu, int coff, int K, int N, int mode,
-                                 float* __restrict__ out) {
+struct PackStepJob { int coff, K, N, mode; long off; };
+struct PackStepArgs { const float* U; float* out; int ldu; PackStepJob job[4]; };
+__global__ void pack_step_kernel(PackStepArgs pa) {
+    const PackStepJob jb = pa.job[blockIdx.y];
+    const float* __restrict__ U = pa.U;
+    float* __restrict__ out = pa.out + jb.off;
+    const int ldu = pa.ldu, coff = jb.coff, K = jb.K, N = jb.N, mode = jb.mode;
     const long total = (long)K * N;
     const int G4 = K / 64;                 // float4 groups per wave
     for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
@@ -261,10 +266,13 @@ extern "C" int seqrec_rnn_pack_u_stepwise(int cell, int H, const float* U, float
     if (!U || !upack) return SEQREC_E_ARG;
     hipStream_t st = as_stream(stream);
     const long HH = (long)H * H;
-    hipLaunchKernelGGL(pack_step_kernel, dim3(256), dim3(256), 0, st, U, 3 * H, 0, H, 2 * H, 0, upack);
-    hipLaunchKernelGGL(pack_step_kernel, dim3(256), dim3(256), 0, st, U, 3 * H, 2 * H, H, H, 0, upack + 2 * HH);
-    hipLaunchKernelGGL(pack_step_kernel, dim3(256), dim3(256), 0, st, U, 3 * H, 2 * H, H, H, 1, upack + 3 * HH);
-    hipLaunchKernelGGL(pack_step_kernel, dim3(256), dim3(256), 0, st, U, 3 * H, 0, 2 * H, H, 1, upack + 4 * HH);
+    PackStepArgs pa = {};
+    pa.U = U; pa.out = upack; pa.ldu = 3 * H;
+    pa.job[0] = PackStepJob{0, H, 2 * H, 0, 0};
+    pa.job[1] = PackStepJob{2 * H, H, H, 0, 2 * HH};
+    pa.job[2] = PackStepJob{2 * H, H, H, 1, 3 * HH};
+    pa.job[3] = PackStepJob{0, 2 * H, H, 1, 4 * HH};
+    hipLaunchKernelGGL(pack_step_kernel, dim3(128, 4), dim3(256), 0, st, pa);
     SEQREC_LAUNCH_CHECK();
     return 0;
 }

@@ -171,6 +171,11 @@ class Engine:
         self.stepwise = (c.scan == "stepwise") or (c.scan == "auto" and c.cell == "gru" and self.Hp <= 256)
         if self.stepwise and c.cell != "gru":
             raise ValueError("scan='stepwise' exists for the GRU only")
+        import os
+        self.use_side = os.environ.get("SEQREC_SIDE_STREAM", "0") != "0"   # measured: overlap slows the scan more than it hides
+        self.side = torch.cuda.Stream(device=self.dev)     # independent work beside the scan (dEneg GEMM)
+        self.ev_fork = torch.cuda.Event()
+        self.ev_join = torch.cuda.Event()
         self.sampler = None       # (thresh uint32-as-int32 tensor, alias int32 tensor, logq float tensor)
         self.step_count = 0
 
@@ -187,10 +192,11 @@ class Engine:
             self.ws[name] = t
         return t[:n].view(*shape) if shape else t[:1]
 
-    def gemm(self, a_kc, b_kc, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, accumulate=0, splitk=1, tag=None):
+    def gemm(self, a_kc, b_kc, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, accumulate=0, splitk=1, tag=None,
+             ws_name="gemm_ws"):
         wsp = None
         if splitk > 1:
-            wsp = self.buf("gemm_ws", splitk * M * N)
+            wsp = self.buf(ws_name, splitk * M * N)
         call("seqrec_gemm_f32", int(a_kc), int(b_kc), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(Cm), ldc, ptr(bias),
              accumulate, splitk, ptr(wsp), self._stream(), tag=tag)
 
@@ -463,7 +469,8 @@ class Engine:
         Hd = r["Hd"]
         Gd, Gt = self.Gd, self.Gt
         tr = self.trainable
-        sparse_jobs = []     # (param, rows tensor, n_rows, width, base) -- scatter lists of this step
+        sparse_jobs = []     # scatter lists of this step (see _job)
+        forked = False
         dHd = self.buf("dHd", n, Hp)
         cs_ws = self.buf("colsum_ws", 64 * max(GHp, self.Vp, c.K if c.output == "sampled" else 1))
         if c.output == "full":
@@ -482,8 +489,19 @@ class Engine:
             self.gemm(1, 0, n, Hp, K, dln, K, Eneg, Hp, dHd, Hp, splitk=self._splitk(n, Hp, K), tag="dH")
             call("seqrec_gather_rows", ptr(Et), ptr(d["tgt"]), ptr(dHd), n, Hp, ptr(dlt), None, 1, st)
             if tr[tname]:
+                # the output-table gradient does not feed the BPTT chain: run it beside the scan
                 dEneg = self.buf("dEneg", K, Hp)
-                self.gemm(0, 0, K, Hp, n, dln, K, Hd, Hp, dEneg, Hp, splitk=self._splitk(K, Hp, n), tag="dEneg")
+                if self.use_side:
+                    main = torch.cuda.current_stream(self.dev)
+                    self.ev_fork.record(main)
+                    self.side.wait_event(self.ev_fork)
+                    with torch.cuda.stream(self.side):
+                        self.gemm(0, 0, K, Hp, n, dln, K, Hd, Hp, dEneg, Hp, splitk=self._splitk(K, Hp, n), tag="dEneg",
+                                  ws_name="gemm_ws_side")
+                        self.ev_join.record(self.side)
+                    forked = True
+                else:
+                    self.gemm(0, 0, K, Hp, n, dln, K, Hd, Hp, dEneg, Hp, splitk=self._splitk(K, Hp, n), tag="dEneg")
                 sparse_jobs.append(self._job(tname, d["tgt"], Hd, Hp, dlt, n, Hp, 0))
                 sparse_jobs.append(self._job(tname, neg, dEneg, Hp, None, K, Hp, n))
             if c.out_bias and tr["bout"]:
@@ -523,6 +541,8 @@ class Engine:
                     call("seqrec_mul", ptr(dX), ptr(drops["in"]), ptr(dX), n * self.Dp, st)
                 base_i = (n + c.K) if c.tied else 0
                 sparse_jobs.append(self._job("E", d["ids"], dX, self.Dp, None, n, self.Dp, base_i))
+        if forked:
+            torch.cuda.current_stream(self.dev).wait_event(self.ev_join)
         # ---- row-sparse contributions: one launch for (up to 4) scatter lists
         groups = [sparse_jobs[i:i + 4] for i in range(0, len(sparse_jobs), 4)]
         packed = [_lib.rows_jobs(g) for g in groups]
