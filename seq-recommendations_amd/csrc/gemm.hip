@@ -263,12 +263,13 @@ extern "C" int seqrec_gemm_f32(int a_kcontig, int b_kcontig, int64_t M, int64_t 
     if (splits < 1) splits = 1;
     g.k_per_split = kps;
     if (splits > 1) { g.C = workspace; g.ldc = N; } else { g.C = C; g.ldc = ldc; }
-    // tile choice: the biggest tile that still puts >= 2 workgroups on every CU (256 CUs)
+    // tile choice: the biggest tile that still puts >= 4 workgroups on every CU (256 CUs); measured on
+    // the c3 shapes, 64x64 beats 128x64 below that (K is short: prologue/epilogue dominate)
     const long t128 = ((M + 127) / 128) * ((N + 127) / 128) * splits;
     const long t12864 = ((M + 127) / 128) * ((N + 63) / 64) * splits;
     int rc;
-    if (t128 >= 512) rc = launch_gemm<128, 128>(a_kcontig, b_kcontig, g, splits, st);
-    else if (t12864 >= 512) rc = launch_gemm<128, 64>(a_kcontig, b_kcontig, g, splits, st);
+    if (t128 >= 1024) rc = launch_gemm<128, 128>(a_kcontig, b_kcontig, g, splits, st);
+    else if (t12864 >= 1024) rc = launch_gemm<128, 64>(a_kcontig, b_kcontig, g, splits, st);
     else rc = launch_gemm<64, 64>(a_kcontig, b_kcontig, g, splits, st);
     if (rc) return rc;
     if (splits > 1) {
