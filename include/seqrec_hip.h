@@ -90,12 +90,13 @@ int seqrec_rnn_bwd(int cell, int act, int H, int H_real, int T, int B, const int
                    const float* dHout, const float* Hout, const float* gates, const float* aux,
                    float* dPre, const float* upack, void* stream);
 
-/*      Step-wise form of the same scan (GRU only; rnn_step.hip): one small whole-chip launch per
- *      recurrent GEMM (2 per step) instead of one persistent workgroup per 16 sessions -- shorter
+/*      Step-wise form of the same scan (rnn_step.hip): one small whole-chip launch per recurrent
+ *      GEMM (GRU: 2 per step; LSTM/SimpleRNN: 1 forward, pointwise + GEMM backward) instead of one
+ *      persistent workgroup per 16 sessions -- shorter
  *      critical path when few long sessions dominate (MSNBC-shaped batches).  Needs the step offsets
  *      on the HOST (step_off_host, T+1 ints) to size the launches; same buffers and results.
  *      upack: seqrec_rnn_upack_floats() floats written by seqrec_rnn_pack_u_stepwise.
- *      bwd workspace: 2 * N_tok * H floats.  Other cells return SEQREC_E_UNSUPPORTED. */
+ *      bwd workspace: 2 * N_tok * H floats. */
 int seqrec_rnn_pack_u_stepwise(int cell, int H, const float* U, float* upack, void* stream);
 int seqrec_rnn_fwd_stepwise(int cell, int act, int H, int H_real, int T, int B,
                             const int32_t* step_off_host, const float* XW, float* Hout,

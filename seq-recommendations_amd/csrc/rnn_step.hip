@@ -91,6 +91,23 @@ __device__ __forceinline__ float tile_16x16(const float* __restrict__ ab, float*
     return (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
 }
 
+// LSTM forward layout: out[((cb*4 + g)*(H/16) + i)*64 + lane] (float4), element e <-> kb = 4*i + e,
+//   value = U[(4*kb + (lane>>4)) * 4H + g*H + 16*cb + (lane&15)]
+__global__ void pack_lstm_fwd_kernel(const float* __restrict__ U, int H, float* __restrict__ out) {
+    const long total = 4L * H * H;
+    const int G4 = H / 16;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+        long q = o;
+        const int e = (int)(q & 3); q >>= 2;
+        const int l = (int)(q & 63); q >>= 6;
+        const int i = (int)(q % G4); q /= G4;
+        const int g = (int)(q & 3); q >>= 2;
+        const int cb = (int)q;
+        const int k = 4 * (4 * i + e) + (l >> 4);
+        out[o] = U[(long)k * 4 * H + g * H + 16 * cb + (l & 15)];
+    }
+}
+
 template <int J, int ACT, int PHASE>
 __global__ __launch_bounds__(256) void gru_step_fwd(StepArgs a) {
     // PHASE 0: [z|r] = hs(xw + h_prev.U_zr), r*h_prev        grid (rows/16, 2H/16)
@@ -223,6 +240,175 @@ __global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LSTM forward step (ONE launch per step): workgroup = 16 rows x 16 hidden columns, wave g computes
+// gate g's pre-activation over the whole K; gate values meet in LDS and thread (row, col) finishes
+// c and h.  packed: [cb][gate][K/16 float4 groups][lane]
+// SimpleRNN forward step: same tile with K split over the waves.
+// ---------------------------------------------------------------------------------------------
+template <int J, int ACT>
+__global__ __launch_bounds__(256) void lstm_step_fwd(StepArgs a) {
+    constexpr int H = 64 * J, LDA = H + 2, GH = 4 * H, G4 = H / 16;
+    __shared__ float ab[16 * LDA];
+    __shared__ float red[4 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r0 = blockIdx.x * 16, cb = blockIdx.y;
+    const int nact = min(16, a.bt - r0);
+    const int row = tid >> 4, col = 16 * cb + (tid & 15);
+    const bool ok = row < nact;
+    const rsrc_t rXW = mk_rsrc(a.XW), rH = mk_rsrc(a.Hout), rG = mk_rsrc(a.gates), rC = mk_rsrc(a.aux);
+    const int soG = (a.p0 + r0) * GH * 4, soH = (a.p0 + r0) * H * 4, soP = (a.pprev0 + r0) * H * 4;
+    const int vg = ok ? (row * GH + col) * 4 : INVALID_OFF;
+    const int vh = ok ? (row * H + col) * 4 : INVALID_OFF;
+    float xw[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) xw[g] = bload(rXW, vg + g * H * 4, soG);
+    const float cp = bload(rC, a.first ? INVALID_OFF : vh, soP);
+    if (!a.first) {
+        float4 b[G4];
+        const float4* pk = reinterpret_cast<const float4*>(a.pk) + (size_t)(cb * 4 + w) * G4 * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < G4; ++i) b[i] = pk[i * 64];
+        const float* src = a.Hout + (long)(a.pprev0 + r0) * H;
+#pragma unroll
+        for (int it = 0; it < (16 * (H / 4)) / 256; ++it) {
+            const int idx = tid + 256 * it;
+            const int rr = idx / (H / 4), c4 = idx % (H / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rr < nact) v = reinterpret_cast<const float4*>(src + (long)rr * H)[c4];
+            float* d = ab + rr * LDA + 4 * c4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+        const float* ap = ab + (lane & 15) * LDA + (lane >> 4);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < G4; ++i) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 0], b[i].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 4], b[i].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 8], b[i].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 12], b[i].w, acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[w * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc0[r] + acc1[r];
+        __syncthreads();
+    }
+    const float pi = (a.first ? 0.f : red[tid]) + xw[0];
+    const float pf = (a.first ? 0.f : red[256 + tid]) + xw[1];
+    const float pc = (a.first ? 0.f : red[512 + tid]) + xw[2];
+    const float po = (a.first ? 0.f : red[768 + tid]) + xw[3];
+    const float gi = hard_sigmoid(pi), gf = hard_sigmoid(pf), gg = act_fwd<ACT>(pc), go = hard_sigmoid(po);
+    float c = gf * cp + gi * gg;
+    float h = go * act_fwd<ACT>(c);
+    if (col >= a.H_real) { c = 0.f; h = 0.f; }
+    bstore(rH, vh, soH, h);
+    bstore(rC, vh, soH, c);
+    bstore(rG, vg, soG, gi);
+    bstore(rG, vg + H * 4, soG, gf);
+    bstore(rG, vg + 2 * H * 4, soG, gg);
+    bstore(rG, vg + 3 * H * 4, soG, go);
+}
+
+template <int J, int ACT>
+__global__ __launch_bounds__(256) void srnn_step_fwd(StepArgs a) {
+    constexpr int H = 64 * J, LDA = H + 2;
+    __shared__ float ab[16 * LDA];
+    __shared__ float red[4 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r0 = blockIdx.x * 16, cb = blockIdx.y;
+    const int nact = min(16, a.bt - r0);
+    const int row = tid >> 4, col = 16 * cb + (tid & 15);
+    const bool ok = row < nact;
+    const rsrc_t rXW = mk_rsrc(a.XW), rH = mk_rsrc(a.Hout);
+    const int soH = (a.p0 + r0) * H * 4;
+    const int vh = ok ? (row * H + col) * 4 : INVALID_OFF;
+    const float xw = bload(rXW, vh, soH);
+    float acc = 0.f;
+    if (!a.first) {
+        float4 b[H / 64];
+        const float4* pk = reinterpret_cast<const float4*>(a.pk) + (size_t)(cb * 4 + w) * (H / 64) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < H / 64; ++i) b[i] = pk[i * 64];
+        const float* src = a.Hout + (long)(a.pprev0 + r0) * H;
+#pragma unroll
+        for (int it = 0; it < (16 * (H / 4)) / 256; ++it) {
+            const int idx = tid + 256 * it;
+            const int rr = idx / (H / 4), c4 = idx % (H / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rr < nact) v = reinterpret_cast<const float4*>(src + (long)rr * H)[c4];
+            float* d = ab + rr * LDA + 4 * c4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+        acc = tile_16x16<H>(ab, red, b, tid);
+    }
+    float y = act_fwd<ACT>(acc + xw);
+    if (col >= a.H_real) y = 0.f;
+    bstore(rH, vh, soH, y);
+}
+
+// pointwise part of one backward step: dPre[p] from dh (= dHout + carried dh), the stash and, for the
+// LSTM, the carried dc (dCc).  One thread per (row, hidden col).  grid = ceil(bt*H / 256)
+template <int CELL, int ACT>
+__global__ void pointwise_bwd_step(StepArgs a) {
+    const int H = a.H;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)a.bt * H) return;
+    const int row = (int)(e / H), col = (int)(e % H);
+    const long q = (long)a.p0 + row;
+    float dh = a.dHout[q * H + col];
+    if (row < a.bnext) dh += a.dHc[q * H + col];
+    if (CELL == SEQREC_CELL_SIMPLERNN) {
+        a.dPre[q * H + col] = dh * act_grad<ACT>(a.Hout[q * H + col]);
+    } else {
+        const long GH = 4L * H;
+        const float* gp = a.gates + q * GH + col;
+        const float gi = gp[0], gf = gp[H], gg = gp[2 * H], go = gp[3 * H];
+        const float cn = a.aux[q * H + col];
+        const float cp = a.first ? 0.f : a.aux[((long)a.pprev0 + row) * H + col];
+        const float dcin = row < a.bnext ? a.tmpc[q * H + col] : 0.f;      // dc carried from step t+1
+        const float ac = act_fwd<ACT>(cn);
+        const float dct = dcin + dh * go * act_grad<ACT>(ac);
+        float* o = a.dPre + q * GH + col;
+        o[0] = dct * gg * hard_sigmoid_grad(gi);
+        o[H] = dct * cp * hard_sigmoid_grad(gf);
+        o[2 * H] = dct * gi * act_grad<ACT>(gg);
+        o[3 * H] = dh * ac * hard_sigmoid_grad(go);
+        if (!a.first) a.tmpc[((long)a.pprev0 + row) * H + col] = dct * gf;   // dc for the previous token
+    }
+}
+
+// dHc[prev token][own 16 cols] = dPre[p][0:K] . packed(U^T)      (K = G*H), skipped at t = 0
+template <int K>
+__global__ __launch_bounds__(256) void gemm_bwd_step(StepArgs a, int H, int ldp) {
+    constexpr int LDA = K + 2;
+    __shared__ float ab[16 * LDA];
+    __shared__ float red[4 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r0 = blockIdx.x * 16, cb = blockIdx.y;
+    const int nact = min(16, a.bt - r0);
+    const int row = tid >> 4, col = 16 * cb + (tid & 15);
+    const bool ok = row < nact;
+    float4 b[K / 64];
+    const float4* pk = reinterpret_cast<const float4*>(a.pk) + (size_t)(cb * 4 + w) * (K / 64) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < K / 64; ++i) b[i] = pk[i * 64];
+    const long pt = (long)a.p0 + r0;
+#pragma unroll
+    for (int it = 0; it < (16 * (K / 4)) / 256; ++it) {
+        const int idx = tid + 256 * it;
+        const int rr = idx / (K / 4), c4 = idx % (K / 4);
+        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rr < nact) d = reinterpret_cast<const float4*>(a.dPre + (pt + rr) * ldp)[c4];
+        float* o = ab + rr * LDA + 4 * c4;
+        o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = d.w;
+    }
+    __syncthreads();
+    const float acc = tile_16x16<K>(ab, red, b, tid);
+    const rsrc_t rC = mk_rsrc(a.dHc);
+    bstore(rC, ok ? (row * H + col) * 4 : INVALID_OFF, (a.pprev0 + r0) * H * 4, acc);
+}
+
 template <typename KF> int launch_step(KF kern, dim3 grid, const StepArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, a);
     SEQREC_LAUNCH_CHECK();
@@ -249,11 +435,54 @@ template <typename KF> int launch_step(KF kern, dim3 grid, const StepArgs& a, hi
         if (rc__) return rc__;                                                                  \
     } while (0)
 
+#define CELL_DISPATCH(KERN, GRID)                                                              \
+    do {                                                                                        \
+        int rc__ = SEQREC_E_SHAPE;                                                              \
+        switch (J * 4 + act) {                                                                  \
+            case 4 * 1 + 0: rc__ = launch_step(KERN<1, 0>, GRID, a, st); break;                 \
+            case 4 * 1 + 1: rc__ = launch_step(KERN<1, 1>, GRID, a, st); break;                 \
+            case 4 * 1 + 2: rc__ = launch_step(KERN<1, 2>, GRID, a, st); break;                 \
+            case 4 * 2 + 0: rc__ = launch_step(KERN<2, 0>, GRID, a, st); break;                 \
+            case 4 * 2 + 1: rc__ = launch_step(KERN<2, 1>, GRID, a, st); break;                 \
+            case 4 * 2 + 2: rc__ = launch_step(KERN<2, 2>, GRID, a, st); break;                 \
+            case 4 * 4 + 0: rc__ = launch_step(KERN<4, 0>, GRID, a, st); break;                 \
+            case 4 * 4 + 1: rc__ = launch_step(KERN<4, 1>, GRID, a, st); break;                 \
+            case 4 * 4 + 2: rc__ = launch_step(KERN<4, 2>, GRID, a, st); break;                 \
+            case 4 * 8 + 0: rc__ = launch_step(KERN<8, 0>, GRID, a, st); break;                 \
+            case 4 * 8 + 1: rc__ = launch_step(KERN<8, 1>, GRID, a, st); break;                 \
+            case 4 * 8 + 2: rc__ = launch_step(KERN<8, 2>, GRID, a, st); break;                 \
+        }                                                                                       \
+        if (rc__) return rc__;                                                                  \
+    } while (0)
+
+template <int CELL> int launch_pointwise(int act, const StepArgs& a, hipStream_t st) {
+    const unsigned blocks = (unsigned)(((long)a.bt * a.H + 255) / 256);
+    if (act == 0) hipLaunchKernelGGL((pointwise_bwd_step<CELL, 0>), dim3(blocks), dim3(256), 0, st, a);
+    else if (act == 1) hipLaunchKernelGGL((pointwise_bwd_step<CELL, 1>), dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((pointwise_bwd_step<CELL, 2>), dim3(blocks), dim3(256), 0, st, a);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_gemm_bwd(int K, dim3 grid, const StepArgs& a, int H, int ldp, hipStream_t st) {
+    switch (K) {
+        case 64: hipLaunchKernelGGL(gemm_bwd_step<64>, grid, dim3(256), 0, st, a, H, ldp); break;
+        case 128: hipLaunchKernelGGL(gemm_bwd_step<128>, grid, dim3(256), 0, st, a, H, ldp); break;
+        case 256: hipLaunchKernelGGL(gemm_bwd_step<256>, grid, dim3(256), 0, st, a, H, ldp); break;
+        case 512: hipLaunchKernelGGL(gemm_bwd_step<512>, grid, dim3(256), 0, st, a, H, ldp); break;
+        case 1024: hipLaunchKernelGGL(gemm_bwd_step<1024>, grid, dim3(256), 0, st, a, H, ldp); break;
+        case 2048: hipLaunchKernelGGL(gemm_bwd_step<2048>, grid, dim3(256), 0, st, a, H, ldp); break;
+        default: return SEQREC_E_SHAPE;
+    }
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+
 bool ok_shape(int cell, int act, int H, int H_real, int T, int B) {
-    if (cell != SEQREC_CELL_GRU || act < 0 || act > 2) return false;
+    if (cell < 0 || cell > 2 || act < 0 || act > 2) return false;
     if (!(H == 64 || H == 128 || H == 256 || H == 512)) return false;
     if (H_real < 1 || H_real > H || T < 0 || B < 0) return false;
-    if ((long)B * T * 3 * H * 4 >= 0x7FFFFFF0L) return false;
+    if ((long)B * T * 4 * H * 4 >= 0x7FFFFFF0L) return false;
     return true;
 }
 
@@ -261,11 +490,30 @@ bool ok_shape(int cell, int act, int H, int H_real, int T, int B) {
 
 // layouts, in this order inside upack: fwd [z|r] (H x 2H), fwd h (H x H), bwd U_h^T (H x H), bwd [U_z U_r]^T (2H x H)
 extern "C" int seqrec_rnn_pack_u_stepwise(int cell, int H, const float* U, float* upack, void* stream) {
-    if (cell != SEQREC_CELL_GRU) return SEQREC_E_UNSUPPORTED;
+    if (cell < 0 || cell > 2) return SEQREC_E_UNSUPPORTED;
     if (!(H == 64 || H == 128 || H == 256 || H == 512)) return SEQREC_E_SHAPE;
     if (!U || !upack) return SEQREC_E_ARG;
     hipStream_t st = as_stream(stream);
     const long HH = (long)H * H;
+    if (cell == SEQREC_CELL_LSTM) {
+        // fwd: [cb][gate][K/16 groups][lane] -- wave g streams gate g's 16 columns over the whole K
+        hipLaunchKernelGGL(pack_lstm_fwd_kernel, dim3(256), dim3(256), 0, st, U, H, upack);
+        PackStepArgs pl = {};
+        pl.U = U; pl.out = upack; pl.ldu = 4 * H;
+        pl.job[0] = PackStepJob{0, 4 * H, H, 1, 4 * HH};          // bwd: U^T, K = 4H
+        hipLaunchKernelGGL(pack_step_kernel, dim3(128, 1), dim3(256), 0, st, pl);
+        SEQREC_LAUNCH_CHECK();
+        return 0;
+    }
+    if (cell == SEQREC_CELL_SIMPLERNN) {
+        PackStepArgs ps = {};
+        ps.U = U; ps.out = upack; ps.ldu = H;
+        ps.job[0] = PackStepJob{0, H, H, 0, 0};
+        ps.job[1] = PackStepJob{0, H, H, 1, HH};
+        hipLaunchKernelGGL(pack_step_kernel, dim3(128, 2), dim3(256), 0, st, ps);
+        SEQREC_LAUNCH_CHECK();
+        return 0;
+    }
     PackStepArgs pa = {};
     pa.U = U; pa.out = upack; pa.ldu = 3 * H;
     pa.job[0] = PackStepJob{0, H, 2 * H, 0, 0};
@@ -280,9 +528,10 @@ extern "C" int seqrec_rnn_pack_u_stepwise(int cell, int H, const float* U, float
 extern "C" int seqrec_rnn_fwd_stepwise(int cell, int act, int H, int H_real, int T, int B,
                                        const int32_t* step_off_host, const float* XW, float* Hout,
                                        float* gates, float* aux, const float* upack, void* stream) {
-    if (!ok_shape(cell, act, H, H_real, T, B)) return cell == SEQREC_CELL_GRU ? SEQREC_E_SHAPE : SEQREC_E_UNSUPPORTED;
+    if (!ok_shape(cell, act, H, H_real, T, B)) return SEQREC_E_SHAPE;
     if (T == 0 || B == 0) return 0;
-    if (!step_off_host || !XW || !Hout || !gates || !aux || !upack) return SEQREC_E_ARG;
+    if (!step_off_host || !XW || !Hout || !upack) return SEQREC_E_ARG;
+    if (cell != SEQREC_CELL_SIMPLERNN && (!gates || !aux)) return SEQREC_E_ARG;
     hipStream_t st = as_stream(stream);
     const int J = H / 64;
     const long HH = (long)H * H;
@@ -295,9 +544,15 @@ extern "C" int seqrec_rnn_fwd_stepwise(int cell, int act, int H, int H_real, int
         if (a.bt <= 0) break;
         const unsigned rb = (unsigned)((a.bt + 15) / 16);
         a.pk = upack;
-        STEP_DISPATCH(gru_step_fwd, 0, dim3(rb, 2 * H / 16));
-        a.pk = upack + 2 * HH;
-        STEP_DISPATCH(gru_step_fwd, 1, dim3(rb, H / 16));
+        if (cell == SEQREC_CELL_GRU) {
+            STEP_DISPATCH(gru_step_fwd, 0, dim3(rb, 2 * H / 16));
+            a.pk = upack + 2 * HH;
+            STEP_DISPATCH(gru_step_fwd, 1, dim3(rb, H / 16));
+        } else if (cell == SEQREC_CELL_LSTM) {
+            CELL_DISPATCH(lstm_step_fwd, dim3(rb, H / 16));
+        } else {
+            CELL_DISPATCH(srnn_step_fwd, dim3(rb, H / 16));
+        }
     }
     return 0;
 }
@@ -307,9 +562,10 @@ extern "C" int seqrec_rnn_bwd_stepwise(int cell, int act, int H, int H_real, int
                                        const int32_t* step_off_host, const float* dHout, const float* Hout,
                                        const float* gates, const float* aux, float* dPre, const float* upack,
                                        float* workspace, void* stream) {
-    if (!ok_shape(cell, act, H, H_real, T, B)) return cell == SEQREC_CELL_GRU ? SEQREC_E_SHAPE : SEQREC_E_UNSUPPORTED;
+    if (!ok_shape(cell, act, H, H_real, T, B)) return SEQREC_E_SHAPE;
     if (T == 0 || B == 0) return 0;
-    if (!step_off_host || !dHout || !Hout || !gates || !dPre || !upack || !workspace) return SEQREC_E_ARG;
+    if (!step_off_host || !dHout || !Hout || !dPre || !upack || !workspace) return SEQREC_E_ARG;
+    if (cell != SEQREC_CELL_SIMPLERNN && (!gates || !aux)) return SEQREC_E_ARG;
     hipStream_t st = as_stream(stream);
     const int J = H / 64;
     const long HH = (long)H * H;
@@ -325,11 +581,22 @@ extern "C" int seqrec_rnn_bwd_stepwise(int cell, int act, int H, int H_real, int
         a.pprev0 = t > 0 ? step_off_host[t - 1] : 0;
         a.first = t == 0;
         const unsigned rb = (unsigned)((a.bt + 15) / 16);
-        a.pk = upack + 3 * HH;
-        STEP_DISPATCH(gru_step_bwd, 0, dim3(rb, H / 16));
-        if (t > 0) {
-            a.pk = upack + 4 * HH;
-            STEP_DISPATCH(gru_step_bwd, 1, dim3(rb, H / 16));
+        if (cell == SEQREC_CELL_GRU) {
+            a.pk = upack + 3 * HH;
+            STEP_DISPATCH(gru_step_bwd, 0, dim3(rb, H / 16));
+            if (t > 0) {
+                a.pk = upack + 4 * HH;
+                STEP_DISPATCH(gru_step_bwd, 1, dim3(rb, H / 16));
+            }
+        } else {
+            const int G = cell == SEQREC_CELL_LSTM ? 4 : 1;
+            int rc = cell == SEQREC_CELL_LSTM ? launch_pointwise<SEQREC_CELL_LSTM>(act, a, st)
+                                              : launch_pointwise<SEQREC_CELL_SIMPLERNN>(act, a, st);
+            if (rc) return rc;
+            if (t > 0) {
+                a.pk = upack + (long)G * HH;
+                if ((rc = launch_gemm_bwd(G * H, dim3(rb, H / 16), a, H, G * H, st))) return rc;
+            }
         }
     }
     return 0;

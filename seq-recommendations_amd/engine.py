@@ -168,9 +168,7 @@ class Engine:
         self.loss_sum = z(1)
         self.upack = torch.empty(int(_lib.load().seqrec_rnn_upack_floats(CELL[c.cell], self.Hp)), **f32)
         self.upack_dirty = True
-        self.stepwise = (c.scan == "stepwise") or (c.scan == "auto" and c.cell == "gru" and self.Hp <= 256)
-        if self.stepwise and c.cell != "gru":
-            raise ValueError("scan='stepwise' exists for the GRU only")
+        self.stepwise = (c.scan == "stepwise") or (c.scan == "auto" and self.Hp >= 128)
         import os
         self.use_side = os.environ.get("SEQREC_SIDE_STREAM", "0") != "0"   # measured: overlap slows the scan more than it hides
         self.side = torch.cuda.Stream(device=self.dev)     # independent work beside the scan (dEneg GEMM)

@@ -366,32 +366,33 @@ def test_rank_count_vs_numpy():
     assert np.abs(got - ref).max() <= 2 and (got == ref).mean() > 0.97     # fp32 near-ties only
 
 
+@pytest.mark.parametrize("cell", ["gru", "lstm", "simplernn"])
 @pytest.mark.parametrize("H,B,maxlen,act", [(64, 5, 6, "relu"), (64, 37, 12, "tanh"), (128, 100, 9, "relu"),
                                             (256, 70, 20, "relu"), (256, 512, 49, "tanh"), (128, 40, 10, "linear"),
                                             (512, 33, 7, "relu")])
-def test_gru_stepwise_scan_vs_oracle_and_persistent(H, B, maxlen, act):
-    """The launch-per-step GRU scan (rnn_step.hip) against the oracle, and bit-for-bit-close to the
-    persistent scan (same fp32 MFMA chains, only the accumulator pairing differs)."""
-    cell = "gru"
+def test_stepwise_scan_vs_oracle_and_persistent(cell, H, B, maxlen, act):
+    """The launch-per-step scan (rnn_step.hip) against the oracle, and close to the persistent scan
+    (same fp32 MFMA chains, only the accumulation split differs)."""
     rng = np.random.default_rng(H * 3 + B + maxlen)
     rb, XW, U = packed_scan_inputs(rng, cell, H, B, maxlen)
-    n, G = rb.n_tok, 3
+    n, G = rb.n_tok, onn.N_GATES[cell]
+    ci = L.CELL[cell]
     dH = (rng.normal(size=(n, H)) * 0.5).astype(np.float32)
     ref = oracle_scan(cell, act, rb, XW, U, dH)
     Hout = torch.full((n, H), float("nan"), device="cuda"); gates = torch.full((n, G * H), float("nan"), device="cuda")
     aux = torch.full((n, H), float("nan"), device="cuda")
-    up = torch.empty(int(L.load().seqrec_rnn_upack_floats(2, H)), device="cuda")
+    up = torch.empty(int(L.load().seqrec_rnn_upack_floats(ci, H)), device="cuda")
     XWd, Ud = dev(XW), dev(U)
-    call("seqrec_rnn_pack_u_stepwise", 2, H, ptr(Ud), ptr(up), st())
+    call("seqrec_rnn_pack_u_stepwise", ci, H, ptr(Ud), ptr(up), st())
     so = rb.step_off
-    call("seqrec_rnn_fwd_stepwise", 2, L.ACT[act], H, H, rb.T, rb.B, so.ctypes.data, ptr(XWd), ptr(Hout), ptr(gates), ptr(aux),
+    call("seqrec_rnn_fwd_stepwise", ci, L.ACT[act], H, H, rb.T, rb.B, so.ctypes.data, ptr(XWd), ptr(Hout), ptr(gates), ptr(aux),
          ptr(up), st())
     got = Hout.cpu().numpy()
     scale = max(1.0, np.abs(ref["H"]).max())
     assert np.abs(got - ref["H"]).max() <= 3e-5 * scale
     dPre = torch.full((n, G * H), float("nan"), device="cuda")
     ws = torch.full((2 * n * H,), float("nan"), device="cuda")
-    call("seqrec_rnn_bwd_stepwise", 2, L.ACT[act], H, H, rb.T, rb.B, so.ctypes.data, ptr(dev(dH)), ptr(Hout), ptr(gates), ptr(aux),
+    call("seqrec_rnn_bwd_stepwise", ci, L.ACT[act], H, H, rb.T, rb.B, so.ctypes.data, ptr(dev(dH)), ptr(Hout), ptr(gates), ptr(aux),
          ptr(dPre), ptr(up), ptr(ws), st())
     gp = dPre.cpu().numpy()
     s2 = max(1.0, np.abs(ref["dPre"]).max())
@@ -399,65 +400,6 @@ def test_gru_stepwise_scan_vs_oracle_and_persistent(H, B, maxlen, act):
     assert np.isfinite(gp).all() and bad.mean() < 2e-4, (bad.mean(), np.abs(gp - ref["dPre"]).max())
     # persistent scan on the same inputs
     H2 = torch.empty((n, H), device="cuda"); g2 = torch.empty((n, G * H), device="cuda"); a2 = torch.empty((n, H), device="cuda")
-    call("seqrec_rnn_pack_u", 2, H, ptr(Ud), ptr(up), st())
-    call("seqrec_rnn_fwd", 2, L.ACT[act], H, H, rb.T, rb.B, ptr(dev(rb.step_off)), ptr(XWd), ptr(H2), ptr(g2), ptr(a2), ptr(up), st())
+    call("seqrec_rnn_pack_u", ci, H, ptr(Ud), ptr(up), st())
+    call("seqrec_rnn_fwd", ci, L.ACT[act], H, H, rb.T, rb.B, ptr(dev(rb.step_off)), ptr(XWd), ptr(H2), ptr(g2), ptr(a2), ptr(up), st())
     assert np.abs(H2.cpu().numpy() - got).max() <= 2e-5 * scale
-    assert lib_rc("seqrec_rnn_fwd_stepwise", 1) == -3
-
-
-def lib_rc(name, cell):
-    lib = L.load()
-    return getattr(lib, name)(cell, 0, 64, 64, 1, 1, None, None, None, None, None, None, None)
-
-
-def test_multi_launch_forms_equal_single_forms():
-    rng = np.random.default_rng(12)
-    # dense
-    shapes = [(256, 768), (768,), (300, 5)]
-    g = [rng.normal(size=sh).astype(np.float32) * 0.01 for sh in shapes]
-    p = [rng.normal(size=sh).astype(np.float32) for sh in shapes]
-    a = [np.abs(rng.normal(size=sh)).astype(np.float32) for sh in shapes]
-    gd, pd_, ad = [dev(x) for x in g], [dev(x) for x in p], [dev(x) for x in a]
-    sq = torch.zeros(1, device="cuda"); scale = torch.empty(1, device="cuda")
-    nn = L.i64_array([x.numel() for x in gd])
-    call("seqrec_sqnorm_multi", 3, L.ptr_array(gd), nn, ptr(sq), st())
-    ref = sum((x.astype(np.float64) ** 2).sum() for x in g)
-    assert abs(sq.item() - ref) <= 1e-5 * ref
-    call("seqrec_clip_scale", ptr(sq), 0.05, ptr(scale), st())
-    sc = min(1.0, 0.05 / np.sqrt(ref))
-    call("seqrec_adagrad_dense_multi", 3, L.ptr_array(pd_), L.ptr_array(ad), L.ptr_array(gd), nn, 0.01, 1e-8, ptr(scale), st())
-    for i in range(3):
-        gv = g[i] * np.float32(sc)
-        ar = a[i] + gv * gv
-        np.testing.assert_allclose(ad[i].cpu().numpy(), ar, rtol=2e-6)
-        np.testing.assert_allclose(pd_[i].cpu().numpy(), p[i] - np.float32(0.01) * gv / (np.sqrt(ar) + np.float32(1e-8)), rtol=3e-6, atol=1e-7)
-    # rows: two tables, three lists, shared bases on the first table
-    V1, W1, V2, W2 = 500, 256, 300, 1
-    T1, A1 = rng.normal(size=(V1, W1)).astype(np.float32), np.abs(rng.normal(size=(V1, W1))).astype(np.float32)
-    T2, A2 = rng.normal(size=(V2, W2)).astype(np.float32), np.abs(rng.normal(size=(V2, W2))).astype(np.float32)
-    r1 = rng.integers(0, 40, 200).astype(np.int32); v1 = rng.normal(size=(200, W1)).astype(np.float32); s1 = rng.normal(size=200).astype(np.float32)
-    r2 = rng.integers(0, V1, 90).astype(np.int32); v2 = rng.normal(size=(90, W1)).astype(np.float32)
-    r3 = rng.integers(0, V2, 70).astype(np.int32); v3 = rng.normal(size=(70, 1)).astype(np.float32)
-    d = {k: dev(v) for k, v in dict(T1=T1, A1=A1, T2=T2, A2=A2, r1=r1, v1=v1, s1=s1, r2=r2, v2=v2, r3=r3, v3=v3).items()}
-    G1 = torch.zeros((V1, W1), device="cuda"); G2 = torch.zeros((V2, W2), device="cuda")
-    S1 = torch.full((V1,), 2 ** 31 - 1, dtype=torch.int32, device="cuda"); S2 = torch.full((V2,), 2 ** 31 - 1, dtype=torch.int32, device="cuda")
-    jobs = [dict(table=d["T1"], accum=d["A1"], gtab=G1, slot=S1, rows=d["r1"], vals=d["v1"], ldv=W1, row_scale=d["s1"], n=200, width=W1, base=0),
-            dict(table=d["T1"], accum=d["A1"], gtab=G1, slot=S1, rows=d["r2"], vals=d["v2"], ldv=W1, row_scale=None, n=90, width=W1, base=200),
-            dict(table=d["T2"], accum=d["A2"], gtab=G2, slot=S2, rows=d["r3"], vals=d["v3"], ldv=1, row_scale=None, n=70, width=1, base=0)]
-    arr, cnt = L.rows_jobs(jobs)
-    call("seqrec_rows_scatter_add_multi", arr, cnt, st())
-    g1 = np.zeros((V1, W1)); np.add.at(g1, r1, v1.astype(np.float64) * s1[:, None]); np.add.at(g1, r2, v2.astype(np.float64))
-    g2 = np.zeros((V2, 1)); np.add.at(g2, r3, v3.astype(np.float64))
-    np.testing.assert_allclose(G1.cpu().numpy(), g1, atol=2e-4)
-    sq.zero_()
-    call("seqrec_rows_sqnorm_multi", arr, cnt, ptr(sq), st())
-    tot = (g1 ** 2).sum() + (g2 ** 2).sum()
-    assert abs(sq.item() - tot) <= 1e-4 * tot
-    scale.fill_(0.5)
-    call("seqrec_rows_adagrad_multi", arr, cnt, 0.01, 1e-8, ptr(scale), st())
-    for (T, A, gg, Td, Ad) in ((T1, A1, g1, d["T1"], d["A1"]), (T2, A2, g2, d["T2"], d["A2"])):
-        gv = gg * 0.5
-        ar = A + gv * gv
-        np.testing.assert_allclose(Ad.cpu().numpy(), ar, rtol=3e-6, atol=1e-7)
-        np.testing.assert_allclose(Td.cpu().numpy(), T - 0.01 * gv / (np.sqrt(ar) + 1e-8), rtol=3e-6, atol=3e-7)
-    assert torch.all(G1 == 0) and torch.all(G2 == 0) and torch.all(S1 == 2 ** 31 - 1) and torch.all(S2 == 2 ** 31 - 1)

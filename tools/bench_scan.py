@@ -20,8 +20,7 @@ def main():
     up = torch.empty(int(L.load().seqrec_rnn_upack_floats(L.CELL[cell], H)), device="cuda")
     call("seqrec_rnn_pack_u", L.CELL[cell], H, ptr(U), ptr(up), st)
     up2 = torch.empty_like(up)
-    if cell == "gru":
-        call("seqrec_rnn_pack_u_stepwise", L.CELL[cell], H, ptr(U), ptr(up2), st)
+    call("seqrec_rnn_pack_u_stepwise", L.CELL[cell], H, ptr(U), ptr(up2), st)
     res = []
     for i in range(8):
         rb = Bt.pack_flat(flat, starts, np.arange(i * 512, (i + 1) * 512))
@@ -36,7 +35,7 @@ def main():
         soh = rb.step_off
         def f2(): call("seqrec_rnn_fwd_stepwise", L.CELL[cell], 0, H, H, rb.T, rb.B, soh.ctypes.data, ptr(XW), ptr(Hout), ptr(gates), ptr(aux), ptr(up2), st)
         def b2(): call("seqrec_rnn_bwd_stepwise", L.CELL[cell], 0, H, H, rb.T, rb.B, soh.ctypes.data, ptr(dH), ptr(Hout), ptr(gates), ptr(aux), ptr(dPre), ptr(up2), ptr(ws), st)
-        fns = (f, b) + ((f2, b2) if cell == "gru" else ())
+        fns = (f, b, f2, b2)
         out = []
         for fn in fns:
             fn(); torch.cuda.synchronize()
