@@ -96,15 +96,19 @@ int seqrec_rnn_bwd(int cell, int act, int H, int H_real, int T, int B, const int
  *      critical path when few long sessions dominate (MSNBC-shaped batches).  Needs the step offsets
  *      on the HOST (step_off_host, T+1 ints) to size the launches; same buffers and results.
  *      upack: seqrec_rnn_upack_floats() floats written by seqrec_rnn_pack_u_stepwise.
- *      bwd workspace: 2 * N_tok * H floats. */
+ *      bwd workspace: 2 * N_tok * H floats.
+ *      rmask (nullable): recurrent-dropout multipliers [G][B][H] for the SORTED session rows
+ *      (Keras recurrent_dropout, model.py:346,351: one mask per gate, fixed over time); with it the
+ *      GRU aux stash holds r*h_prev WITHOUT the mask. */
 int seqrec_rnn_pack_u_stepwise(int cell, int H, const float* U, float* upack, void* stream);
 int seqrec_rnn_fwd_stepwise(int cell, int act, int H, int H_real, int T, int B,
                             const int32_t* step_off_host, const float* XW, float* Hout,
-                            float* gates, float* aux, const float* upack, void* stream);
+                            float* gates, float* aux, const float* upack, const float* rmask,
+                            void* stream);
 int seqrec_rnn_bwd_stepwise(int cell, int act, int H, int H_real, int T, int B,
                             const int32_t* step_off_host, const float* dHout, const float* Hout,
                             const float* gates, const float* aux, float* dPre, const float* upack,
-                            float* workspace, void* stream);
+                            float* workspace, const float* rmask, void* stream);
 
 /* ---- softmax + Theano categorical_crossentropy under the Keras token-mean mask
  *      (model.py:175-177,257,397), fused with its gradient.

@@ -27,11 +27,12 @@ class RaggedBatch:
     prev       int32[N_tok]
     tok_b      int32[N_tok]   original batch index of the token's session
     tok_s      int32[N_tok]   step index t of the token
+    tok_row    int32[N_tok]   sorted session row b of the token (p = step_off[t] + b)
     n_sessions number of sessions the caller handed over (incl. empty ones) -- Keras
                weights epoch losses by this batch size.
     """
 
-    __slots__ = ("order", "lengths", "step_off", "ids", "tgt", "x", "prev", "tok_b", "tok_s",
+    __slots__ = ("order", "lengths", "step_off", "ids", "tgt", "x", "prev", "tok_b", "tok_s", "tok_row",
                  "n_sessions", "B", "T", "n_tok")
 
 
@@ -63,6 +64,7 @@ def _finish(rb, order, ls, step_off, tok_t, tok_bs, B, T, n_tok, n_sessions):
     rb.prev = prev.astype(np.int32)
     rb.tok_b = order[tok_bs].astype(np.int32)
     rb.tok_s = tok_t.astype(np.int32)
+    rb.tok_row = tok_bs.astype(np.int32)
     rb.B, rb.T, rb.n_tok, rb.n_sessions = B, T, n_tok, n_sessions
     return rb
 

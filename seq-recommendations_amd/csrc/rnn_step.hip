@@ -35,6 +35,8 @@ struct StepArgs {
     const float* XW; float* Hout; float* gates; float* aux;
     const float* pk;                          // packed B for this launch
     const float* dHout; float* dPre; float* dHc; float* tmpc;
+    const float* rmask;                       // recurrent-dropout multipliers [G][B][H] (sorted session rows) or null
+    int B;
 };
 
 // Workgroup = 16 session rows x 16 output columns; the 4 waves split K (wave w owns k-blocks
@@ -90,6 +92,9 @@ __device__ __forceinline__ float tile_16x16(const float* __restrict__ ab, float*
     __syncthreads();
     return (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
 }
+__device__ __forceinline__ float4 mask4(const float* __restrict__ rmask, int B, int H, int g, int srow, int c4) {
+    return reinterpret_cast<const float4*>(rmask + ((long)g * B + srow) * H)[c4];
+}
 
 // LSTM forward layout: out[((cb*4 + g)*(H/16) + i)*64 + lane] (float4), element e <-> kb = 4*i + e,
 //   value = U[(4*kb + (lane>>4)) * 4H + g*H + 16*cb + (lane&15)]
@@ -130,7 +135,10 @@ __global__ __launch_bounds__(256) void gru_step_fwd(StepArgs a) {
     if (PHASE == 1) {
         zg = bload(rG, vg, soG);
         h0 = bload(rH, a.first ? INVALID_OFF : vh, soP);
+    } else if (col >= H) {
+        h0 = bload(rH, (a.first || !ok) ? INVALID_OFF : (row * H + (col - H)) * 4, soP);   // h_prev for r * h_prev
     }
+    const int mg = PHASE == 1 ? 2 : (col >= H ? 1 : 0);      // gate whose recurrent-dropout mask applies to A
     float acc = 0.f;
     if (!a.first) {
         float4 b[H / 64];
@@ -144,7 +152,13 @@ __global__ __launch_bounds__(256) void gru_step_fwd(StepArgs a) {
             const int idx = tid + 256 * it;
             const int rr = idx / (H / 4), c4 = idx % (H / 4);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rr < nact) v = reinterpret_cast<const float4*>(src + (long)rr * H)[c4];
+            if (rr < nact) {
+                v = reinterpret_cast<const float4*>(src + (long)rr * H)[c4];
+                if (a.rmask) {
+                    const float4 m = mask4(a.rmask, a.B, H, mg, r0 + rr, c4);
+                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+                }
+            }
             float* d = ab + rr * LDA + 4 * c4;
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
@@ -154,11 +168,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd(StepArgs a) {
     if (PHASE == 0) {
         const float g = hard_sigmoid(acc + xw);
         bstore(rG, vg, soG, g);
-        if (col >= H) {                                       // reset gate: also publish r * h_prev
-            const int hc = col - H;
-            const float hp = a.first ? 0.f : ab[row * LDA + hc];
-            bstore(rA, ok ? (row * H + hc) * 4 : INVALID_OFF, soH, g * hp);
-        }
+        if (col >= H) bstore(rA, ok ? (row * H + (col - H)) * 4 : INVALID_OFF, soH, g * h0);   // publish r * h_prev
     } else {
         const float hh = act_fwd<ACT>(acc + xw);
         float hn = zg * h0 + (1.f - zg) * hh;
@@ -230,12 +240,18 @@ __global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a) {
         o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = d.w;
     }
     __syncthreads();
-    const float acc = tile_16x16<K>(ab, red, b, tid);
+    float acc = tile_16x16<K>(ab, red, b, tid);
+    const int srow = min(r0 + row, a.B - 1);
     if (PHASE == 0) {
+        if (a.rmask) acc *= a.rmask[((long)2 * a.B + srow) * H + col];          // d(r*h*m2) -> d(r*h)
         bstore(rDP, vg, soG, e_dh * (e_h0 - e_hh) * hard_sigmoid_grad(e_z));
         bstore(rDP, vg + H * 4, soG, acc * e_h0 * hard_sigmoid_grad(e_r));
         bstore(rT, vh, soH, e_dh * e_z + acc * e_r);
     } else {
+        if (a.rmask) {   // K = 2H is split over the waves as [z z r r]: the two halves carry different masks
+            acc = (red[tid] + red[256 + tid]) * a.rmask[((long)0 * a.B + srow) * H + col] +
+                  (red[512 + tid] + red[768 + tid]) * a.rmask[((long)1 * a.B + srow) * H + col];
+        }
         bstore(rC, vh, soP, e_t + acc);
     }
 }
@@ -246,10 +262,10 @@ __global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a) {
 // c and h.  packed: [cb][gate][K/16 float4 groups][lane]
 // SimpleRNN forward step: same tile with K split over the waves.
 // ---------------------------------------------------------------------------------------------
-template <int J, int ACT>
-__global__ __launch_bounds__(256) void lstm_step_fwd(StepArgs a) {
+template <int J, int ACT, bool RD>
+__device__ __forceinline__ void lstm_step_fwd_body(const StepArgs& a) {
     constexpr int H = 64 * J, LDA = H + 2, GH = 4 * H, G4 = H / 16;
-    __shared__ float ab[16 * LDA];
+    __shared__ float ab[(RD ? 4 : 1) * 16 * LDA];
     __shared__ float red[4 * 256];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r0 = blockIdx.x * 16, cb = blockIdx.y;
@@ -276,11 +292,21 @@ __global__ __launch_bounds__(256) void lstm_step_fwd(StepArgs a) {
             const int rr = idx / (H / 4), c4 = idx % (H / 4);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (rr < nact) v = reinterpret_cast<const float4*>(src + (long)rr * H)[c4];
-            float* d = ab + rr * LDA + 4 * c4;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            if (RD) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (rr < nact) m = mask4(a.rmask, a.B, H, g, r0 + rr, c4);
+                    float* d = ab + g * 16 * LDA + rr * LDA + 4 * c4;
+                    d[0] = v.x * m.x; d[1] = v.y * m.y; d[2] = v.z * m.z; d[3] = v.w * m.w;
+                }
+            } else {
+                float* d = ab + rr * LDA + 4 * c4;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
         }
         __syncthreads();
-        const float* ap = ab + (lane & 15) * LDA + (lane >> 4);
+        const float* ap = ab + (RD ? w * 16 * LDA : 0) + (lane & 15) * LDA + (lane >> 4);
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < G4; ++i) {
@@ -309,6 +335,8 @@ __global__ __launch_bounds__(256) void lstm_step_fwd(StepArgs a) {
     bstore(rG, vg + 3 * H * 4, soG, go);
 }
 
+template <int J, int ACT> __global__ __launch_bounds__(256) void lstm_step_fwd_nd(StepArgs a) { lstm_step_fwd_body<J, ACT, false>(a); }
+template <int J, int ACT> __global__ __launch_bounds__(256) void lstm_step_fwd_rd(StepArgs a) { lstm_step_fwd_body<J, ACT, true>(a); }
 template <int J, int ACT>
 __global__ __launch_bounds__(256) void srnn_step_fwd(StepArgs a) {
     constexpr int H = 64 * J, LDA = H + 2;
@@ -335,7 +363,13 @@ __global__ __launch_bounds__(256) void srnn_step_fwd(StepArgs a) {
             const int idx = tid + 256 * it;
             const int rr = idx / (H / 4), c4 = idx % (H / 4);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rr < nact) v = reinterpret_cast<const float4*>(src + (long)rr * H)[c4];
+            if (rr < nact) {
+                v = reinterpret_cast<const float4*>(src + (long)rr * H)[c4];
+                if (a.rmask) {
+                    const float4 m = mask4(a.rmask, a.B, H, 0, r0 + rr, c4);
+                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+                }
+            }
             float* d = ab + rr * LDA + 4 * c4;
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
@@ -404,7 +438,17 @@ __global__ __launch_bounds__(256) void gemm_bwd_step(StepArgs a, int H, int ldp)
         o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = d.w;
     }
     __syncthreads();
-    const float acc = tile_16x16<K>(ab, red, b, tid);
+    float acc = tile_16x16<K>(ab, red, b, tid);
+    if (a.rmask) {
+        const int srow = min(r0 + row, a.B - 1);
+        if (K == H) {
+            acc *= a.rmask[(long)srow * H + col];
+        } else {      // LSTM: K = 4H split over the waves = gate blocks i,f,c,o, each with its own mask
+            acc = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc += red[g * 256 + tid] * a.rmask[((long)g * a.B + srow) * H + col];
+        }
+    }
     const rsrc_t rC = mk_rsrc(a.dHc);
     bstore(rC, ok ? (row * H + col) * 4 : INVALID_OFF, (a.pprev0 + r0) * H * 4, acc);
 }
@@ -527,7 +571,8 @@ extern "C" int seqrec_rnn_pack_u_stepwise(int cell, int H, const float* U, float
 
 extern "C" int seqrec_rnn_fwd_stepwise(int cell, int act, int H, int H_real, int T, int B,
                                        const int32_t* step_off_host, const float* XW, float* Hout,
-                                       float* gates, float* aux, const float* upack, void* stream) {
+                                       float* gates, float* aux, const float* upack, const float* rmask,
+                                       void* stream) {
     if (!ok_shape(cell, act, H, H_real, T, B)) return SEQREC_E_SHAPE;
     if (T == 0 || B == 0) return 0;
     if (!step_off_host || !XW || !Hout || !upack) return SEQREC_E_ARG;
@@ -537,6 +582,7 @@ extern "C" int seqrec_rnn_fwd_stepwise(int cell, int act, int H, int H_real, int
     const long HH = (long)H * H;
     StepArgs a = {};
     a.H = H; a.H_real = H_real; a.XW = XW; a.Hout = Hout; a.gates = gates; a.aux = aux;
+    a.rmask = rmask; a.B = B;
     for (int t = 0; t < T; ++t) {
         a.p0 = step_off_host[t]; a.bt = step_off_host[t + 1] - a.p0;
         a.pprev0 = t > 0 ? step_off_host[t - 1] : 0;
@@ -549,7 +595,8 @@ extern "C" int seqrec_rnn_fwd_stepwise(int cell, int act, int H, int H_real, int
             a.pk = upack + 2 * HH;
             STEP_DISPATCH(gru_step_fwd, 1, dim3(rb, H / 16));
         } else if (cell == SEQREC_CELL_LSTM) {
-            CELL_DISPATCH(lstm_step_fwd, dim3(rb, H / 16));
+            if (rmask) { CELL_DISPATCH(lstm_step_fwd_rd, dim3(rb, H / 16)); }
+            else { CELL_DISPATCH(lstm_step_fwd_nd, dim3(rb, H / 16)); }
         } else {
             CELL_DISPATCH(srnn_step_fwd, dim3(rb, H / 16));
         }
@@ -561,7 +608,7 @@ extern "C" int seqrec_rnn_fwd_stepwise(int cell, int act, int H, int H_real, int
 extern "C" int seqrec_rnn_bwd_stepwise(int cell, int act, int H, int H_real, int T, int B,
                                        const int32_t* step_off_host, const float* dHout, const float* Hout,
                                        const float* gates, const float* aux, float* dPre, const float* upack,
-                                       float* workspace, void* stream) {
+                                       float* workspace, const float* rmask, void* stream) {
     if (!ok_shape(cell, act, H, H_real, T, B)) return SEQREC_E_SHAPE;
     if (T == 0 || B == 0) return 0;
     if (!step_off_host || !dHout || !Hout || !dPre || !upack || !workspace) return SEQREC_E_ARG;
@@ -574,6 +621,7 @@ extern "C" int seqrec_rnn_bwd_stepwise(int cell, int act, int H, int H_real, int
     a.H = H; a.H_real = H_real; a.Hout = const_cast<float*>(Hout); a.gates = const_cast<float*>(gates);
     a.aux = const_cast<float*>(aux); a.dHout = dHout; a.dPre = dPre;
     a.dHc = workspace; a.tmpc = workspace + ntok * H;
+    a.rmask = rmask; a.B = B;
     for (int t = T - 1; t >= 0; --t) {
         a.p0 = step_off_host[t]; a.bt = step_off_host[t + 1] - a.p0;
         if (a.bt <= 0) continue;

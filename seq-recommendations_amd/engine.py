@@ -113,8 +113,6 @@ class Engine:
         c = cfg
         if c.cell not in CELL or c.act not in ACT:
             raise ValueError("unsupported cell/activation %r/%r" % (c.cell, c.act))
-        if c.drop_rec > 0:
-            raise NotImplementedError("recurrent (z_to_z) dropout is not implemented in the HIP scan yet")
         self.Hp = _pad_h(c.H)
         self.G = c.G
         self.GHp = self.G * self.Hp
@@ -168,7 +166,9 @@ class Engine:
         self.loss_sum = z(1)
         self.upack = torch.empty(int(_lib.load().seqrec_rnn_upack_floats(CELL[c.cell], self.Hp)), **f32)
         self.upack_dirty = True
-        self.stepwise = (c.scan == "stepwise") or (c.scan == "auto" and self.Hp >= 128)
+        self.stepwise = (c.scan == "stepwise") or (c.scan == "auto" and (self.Hp >= 128 or c.drop_rec > 0))
+        if c.drop_rec > 0 and not self.stepwise:
+            raise NotImplementedError("recurrent (z_to_z) dropout needs scan='stepwise' (or 'auto')")
         import os
         self.use_side = os.environ.get("SEQREC_SIDE_STREAM", "0") != "0"   # measured: overlap slows the scan more than it hides
         self.side = torch.cuda.Stream(device=self.dev)     # independent work beside the scan (dEneg GEMM)
@@ -315,6 +315,8 @@ class Engine:
         out = {}
         if c.drop_in > 0 or c.drop_out > 0:
             key = (rb.tok_b.astype(np.int64) << 16) + rb.tok_s.astype(np.int64)
+        if n == 0:
+            return out
         if c.drop_in > 0:
             sid = _lib.STREAM_DROP_IN + 16 * (step + 1)
             if c.input == "onehot":
@@ -330,6 +332,18 @@ class Engine:
                 call("seqrec_dropout_mask", c.seed, sid, ptr(rk), n, w, ld, float(c.drop_in), ptr(m), st)
             out["in"] = m
             out["_rk_in"] = rk
+        if c.drop_rec > 0:
+            # Keras recurrent_dropout: one mask per gate and session, reused at every step.
+            # row key = gate * 2^20 + ORIGINAL batch index of the session
+            sid = _lib.STREAM_DROP_REC + 16 * (step + 1)
+            G, B = self.G, d["B"]
+            rk = (np.arange(G, dtype=np.int64)[:, None] * (1 << 20) + rb.order.astype(np.int64)[None, :]).reshape(-1)
+            rkd = torch.from_numpy(rk).to(self.dev)
+            m = self.buf("rec_mask", G * B, self.Hp)
+            m.zero_()
+            call("seqrec_dropout_mask", c.seed, sid, ptr(rkd), G * B, c.H, self.Hp, float(c.drop_rec), ptr(m), st)
+            out["rec"] = m
+            out["_rk_rec"] = rkd
         if c.drop_out > 0:
             sid = _lib.STREAM_DROP_OUT + 16 * (step + 1)
             rk = torch.from_numpy(key).to(self.dev)
@@ -346,7 +360,7 @@ class Engine:
                     ldv=ldv, row_scale=row_scale, n=n, width=width, base=base, name=name)
 
     # ------------------------------------------------------------------ recurrent scan
-    def _scan_fwd(self, d, XW, Hout, gates, aux):
+    def _scan_fwd(self, d, XW, Hout, gates, aux, rmask=None):
         c, st = self.cfg, self._stream()
         Hp = self.Hp
         if self.upack_dirty:
@@ -356,19 +370,19 @@ class Engine:
         if self.stepwise:
             so = d["rb"].step_off
             call("seqrec_rnn_fwd_stepwise", CELL[c.cell], ACT[c.act], Hp, c.H, d["T"], d["B"], so.ctypes.data, ptr(XW), ptr(Hout),
-                 ptr(gates), ptr(aux), ptr(self.upack), st)
+                 ptr(gates), ptr(aux), ptr(self.upack), ptr(rmask), st)
         else:
             call("seqrec_rnn_fwd", CELL[c.cell], ACT[c.act], Hp, c.H, d["T"], d["B"], ptr(d["step_off"]), ptr(XW),
                  ptr(Hout), ptr(gates), ptr(aux), ptr(self.upack), st)
 
-    def _scan_bwd(self, d, dHout, Hout, gates, aux, dPre):
+    def _scan_bwd(self, d, dHout, Hout, gates, aux, dPre, rmask=None):
         c, st = self.cfg, self._stream()
         Hp = self.Hp
         if self.stepwise:
             so = d["rb"].step_off
             wsp = self.buf("scan_ws", 2 * d["n"] * Hp)
             call("seqrec_rnn_bwd_stepwise", CELL[c.cell], ACT[c.act], Hp, c.H, d["T"], d["B"], so.ctypes.data, ptr(dHout),
-                 ptr(Hout), ptr(gates), ptr(aux), ptr(dPre), ptr(self.upack), ptr(wsp), st)
+                 ptr(Hout), ptr(gates), ptr(aux), ptr(dPre), ptr(self.upack), ptr(wsp), ptr(rmask), st)
         else:
             call("seqrec_rnn_bwd", CELL[c.cell], ACT[c.act], Hp, c.H, d["T"], d["B"], ptr(d["step_off"]), ptr(dHout), ptr(Hout),
                  ptr(gates), ptr(aux), ptr(dPre), ptr(self.upack), st)
@@ -408,7 +422,7 @@ class Engine:
         Hout = self.buf("Hout", n, Hp)
         gates = self.buf("gates", n, GHp)
         aux = self.buf("aux", n, Hp)
-        self._scan_fwd(d, XW, Hout, gates, aux)
+        self._scan_fwd(d, XW, Hout, gates, aux, drops.get("rec"))
         r.update(XW=XW, Hout=Hout, gates=gates, aux=aux)
         Hd = Hout
         if "out" in drops:
@@ -511,14 +525,27 @@ class Engine:
         if "out" in drops:
             call("seqrec_mul", ptr(dHd), ptr(drops["out"]), ptr(dHd), n * Hp, st)
         dPre = self.buf("dPre", n, GHp)
-        self._scan_bwd(d, dHout, r["Hout"], r["gates"], r["aux"], dPre)
+        self._scan_bwd(d, dHout, r["Hout"], r["gates"], r["aux"], dPre, drops.get("rec"))
         if c.use_bias and tr["b"]:
             call("seqrec_colsum", ptr(dPre), n, GHp, GHp, ptr(Gd["b"]), 0, ptr(cs_ws), st)
         if tr["U"]:
             Hprev = self.buf("Hprev", n, Hp)
             call("seqrec_gather_rows", ptr(r["Hout"]), ptr(d["prev"]), ptr(Hprev), n, Hp, None, None, 0, st)
             sk = self._splitk(Hp, GHp, n)
-            if c.cell == "gru":
+            if "rec" in drops:
+                # dU_g = (A_g * m_g)^T . dPre_g with the gate's time-invariant mask expanded to tokens
+                B_ = d["B"]
+                rowidx = self.buf("tok_row", n, dtype=torch.int32)
+                rowidx.copy_(torch.from_numpy(d["rb"].tok_row).to(self.dev))
+                mt = self.buf("mask_tok", n, Hp)
+                Am = self.buf("A_masked", n, Hp)
+                for g in range(self.G):
+                    call("seqrec_gather_rows", ptr(drops["rec"][g * B_:(g + 1) * B_]), ptr(rowidx), ptr(mt), n, Hp, None, None, 0, st)
+                    src = r["aux"] if (c.cell == "gru" and g == 2) else Hprev
+                    call("seqrec_mul", ptr(src), ptr(mt), ptr(Am), n * Hp, st)
+                    self.gemm(0, 0, Hp, Hp, n, Am, Hp, dPre[:, g * Hp:], GHp, Gd["U"][:, g * Hp:], GHp,
+                              splitk=self._splitk(Hp, Hp, n), tag="dU")
+            elif c.cell == "gru":
                 self.gemm(0, 0, Hp, 2 * Hp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp, splitk=sk, tag="dU")
                 self.gemm(0, 0, Hp, Hp, n, r["aux"], Hp, dPre[:, 2 * Hp:], GHp, Gd["U"][:, 2 * Hp:], GHp, splitk=sk, tag="dU")
             else:

@@ -5,8 +5,9 @@ reference, so its callers (experiments_methods.py, the L5 scripts) work unchange
 
   RNNBaseline(timesteps, features, n_classes, ...)                     model.py:241-258
   RNNFullModel(timesteps, x_dim, y_dim, z_dim, ..., y_to_z=True, ...)   model.py:322-403
-      -- the "ytoz" wiring (y_to_z only) is the hot path; the x_to_y / y_to_y / x_to_z side
-         branches raise NotImplementedError
+      -- the "ytoz" wiring (y_to_z only) is the hot path, with all three dropouts (y_to_z,
+         z_to_z = Keras recurrent_dropout, z_to_y); the x_to_y / y_to_y / x_to_z side branches
+         raise NotImplementedError
   BaseRNNModel.compile_model / fit_model / fit_generator / predict / evaluate /
       save_model_weights / load_model_weights / get_layer_weights / set_layer_weights_trainable /
       set_layer_weights / get_model_weights / get_activations              model.py:170-238

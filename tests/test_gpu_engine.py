@@ -21,6 +21,14 @@ CASES = [
     dict(cell="lstm", act="relu", H=128, V=2000, inp="embed", out="sampled", D=64, K=100, drop_out=0.25, drop_in=0.1),
     dict(cell="gru", act="tanh", H=64, V=1500, inp="embed", out="sampled", D=64, K=64, tied=True),
     dict(cell="simplernn", act="tanh", H=64, V=400, inp="embed", out="full", D=32),
+    # recurrent (z_to_z) dropout: per-gate, per-session masks fixed over time (Keras recurrent_dropout)
+    dict(cell="lstm", act="relu", H=64, V=17, inp="onehot", out="full", drop_rec=0.25),
+    dict(cell="lstm", act="tanh", H=100, V=33, inp="onehot", out="full", drop_rec=0.2, drop_out=0.3, drop_in=0.1),
+    dict(cell="gru", act="relu", H=128, V=2000, inp="embed", out="sampled", D=64, K=100, drop_rec=0.3),
+    dict(cell="simplernn", act="relu", H=64, V=17, inp="onehot", out="full", drop_rec=0.4),
+    # the persistent scan stays selectable
+    dict(cell="gru", act="relu", H=256, V=800, inp="embed", out="sampled", D=64, K=64, scan="persistent"),
+    dict(cell="lstm", act="relu", H=128, V=17, inp="onehot", out="full", scan="persistent"),
 ]
 
 

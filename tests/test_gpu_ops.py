@@ -386,14 +386,14 @@ def test_stepwise_scan_vs_oracle_and_persistent(cell, H, B, maxlen, act):
     call("seqrec_rnn_pack_u_stepwise", ci, H, ptr(Ud), ptr(up), st())
     so = rb.step_off
     call("seqrec_rnn_fwd_stepwise", ci, L.ACT[act], H, H, rb.T, rb.B, so.ctypes.data, ptr(XWd), ptr(Hout), ptr(gates), ptr(aux),
-         ptr(up), st())
+         ptr(up), None, st())
     got = Hout.cpu().numpy()
     scale = max(1.0, np.abs(ref["H"]).max())
     assert np.abs(got - ref["H"]).max() <= 3e-5 * scale
     dPre = torch.full((n, G * H), float("nan"), device="cuda")
     ws = torch.full((2 * n * H,), float("nan"), device="cuda")
     call("seqrec_rnn_bwd_stepwise", ci, L.ACT[act], H, H, rb.T, rb.B, so.ctypes.data, ptr(dev(dH)), ptr(Hout), ptr(gates), ptr(aux),
-         ptr(dPre), ptr(up), ptr(ws), st())
+         ptr(dPre), ptr(up), ptr(ws), None, st())
     gp = dPre.cpu().numpy()
     s2 = max(1.0, np.abs(ref["dPre"]).max())
     bad = np.abs(gp - ref["dPre"]) > 1e-4 * s2

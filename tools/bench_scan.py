@@ -33,8 +33,8 @@ def main():
         def b(): call("seqrec_rnn_bwd", L.CELL[cell], 0, H, H, rb.T, rb.B, ptr(so), ptr(dH), ptr(Hout), ptr(gates), ptr(aux), ptr(dPre), ptr(up), st)
         ws = torch.empty(2 * n * H, device="cuda")
         soh = rb.step_off
-        def f2(): call("seqrec_rnn_fwd_stepwise", L.CELL[cell], 0, H, H, rb.T, rb.B, soh.ctypes.data, ptr(XW), ptr(Hout), ptr(gates), ptr(aux), ptr(up2), st)
-        def b2(): call("seqrec_rnn_bwd_stepwise", L.CELL[cell], 0, H, H, rb.T, rb.B, soh.ctypes.data, ptr(dH), ptr(Hout), ptr(gates), ptr(aux), ptr(dPre), ptr(up2), ptr(ws), st)
+        def f2(): call("seqrec_rnn_fwd_stepwise", L.CELL[cell], 0, H, H, rb.T, rb.B, soh.ctypes.data, ptr(XW), ptr(Hout), ptr(gates), ptr(aux), ptr(up2), None, st)
+        def b2(): call("seqrec_rnn_bwd_stepwise", L.CELL[cell], 0, H, H, rb.T, rb.B, soh.ctypes.data, ptr(dH), ptr(Hout), ptr(gates), ptr(aux), ptr(dPre), ptr(up2), ptr(ws), None, st)
         fns = (f, b, f2, b2)
         out = []
         for fn in fns:
