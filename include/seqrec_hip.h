@@ -93,8 +93,7 @@ int seqrec_rnn_bwd(int cell, int act, int H, int H_real, int T, int B, const int
 /*      Step-wise form of the same scan (rnn_step.hip): one small whole-chip launch per recurrent
  *      GEMM (GRU: 2 per step; LSTM/SimpleRNN: 1 forward, pointwise + GEMM backward) instead of one
  *      persistent workgroup per 16 sessions -- shorter
- *      critical path when few long sessions dominate (MSNBC-shaped batches).  Needs the step offsets
- *      on the HOST (step_off_host, T+1 ints) to size the launches; same buffers and results.
+ *      critical path when few long sessions dominate (MSNBC-shaped batches); same buffers and results.
  *      upack: seqrec_rnn_upack_floats() floats written by seqrec_rnn_pack_u_stepwise.
  *      bwd workspace: 2 * N_tok * H floats.
  *      rmask (nullable): recurrent-dropout multipliers [G][B][H] for the SORTED session rows
@@ -102,13 +101,21 @@ int seqrec_rnn_bwd(int cell, int act, int H, int H_real, int T, int B, const int
  *      GRU aux stash holds r*h_prev WITHOUT the mask. */
 int seqrec_rnn_pack_u_stepwise(int cell, int H, const float* U, float* upack, void* stream);
 int seqrec_rnn_fwd_stepwise(int cell, int act, int H, int H_real, int T, int B,
-                            const int32_t* step_off_host, const float* XW, float* Hout,
-                            float* gates, float* aux, const float* upack, const float* rmask,
-                            void* stream);
+                            const int32_t* step_off, const int32_t* step_off_host, const float* XW,
+                            float* Hout, float* gates, float* aux, const float* upack,
+                            const float* rmask, int use_graph, void* stream);
 int seqrec_rnn_bwd_stepwise(int cell, int act, int H, int H_real, int T, int B,
-                            const int32_t* step_off_host, const float* dHout, const float* Hout,
-                            const float* gates, const float* aux, float* dPre, const float* upack,
-                            float* workspace, const float* rmask, void* stream);
+                            const int32_t* step_off, const int32_t* step_off_host, int64_t n_tok,
+                            const float* dHout, const float* Hout, const float* gates, const float* aux,
+                            float* dPre, const float* upack, float* workspace, const float* rmask,
+                            int use_graph, void* stream);
+/*      step_off: DEVICE int32[T+1] (the kernels read every per-step size from it);
+ *      step_off_host (nullable): the same on the host, used only to size eager launches exactly;
+ *      use_graph != 0: the launch sequence is captured ONCE per distinct argument tuple into a
+ *      hipGraph (process-wide cache, <= 256 entries) and replayed -- callers must then pass stable
+ *      pointers (copy each batch's step table into one fixed device buffer).  This cache is the only
+ *      hidden state of the library; seqrec_graph_cache_clear() drops it. */
+int seqrec_graph_cache_clear(void);
 
 /* ---- softmax + Theano categorical_crossentropy under the Keras token-mean mask
  *      (model.py:175-177,257,397), fused with its gradient.

@@ -32,12 +32,26 @@ __device__ __forceinline__ void bstore(rsrc_t r, int voff, int soff, float v) {
 struct StepArgs {
     int H, H_real;
     int p0, pprev0, bt, bnext, first;        // token offset of this step / previous step, rows, rows of step t+1
+    const int* step_off;                      // DEVICE step offsets: the per-step values above are read from it
+    int t, T;                                 //   (kernel-side) so that a captured launch graph is batch-independent
     const float* XW; float* Hout; float* gates; float* aux;
     const float* pk;                          // packed B for this launch
     const float* dHout; float* dPre; float* dHc; float* tmpc;
     const float* rmask;                       // recurrent-dropout multipliers [G][B][H] (sorted session rows) or null
     int B;
 };
+
+// per-step geometry from the device-resident step offsets (uniform scalar loads)
+__device__ __forceinline__ StepArgs resolve(StepArgs a) {
+    if (!a.step_off) return a;               // eager launches carry the host-resolved values
+    const int* so = a.step_off;
+    a.p0 = so[a.t];
+    a.bt = so[a.t + 1] - a.p0;
+    a.pprev0 = a.t > 0 ? so[a.t - 1] : 0;
+    a.bnext = a.t + 1 < a.T ? so[a.t + 2] - so[a.t + 1] : 0;
+    a.first = a.t == 0;
+    return a;
+}
 
 // Workgroup = 16 session rows x 16 output columns; the 4 waves split K (wave w owns k-blocks
 // [w*K/16, (w+1)*K/16)), partial 16x16 tiles are summed through LDS and every thread finishes ONE
@@ -114,7 +128,9 @@ __global__ void pack_lstm_fwd_kernel(const float* __restrict__ U, int H, float* 
 }
 
 template <int J, int ACT, int PHASE>
-__global__ __launch_bounds__(256) void gru_step_fwd(StepArgs a) {
+__global__ __launch_bounds__(256) void gru_step_fwd(StepArgs a_in) {
+    const StepArgs a = resolve(a_in);
+    if ((int)blockIdx.x * 16 >= a.bt) return;
     // PHASE 0: [z|r] = hs(xw + h_prev.U_zr), r*h_prev        grid (rows/16, 2H/16)
     // PHASE 1: h~ = act(xw_h + (r*h_prev).U_h), h = z h_prev + (1-z) h~   grid (rows/16, H/16)
     constexpr int H = 64 * J, LDA = H + 2, GH = 3 * H;
@@ -179,7 +195,9 @@ __global__ __launch_bounds__(256) void gru_step_fwd(StepArgs a) {
 }
 
 template <int J, int ACT, int PHASE>
-__global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a) {
+__global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a_in) {
+    const StepArgs a = resolve(a_in);
+    if ((int)blockIdx.x * 16 >= a.bt) return;
     // PHASE 0 (grid rows/16 x H/16): d = dh (1-z) act'(h~) for the whole row -> LDS; drh = d . U_h^T (own cols);
     //          dpre_z, dpre_r, dpre_h -> dPre;  dcar = dh z + drh r -> tmpc
     // PHASE 1 (grid rows/16 x H/16, skipped at t = 0): dh_prev = tmpc + [dpre_z|dpre_r] . U_zr^T -> dHc[prev token]
@@ -263,7 +281,9 @@ __global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a) {
 // SimpleRNN forward step: same tile with K split over the waves.
 // ---------------------------------------------------------------------------------------------
 template <int J, int ACT, bool RD>
-__device__ __forceinline__ void lstm_step_fwd_body(const StepArgs& a) {
+__device__ __forceinline__ void lstm_step_fwd_body(const StepArgs& a_in) {
+    const StepArgs a = resolve(a_in);
+    if ((int)blockIdx.x * 16 >= a.bt) return;
     constexpr int H = 64 * J, LDA = H + 2, GH = 4 * H, G4 = H / 16;
     __shared__ float ab[(RD ? 4 : 1) * 16 * LDA];
     __shared__ float red[4 * 256];
@@ -338,7 +358,9 @@ __device__ __forceinline__ void lstm_step_fwd_body(const StepArgs& a) {
 template <int J, int ACT> __global__ __launch_bounds__(256) void lstm_step_fwd_nd(StepArgs a) { lstm_step_fwd_body<J, ACT, false>(a); }
 template <int J, int ACT> __global__ __launch_bounds__(256) void lstm_step_fwd_rd(StepArgs a) { lstm_step_fwd_body<J, ACT, true>(a); }
 template <int J, int ACT>
-__global__ __launch_bounds__(256) void srnn_step_fwd(StepArgs a) {
+__global__ __launch_bounds__(256) void srnn_step_fwd(StepArgs a_in) {
+    const StepArgs a = resolve(a_in);
+    if ((int)blockIdx.x * 16 >= a.bt) return;
     constexpr int H = 64 * J, LDA = H + 2;
     __shared__ float ab[16 * LDA];
     __shared__ float red[4 * 256];
@@ -384,7 +406,8 @@ __global__ __launch_bounds__(256) void srnn_step_fwd(StepArgs a) {
 // pointwise part of one backward step: dPre[p] from dh (= dHout + carried dh), the stash and, for the
 // LSTM, the carried dc (dCc).  One thread per (row, hidden col).  grid = ceil(bt*H / 256)
 template <int CELL, int ACT>
-__global__ void pointwise_bwd_step(StepArgs a) {
+__global__ void pointwise_bwd_step(StepArgs a_in) {
+    const StepArgs a = resolve(a_in);
     const int H = a.H;
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (long)a.bt * H) return;
@@ -414,7 +437,9 @@ __global__ void pointwise_bwd_step(StepArgs a) {
 
 // dHc[prev token][own 16 cols] = dPre[p][0:K] . packed(U^T)      (K = G*H), skipped at t = 0
 template <int K>
-__global__ __launch_bounds__(256) void gemm_bwd_step(StepArgs a, int H, int ldp) {
+__global__ __launch_bounds__(256) void gemm_bwd_step(StepArgs a_in, int H, int ldp) {
+    const StepArgs a = resolve(a_in);
+    if ((int)blockIdx.x * 16 >= a.bt) return;
     constexpr int LDA = K + 2;
     __shared__ float ab[16 * LDA];
     __shared__ float red[4 * 256];
@@ -569,83 +594,161 @@ extern "C" int seqrec_rnn_pack_u_stepwise(int cell, int H, const float* U, float
     return 0;
 }
 
-extern "C" int seqrec_rnn_fwd_stepwise(int cell, int act, int H, int H_real, int T, int B,
-                                       const int32_t* step_off_host, const float* XW, float* Hout,
-                                       float* gates, float* aux, const float* upack, const float* rmask,
-                                       void* stream) {
-    if (!ok_shape(cell, act, H, H_real, T, B)) return SEQREC_E_SHAPE;
-    if (T == 0 || B == 0) return 0;
-    if (!step_off_host || !XW || !Hout || !upack) return SEQREC_E_ARG;
-    if (cell != SEQREC_CELL_SIMPLERNN && (!gates || !aux)) return SEQREC_E_ARG;
-    hipStream_t st = as_stream(stream);
-    const int J = H / 64;
-    const long HH = (long)H * H;
-    StepArgs a = {};
-    a.H = H; a.H_real = H_real; a.XW = XW; a.Hout = Hout; a.gates = gates; a.aux = aux;
-    a.rmask = rmask; a.B = B;
-    for (int t = 0; t < T; ++t) {
-        a.p0 = step_off_host[t]; a.bt = step_off_host[t + 1] - a.p0;
-        a.pprev0 = t > 0 ? step_off_host[t - 1] : 0;
-        a.first = t == 0;
-        if (a.bt <= 0) break;
-        const unsigned rb = (unsigned)((a.bt + 15) / 16);
-        a.pk = upack;
-        if (cell == SEQREC_CELL_GRU) {
-            STEP_DISPATCH(gru_step_fwd, 0, dim3(rb, 2 * H / 16));
-            a.pk = upack + 2 * HH;
-            STEP_DISPATCH(gru_step_fwd, 1, dim3(rb, H / 16));
-        } else if (cell == SEQREC_CELL_LSTM) {
-            if (rmask) { CELL_DISPATCH(lstm_step_fwd_rd, dim3(rb, H / 16)); }
-            else { CELL_DISPATCH(lstm_step_fwd_nd, dim3(rb, H / 16)); }
-        } else {
-            CELL_DISPATCH(srnn_step_fwd, dim3(rb, H / 16));
+// ---- launch-graph cache: one instantiated hipGraph per distinct argument tuple (the kernels read all
+// batch-dependent geometry from the device step table, so a graph only depends on T, B and pointers)
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+namespace {
+typedef std::vector<unsigned long long> GraphKey;
+std::map<GraphKey, hipGraphExec_t> g_graphs;
+std::mutex g_graph_mu;
+
+hipStream_t g_capture_stream = nullptr;       // capture never runs on the caller's stream (it may be the null stream)
+
+template <typename F> int run_maybe_graph(bool use_graph, const GraphKey& key, hipStream_t st, F&& enqueue) {
+    if (!use_graph) return enqueue(st);
+    std::lock_guard<std::mutex> lk(g_graph_mu);
+    auto it = g_graphs.find(key);
+    if (it == g_graphs.end()) {
+        hipError_t e;
+        if (!g_capture_stream) {
+            e = hipStreamCreateWithFlags(&g_capture_stream, hipStreamNonBlocking);
+            if (e != hipSuccess) return (int)e;
         }
+        hipGraph_t graph;
+        e = hipStreamBeginCapture(g_capture_stream, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) return (int)e;
+        const int rc = enqueue(g_capture_stream);
+        e = hipStreamEndCapture(g_capture_stream, &graph);
+        if (rc) { if (e == hipSuccess) hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess) return (int)e;
+        hipGraphExec_t exec;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (e != hipSuccess) return (int)e;
+        if (g_graphs.size() >= 256) {                      // bounded: drop everything, rebuild on demand
+            for (auto& kv : g_graphs) hipGraphExecDestroy(kv.second);
+            g_graphs.clear();
+        }
+        it = g_graphs.emplace(key, exec).first;
     }
+    const hipError_t e = hipGraphLaunch(it->second, st);
+    return e == hipSuccess ? 0 : (int)e;
+}
+unsigned long long pk_(const void* p) { return (unsigned long long)reinterpret_cast<uintptr_t>(p); }
+}  // namespace
+
+extern "C" int seqrec_graph_cache_clear(void) {
+    std::lock_guard<std::mutex> lk(g_graph_mu);
+    for (auto& kv : g_graphs) hipGraphExecDestroy(kv.second);
+    g_graphs.clear();
     return 0;
 }
 
-// workspace: 2 * N_tok * H floats (carried dh per token, dcar per token)
-extern "C" int seqrec_rnn_bwd_stepwise(int cell, int act, int H, int H_real, int T, int B,
-                                       const int32_t* step_off_host, const float* dHout, const float* Hout,
-                                       const float* gates, const float* aux, float* dPre, const float* upack,
-                                       float* workspace, const float* rmask, void* stream) {
+extern "C" int seqrec_rnn_fwd_stepwise(int cell, int act, int H, int H_real, int T, int B,
+                                       const int32_t* step_off, const int32_t* step_off_host, const float* XW,
+                                       float* Hout, float* gates, float* aux, const float* upack,
+                                       const float* rmask, int use_graph, void* stream) {
     if (!ok_shape(cell, act, H, H_real, T, B)) return SEQREC_E_SHAPE;
     if (T == 0 || B == 0) return 0;
-    if (!step_off_host || !dHout || !Hout || !dPre || !upack || !workspace) return SEQREC_E_ARG;
+    if (!step_off || !XW || !Hout || !upack) return SEQREC_E_ARG;
     if (cell != SEQREC_CELL_SIMPLERNN && (!gates || !aux)) return SEQREC_E_ARG;
     hipStream_t st = as_stream(stream);
     const int J = H / 64;
     const long HH = (long)H * H;
-    const long ntok = step_off_host[T];
-    StepArgs a = {};
-    a.H = H; a.H_real = H_real; a.Hout = const_cast<float*>(Hout); a.gates = const_cast<float*>(gates);
-    a.aux = const_cast<float*>(aux); a.dHout = dHout; a.dPre = dPre;
-    a.dHc = workspace; a.tmpc = workspace + ntok * H;
-    a.rmask = rmask; a.B = B;
-    for (int t = T - 1; t >= 0; --t) {
-        a.p0 = step_off_host[t]; a.bt = step_off_host[t + 1] - a.p0;
-        if (a.bt <= 0) continue;
-        a.bnext = t + 1 < T ? step_off_host[t + 2] - step_off_host[t + 1] : 0;
-        a.pprev0 = t > 0 ? step_off_host[t - 1] : 0;
-        a.first = t == 0;
-        const unsigned rb = (unsigned)((a.bt + 15) / 16);
-        if (cell == SEQREC_CELL_GRU) {
-            a.pk = upack + 3 * HH;
-            STEP_DISPATCH(gru_step_bwd, 0, dim3(rb, H / 16));
-            if (t > 0) {
-                a.pk = upack + 4 * HH;
-                STEP_DISPATCH(gru_step_bwd, 1, dim3(rb, H / 16));
+    const bool graph = use_graph != 0;
+    const int32_t* soh = graph ? nullptr : step_off_host;       // a graph must not bake host-side sizes in
+    auto enqueue = [&](hipStream_t st) -> int {
+        StepArgs a = {};
+        a.H = H; a.H_real = H_real; a.XW = XW; a.Hout = Hout; a.gates = gates; a.aux = aux;
+        a.rmask = rmask; a.B = B; a.step_off = step_off; a.T = T;
+        for (int t = 0; t < T; ++t) {
+            a.t = t;
+            const int bt = soh ? soh[t + 1] - soh[t] : B;       // exact rows when known on the host, else the maximum
+            if (bt <= 0) break;
+            if (soh) {
+                a.step_off = nullptr;
+                a.p0 = soh[t]; a.bt = bt; a.pprev0 = t > 0 ? soh[t - 1] : 0; a.first = t == 0;
+                a.bnext = t + 1 < T ? soh[t + 2] - soh[t + 1] : 0;
             }
-        } else {
-            const int G = cell == SEQREC_CELL_LSTM ? 4 : 1;
-            int rc = cell == SEQREC_CELL_LSTM ? launch_pointwise<SEQREC_CELL_LSTM>(act, a, st)
-                                              : launch_pointwise<SEQREC_CELL_SIMPLERNN>(act, a, st);
-            if (rc) return rc;
-            if (t > 0) {
-                a.pk = upack + (long)G * HH;
-                if ((rc = launch_gemm_bwd(G * H, dim3(rb, H / 16), a, H, G * H, st))) return rc;
+            const unsigned rb = (unsigned)((bt + 15) / 16);
+            a.pk = upack;
+            if (cell == SEQREC_CELL_GRU) {
+                STEP_DISPATCH(gru_step_fwd, 0, dim3(rb, 2 * H / 16));
+                a.pk = upack + 2 * HH;
+                STEP_DISPATCH(gru_step_fwd, 1, dim3(rb, H / 16));
+            } else if (cell == SEQREC_CELL_LSTM) {
+                if (rmask) { CELL_DISPATCH(lstm_step_fwd_rd, dim3(rb, H / 16)); }
+                else { CELL_DISPATCH(lstm_step_fwd_nd, dim3(rb, H / 16)); }
+            } else {
+                CELL_DISPATCH(srnn_step_fwd, dim3(rb, H / 16));
             }
         }
-    }
-    return 0;
+        return 0;
+    };
+    const GraphKey key = {0ull, (unsigned long long)cell, (unsigned long long)act, (unsigned long long)H,
+                          (unsigned long long)H_real, (unsigned long long)T, (unsigned long long)B, pk_(step_off), pk_(XW),
+                          pk_(Hout), pk_(gates), pk_(aux), pk_(upack), pk_(rmask)};
+    return run_maybe_graph(graph, key, st, enqueue);
+}
+
+// workspace: 2 * N_tok * H floats (carried dh per token, dcar / carried dc per token)
+extern "C" int seqrec_rnn_bwd_stepwise(int cell, int act, int H, int H_real, int T, int B,
+                                       const int32_t* step_off, const int32_t* step_off_host, int64_t n_tok,
+                                       const float* dHout, const float* Hout, const float* gates, const float* aux,
+                                       float* dPre, const float* upack, float* workspace, const float* rmask,
+                                       int use_graph, void* stream) {
+    if (!ok_shape(cell, act, H, H_real, T, B)) return SEQREC_E_SHAPE;
+    if (T == 0 || B == 0) return 0;
+    if (!step_off || !dHout || !Hout || !dPre || !upack || !workspace || n_tok <= 0) return SEQREC_E_ARG;
+    if (cell != SEQREC_CELL_SIMPLERNN && (!gates || !aux)) return SEQREC_E_ARG;
+    hipStream_t st = as_stream(stream);
+    const int J = H / 64;
+    const long HH = (long)H * H;
+    const bool graph = use_graph != 0;
+    const int32_t* soh = graph ? nullptr : step_off_host;
+    auto enqueue = [&](hipStream_t st) -> int {
+        StepArgs a = {};
+        a.H = H; a.H_real = H_real; a.Hout = const_cast<float*>(Hout); a.gates = const_cast<float*>(gates);
+        a.aux = const_cast<float*>(aux); a.dHout = dHout; a.dPre = dPre;
+        a.dHc = workspace; a.tmpc = workspace + n_tok * H;
+        a.rmask = rmask; a.B = B; a.step_off = step_off; a.T = T;
+        for (int t = T - 1; t >= 0; --t) {
+            a.t = t;
+            const int bt = soh ? soh[t + 1] - soh[t] : B;
+            if (bt <= 0) continue;
+            if (soh) {
+                a.step_off = nullptr;
+                a.p0 = soh[t]; a.bt = bt; a.pprev0 = t > 0 ? soh[t - 1] : 0; a.first = t == 0;
+                a.bnext = t + 1 < T ? soh[t + 2] - soh[t + 1] : 0;
+            }
+            const unsigned rb = (unsigned)((bt + 15) / 16);
+            if (cell == SEQREC_CELL_GRU) {
+                a.pk = upack + 3 * HH;
+                STEP_DISPATCH(gru_step_bwd, 0, dim3(rb, H / 16));
+                if (t > 0) {
+                    a.pk = upack + 4 * HH;
+                    STEP_DISPATCH(gru_step_bwd, 1, dim3(rb, H / 16));
+                }
+            } else {
+                const int G = cell == SEQREC_CELL_LSTM ? 4 : 1;
+                if (!soh) a.bt = bt;                            // only sizes the pointwise grid
+                int rc = cell == SEQREC_CELL_LSTM ? launch_pointwise<SEQREC_CELL_LSTM>(act, a, st)
+                                                  : launch_pointwise<SEQREC_CELL_SIMPLERNN>(act, a, st);
+                if (rc) return rc;
+                if (t > 0) {
+                    a.pk = upack + (long)G * HH;
+                    if ((rc = launch_gemm_bwd(G * H, dim3(rb, H / 16), a, H, G * H, st))) return rc;
+                }
+            }
+        }
+        return 0;
+    };
+    const GraphKey key = {1ull, (unsigned long long)cell, (unsigned long long)act, (unsigned long long)H,
+                          (unsigned long long)H_real, (unsigned long long)T, (unsigned long long)B, pk_(step_off),
+                          (unsigned long long)n_tok, pk_(dHout), pk_(Hout), pk_(gates), pk_(aux), pk_(dPre), pk_(upack),
+                          pk_(workspace), pk_(rmask)};
+    return run_maybe_graph(graph, key, st, enqueue);
 }

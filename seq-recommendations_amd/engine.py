@@ -170,8 +170,12 @@ class Engine:
         if c.drop_rec > 0 and not self.stepwise:
             raise NotImplementedError("recurrent (z_to_z) dropout needs scan='stepwise' (or 'auto')")
         import os
+        self.use_graph = self.stepwise and os.environ.get("SEQREC_SCAN_GRAPH", "0") != "0"   # hipGraph replay of the scan launches (measured: no gain, GPU-bound)
+        self._so_fixed = None
+        self._so_token = object()
         self.use_side = os.environ.get("SEQREC_SIDE_STREAM", "0") != "0"   # measured: overlap slows the scan more than it hides
-        self.side = torch.cuda.Stream(device=self.dev)     # independent work beside the scan (dEneg GEMM)
+        self.side = torch.cuda.Stream(device=self.dev, priority=0)
+        self.main_hi = torch.cuda.Stream(device=self.dev, priority=-1) if os.environ.get("SEQREC_MAIN_HI", "0") != "0" else None     # independent work beside the scan (dEneg GEMM)
         self.ev_fork = torch.cuda.Event()
         self.ev_join = torch.cuda.Event()
         self.sampler = None       # (thresh uint32-as-int32 tensor, alias int32 tensor, logq float tensor)
@@ -359,6 +363,16 @@ class Engine:
         return dict(table=self.P[name], accum=self.A[name], gtab=self.Gt[name], slot=self.slot[name], rows=rows, vals=vals,
                     ldv=ldv, row_scale=row_scale, n=n, width=width, base=base, name=name)
 
+    def _step_table(self, d):
+        """Device step offsets for the step-wise scan.  In graph mode every batch's table is copied
+        into ONE fixed buffer so the captured launch graph (keyed by pointers, T, B) is reusable."""
+        if not self.use_graph:
+            return d["step_off"]
+        if self._so_fixed is None or self._so_fixed.numel() < d["T"] + 1:
+            self._so_fixed = torch.zeros(max(64, d["T"] + 1), dtype=torch.int32, device=self.dev)
+        self._so_fixed[: d["T"] + 1].copy_(d["step_off"], non_blocking=True)
+        return self._so_fixed
+
     # ------------------------------------------------------------------ recurrent scan
     def _scan_fwd(self, d, XW, Hout, gates, aux, rmask=None):
         c, st = self.cfg, self._stream()
@@ -369,8 +383,9 @@ class Engine:
             self.upack_dirty = False
         if self.stepwise:
             so = d["rb"].step_off
-            call("seqrec_rnn_fwd_stepwise", CELL[c.cell], ACT[c.act], Hp, c.H, d["T"], d["B"], so.ctypes.data, ptr(XW), ptr(Hout),
-                 ptr(gates), ptr(aux), ptr(self.upack), ptr(rmask), st)
+            sod = self._sod_cur = self._step_table(d)
+            call("seqrec_rnn_fwd_stepwise", CELL[c.cell], ACT[c.act], Hp, c.H, d["T"], d["B"], ptr(sod), so.ctypes.data, ptr(XW),
+                 ptr(Hout), ptr(gates), ptr(aux), ptr(self.upack), ptr(rmask), int(self.use_graph), st)
         else:
             call("seqrec_rnn_fwd", CELL[c.cell], ACT[c.act], Hp, c.H, d["T"], d["B"], ptr(d["step_off"]), ptr(XW),
                  ptr(Hout), ptr(gates), ptr(aux), ptr(self.upack), st)
@@ -381,8 +396,10 @@ class Engine:
         if self.stepwise:
             so = d["rb"].step_off
             wsp = self.buf("scan_ws", 2 * d["n"] * Hp)
-            call("seqrec_rnn_bwd_stepwise", CELL[c.cell], ACT[c.act], Hp, c.H, d["T"], d["B"], so.ctypes.data, ptr(dHout),
-                 ptr(Hout), ptr(gates), ptr(aux), ptr(dPre), ptr(self.upack), ptr(wsp), ptr(rmask), st)
+            sod = self._sod_cur          # the table the forward scan of this step installed
+            call("seqrec_rnn_bwd_stepwise", CELL[c.cell], ACT[c.act], Hp, c.H, d["T"], d["B"], ptr(sod), so.ctypes.data, d["n"],
+                 ptr(dHout), ptr(Hout), ptr(gates), ptr(aux), ptr(dPre), ptr(self.upack), ptr(wsp), ptr(rmask),
+                 int(self.use_graph), st)
         else:
             call("seqrec_rnn_bwd", CELL[c.cell], ACT[c.act], Hp, c.H, d["T"], d["B"], ptr(d["step_off"]), ptr(dHout), ptr(Hout),
                  ptr(gates), ptr(aux), ptr(dPre), ptr(self.upack), st)
@@ -465,6 +482,16 @@ class Engine:
 
     # ------------------------------------------------------------------ training step
     def train_step(self, d, lr=0.01, eps=1e-8, clipnorm=1.0, step=None, negatives=None, apply_update=True):
+        if self.main_hi is None:
+            return self._train_step(d, lr, eps, clipnorm, step, negatives, apply_update)
+        cur = torch.cuda.current_stream(self.dev)
+        self.main_hi.wait_stream(cur)
+        with torch.cuda.stream(self.main_hi):
+            out = self._train_step(d, lr, eps, clipnorm, step, negatives, apply_update)
+        cur.wait_stream(self.main_hi)
+        return out
+
+    def _train_step(self, d, lr=0.01, eps=1e-8, clipnorm=1.0, step=None, negatives=None, apply_update=True):
         """One full step on an uploaded batch: forward, masked-mean CE, BPTT, global-norm clip,
         Adagrad.  Returns the batch loss as a 1-element device tensor (no host sync)."""
         c, P = self.cfg, self.P

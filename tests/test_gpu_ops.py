@@ -367,10 +367,11 @@ def test_rank_count_vs_numpy():
 
 
 @pytest.mark.parametrize("cell", ["gru", "lstm", "simplernn"])
+@pytest.mark.parametrize("graph", [0, 1])
 @pytest.mark.parametrize("H,B,maxlen,act", [(64, 5, 6, "relu"), (64, 37, 12, "tanh"), (128, 100, 9, "relu"),
                                             (256, 70, 20, "relu"), (256, 512, 49, "tanh"), (128, 40, 10, "linear"),
                                             (512, 33, 7, "relu")])
-def test_stepwise_scan_vs_oracle_and_persistent(cell, H, B, maxlen, act):
+def test_stepwise_scan_vs_oracle_and_persistent(cell, H, B, maxlen, act, graph):
     """The launch-per-step scan (rnn_step.hip) against the oracle, and close to the persistent scan
     (same fp32 MFMA chains, only the accumulation split differs)."""
     rng = np.random.default_rng(H * 3 + B + maxlen)
@@ -385,15 +386,19 @@ def test_stepwise_scan_vs_oracle_and_persistent(cell, H, B, maxlen, act):
     XWd, Ud = dev(XW), dev(U)
     call("seqrec_rnn_pack_u_stepwise", ci, H, ptr(Ud), ptr(up), st())
     so = rb.step_off
-    call("seqrec_rnn_fwd_stepwise", ci, L.ACT[act], H, H, rb.T, rb.B, so.ctypes.data, ptr(XWd), ptr(Hout), ptr(gates), ptr(aux),
-         ptr(up), None, st())
+    sod = dev(rb.step_off)
+    for rep in range(1 + graph):          # graph mode: the second call replays the captured launches
+        call("seqrec_rnn_fwd_stepwise", ci, L.ACT[act], H, H, rb.T, rb.B, ptr(sod), so.ctypes.data, ptr(XWd), ptr(Hout), ptr(gates),
+             ptr(aux), ptr(up), None, graph, st())
     got = Hout.cpu().numpy()
     scale = max(1.0, np.abs(ref["H"]).max())
     assert np.abs(got - ref["H"]).max() <= 3e-5 * scale
     dPre = torch.full((n, G * H), float("nan"), device="cuda")
     ws = torch.full((2 * n * H,), float("nan"), device="cuda")
-    call("seqrec_rnn_bwd_stepwise", ci, L.ACT[act], H, H, rb.T, rb.B, so.ctypes.data, ptr(dev(dH)), ptr(Hout), ptr(gates), ptr(aux),
-         ptr(dPre), ptr(up), ptr(ws), None, st())
+    dHd = dev(dH)
+    for rep in range(1 + graph):
+        call("seqrec_rnn_bwd_stepwise", ci, L.ACT[act], H, H, rb.T, rb.B, ptr(sod), so.ctypes.data, n, ptr(dHd), ptr(Hout), ptr(gates),
+             ptr(aux), ptr(dPre), ptr(up), ptr(ws), None, graph, st())
     gp = dPre.cpu().numpy()
     s2 = max(1.0, np.abs(ref["dPre"]).max())
     bad = np.abs(gp - ref["dPre"]) > 1e-4 * s2
@@ -403,3 +408,5 @@ def test_stepwise_scan_vs_oracle_and_persistent(cell, H, B, maxlen, act):
     call("seqrec_rnn_pack_u", ci, H, ptr(Ud), ptr(up), st())
     call("seqrec_rnn_fwd", ci, L.ACT[act], H, H, rb.T, rb.B, ptr(dev(rb.step_off)), ptr(XWd), ptr(H2), ptr(g2), ptr(a2), ptr(up), st())
     assert np.abs(H2.cpu().numpy() - got).max() <= 2e-5 * scale
+    if graph:
+        assert L.load().seqrec_graph_cache_clear() == 0

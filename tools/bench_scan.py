@@ -33,9 +33,11 @@ def main():
         def b(): call("seqrec_rnn_bwd", L.CELL[cell], 0, H, H, rb.T, rb.B, ptr(so), ptr(dH), ptr(Hout), ptr(gates), ptr(aux), ptr(dPre), ptr(up), st)
         ws = torch.empty(2 * n * H, device="cuda")
         soh = rb.step_off
-        def f2(): call("seqrec_rnn_fwd_stepwise", L.CELL[cell], 0, H, H, rb.T, rb.B, soh.ctypes.data, ptr(XW), ptr(Hout), ptr(gates), ptr(aux), ptr(up2), None, st)
-        def b2(): call("seqrec_rnn_bwd_stepwise", L.CELL[cell], 0, H, H, rb.T, rb.B, soh.ctypes.data, ptr(dH), ptr(Hout), ptr(gates), ptr(aux), ptr(dPre), ptr(up2), ptr(ws), None, st)
-        fns = (f, b, f2, b2)
+        def f2(): call("seqrec_rnn_fwd_stepwise", L.CELL[cell], 0, H, H, rb.T, rb.B, ptr(so), soh.ctypes.data, ptr(XW), ptr(Hout), ptr(gates), ptr(aux), ptr(up2), None, 0, st)
+        def b2(): call("seqrec_rnn_bwd_stepwise", L.CELL[cell], 0, H, H, rb.T, rb.B, ptr(so), soh.ctypes.data, n, ptr(dH), ptr(Hout), ptr(gates), ptr(aux), ptr(dPre), ptr(up2), ptr(ws), None, 0, st)
+        def f3(): call("seqrec_rnn_fwd_stepwise", L.CELL[cell], 0, H, H, rb.T, rb.B, ptr(so), soh.ctypes.data, ptr(XW), ptr(Hout), ptr(gates), ptr(aux), ptr(up2), None, 1, st)
+        def b3(): call("seqrec_rnn_bwd_stepwise", L.CELL[cell], 0, H, H, rb.T, rb.B, ptr(so), soh.ctypes.data, n, ptr(dH), ptr(Hout), ptr(gates), ptr(aux), ptr(dPre), ptr(up2), ptr(ws), None, 1, st)
+        fns = (f, b, f2, b2, f3, b3)
         out = []
         for fn in fns:
             fn(); torch.cuda.synchronize()
@@ -48,6 +50,6 @@ def main():
     for r in res:
         T, n = r[0], r[1]
         print("T=%2d n_tok=%5d  " % (T, n) + "  ".join("%7.1f us (%.2f/step)" % (x, x / T) for x in r[2:]))
-    print("mean [persistent fwd, bwd, stepwise fwd, bwd]:", ["%.1f" % np.mean([r[i] for r in res]) for i in range(2, len(res[0]))])
+    print("mean [persistent fwd, bwd, stepwise fwd, bwd, graph fwd, bwd]:", ["%.1f" % np.mean([r[i] for r in res]) for i in range(2, len(res[0]))])
 
 main()

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Is the training step host-bound?  Time enqueue-only vs enqueue+sync for N steps (GPU box)."""
+import importlib, os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+E = importlib.import_module("seq-recommendations_amd.engine")
+Bt = importlib.import_module("seq-recommendations_amd.batching")
+Sy = importlib.import_module("seq-recommendations_amd.synthetic")
+Sm = importlib.import_module("seq-recommendations_amd.sampling")
+cd = bench.CONFIGS["c3"]; V = cd["V"]
+cfg = E.NetConfig(cell="gru", act="relu", H=256, V_in=V, V_out=V, input="embed", D=256, output="sampled", K=2000, logq=True, seed=1)
+eng = E.Engine(cfg)
+bench.init_params_device(eng, cd, 1)
+gen = Sy.SyntheticSessions(V, seed=1234)
+p = Sm.log_uniform_probs(V, gen.proposal_rank()); th, al = Sm.build_alias_table(p); eng.set_sampler(th, al, np.log(p).astype(np.float32))
+flat, starts = gen.generate(512 * 32)
+bs = [eng.upload(Bt.pack_flat(flat, starts, np.arange(i * 512, (i + 1) * 512))) for i in range(32)]
+for i in range(20): eng.train_step(bs[i % 32], step=i)
+torch.cuda.synchronize()
+N = 200
+t0 = time.perf_counter()
+for i in range(N): eng.train_step(bs[i % 32], step=20 + i)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("enqueue-only %.1f us/step   enqueue+drain %.1f us/step" % ((t1 - t0) / N * 1e6, (t2 - t0) / N * 1e6))
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+for i in range(50): eng.train_step(bs[i % 32], step=300 + i)
+pr.disable(); torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
