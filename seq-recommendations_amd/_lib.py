@@ -115,6 +115,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own HIP runtime (libamdhip64); it must be in the process BEFORE this library
+    # is loaded, otherwise the system copy under /opt/rocm gets loaded first and the two runtimes do
+    # not share devices or allocations (kernel launches then fail with hipErrorNoDevice).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise SeqrecError(
             "libseqrec_hip.so not found at %s: the HIP extension is required (no CPU fallback). "
