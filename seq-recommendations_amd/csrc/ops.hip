@@ -308,16 +308,26 @@ __global__ void rows_scatter_add_multi_kernel(RowsMulti m) {
     if (lane == 0) atomicMin(J.slot + r, J.base + (int)i);
 }
 __global__ void rows_sqnorm_multi_kernel(RowsMulti m, float* __restrict__ sq) {
+    // every wave owns RPW consecutive contributions and issues their (random, HBM-latency-bound)
+    // accesses together: RPW slot reads, then RPW predicated row reads -- instead of RPW dependent
+    // round trips; one same-address atomic per 4*RPW contributions.
+    constexpr int RPW = 4;
     const seqrec_rows_job& J = m.j[blockIdx.y];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long i = (long)blockIdx.x * (blockDim.x >> 6) + wv;
+    const long i0 = ((long)blockIdx.x * (blockDim.x >> 6) + wv) * RPW;
     __shared__ float part[4];
+    int r[RPW];
+    bool own[RPW];
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) r[k] = (i0 + k < J.n) ? J.rows[i0 + k] : -1;
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) own[k] = r[k] >= 0 && J.slot[r[k]] == J.base + (int)(i0 + k);
     float s = 0.f;
-    if (i < J.n) {
-        const int r = J.rows[i];
-        if (J.slot[r] == J.base + (int)i) {
-            const float* g = J.gtab + (long)r * J.width;
-            for (int c = lane; c < J.width; c += 64) s += g[c] * g[c];
+    for (int c = lane; c < J.width; c += 64) {
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            const float g = own[k] ? J.gtab[(long)r[k] * J.width + c] : 0.f;
+            s += g * g;
         }
     }
     s = wave_sum(s);
@@ -415,7 +425,11 @@ __global__ void sampled_softmax_ce_reg_kernel(float* __restrict__ ln, long ld, c
                                               const float* __restrict__ Eout, const float* __restrict__ bout,
                                               const float* __restrict__ logq, const float* __restrict__ lq_n,
                                               const int* __restrict__ tgt, const int* __restrict__ neg, long n, int K,
-                                              float inv_denom, float* __restrict__ loss_rows, float* __restrict__ dlt) {
+                                              float inv_denom, float* __restrict__ loss_rows, float* __restrict__ dlt,
+                                              int vec) {
+    // lane owns logits k = 256*i + 4*lane + e (e < 4): one 16-byte access per lane per chunk when the
+    // row is 16-byte aligned (vec), else four dword accesses with the same mapping
+    constexpr int NC = KR / 4;
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= n) return;
@@ -423,21 +437,34 @@ __global__ void sampled_softmax_ce_reg_kernel(float* __restrict__ ln, long ld, c
     float* x = ln + row * ld;
     float v[KR];
 #pragma unroll
-    for (int i = 0; i < KR; ++i) {
-        const int k = lane + 64 * i;
-        float l = -INFINITY;
-        if (k < K) {
-            const int id = neg[k];
-            l = x[k];
-            if (ROWS) {
-                if (lq_n) l -= lq_n[k];
-            } else {
-                if (bout) l += bout[id];
-                if (logq) l -= logq[id];
-            }
-            if (id == t) l = -INFINITY;
+    for (int i = 0; i < NC; ++i) {
+        const int k0 = 256 * i + 4 * lane;
+        float4 q = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if (vec && k0 + 3 < K) {
+            q = *reinterpret_cast<const float4*>(x + k0);
+        } else {
+            if (k0 + 0 < K) q.x = x[k0 + 0];
+            if (k0 + 1 < K) q.y = x[k0 + 1];
+            if (k0 + 2 < K) q.z = x[k0 + 2];
+            if (k0 + 3 < K) q.w = x[k0 + 3];
         }
-        v[i] = l;
+        const float qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k0 + e;
+            float l = qq[e];
+            if (k < K) {
+                const int id = neg[k];
+                if (ROWS) {
+                    if (lq_n) l -= lq_n[k];
+                } else {
+                    if (bout) l += bout[id];
+                    if (logq) l -= logq[id];
+                }
+                if (id == t) l = -INFINITY;
+            }
+            v[4 * i + e] = l;
+        }
     }
     const float* h = hd + row * H;
     const float* et = Eout + (ROWS ? row : (long)t) * H;
@@ -468,9 +495,15 @@ __global__ void sampled_softmax_ce_reg_kernel(float* __restrict__ ln, long ld, c
     }
     const float sc = active / s;
 #pragma unroll
-    for (int i = 0; i < KR; ++i) {
-        const int k = lane + 64 * i;
-        if (k < K) x[k] = v[i] * sc;
+    for (int i = 0; i < NC; ++i) {
+        const int k0 = 256 * i + 4 * lane;
+        if (vec && k0 + 3 < K) {
+            *reinterpret_cast<float4*>(x + k0) = make_float4(v[4 * i] * sc, v[4 * i + 1] * sc, v[4 * i + 2] * sc, v[4 * i + 3] * sc);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k0 + e < K) x[k0 + e] = v[4 * i + e] * sc;
+        }
     }
 }
 
@@ -479,13 +512,16 @@ int launch_sampled(float* ln, long ld, const float* hd, int H, const float* Eout
                    const float* lq_n, const int* tgt, const int* neg, long n, int K, float inv_denom, float* loss_rows,
                    float* dlt, hipStream_t st) {
     const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+    const int vec = ((reinterpret_cast<uintptr_t>(ln) & 15) == 0) && (ld % 4 == 0);
 #define SS_ARGS ln, ld, hd, H, Eout, bout, logq, lq_n, tgt, neg, n, K, inv_denom, loss_rows, dlt
-    if (K <= 64 * 8) hipLaunchKernelGGL((sampled_softmax_ce_reg_kernel<ROWS, 8>), grid, block, 0, st, SS_ARGS);
-    else if (K <= 64 * 16) hipLaunchKernelGGL((sampled_softmax_ce_reg_kernel<ROWS, 16>), grid, block, 0, st, SS_ARGS);
-    else if (K <= 64 * 32) hipLaunchKernelGGL((sampled_softmax_ce_reg_kernel<ROWS, 32>), grid, block, 0, st, SS_ARGS);
-    else if (K <= 64 * 64) hipLaunchKernelGGL((sampled_softmax_ce_reg_kernel<ROWS, 64>), grid, block, 0, st, SS_ARGS);
+#define SS_ARGSV SS_ARGS, vec
+    if (K <= 64 * 8) hipLaunchKernelGGL((sampled_softmax_ce_reg_kernel<ROWS, 8>), grid, block, 0, st, SS_ARGSV);
+    else if (K <= 64 * 16) hipLaunchKernelGGL((sampled_softmax_ce_reg_kernel<ROWS, 16>), grid, block, 0, st, SS_ARGSV);
+    else if (K <= 64 * 32) hipLaunchKernelGGL((sampled_softmax_ce_reg_kernel<ROWS, 32>), grid, block, 0, st, SS_ARGSV);
+    else if (K <= 64 * 64) hipLaunchKernelGGL((sampled_softmax_ce_reg_kernel<ROWS, 64>), grid, block, 0, st, SS_ARGSV);
     else hipLaunchKernelGGL(sampled_softmax_ce_kernel<ROWS>, grid, block, 0, st, SS_ARGS);
 #undef SS_ARGS
+#undef SS_ARGSV
     SEQREC_LAUNCH_CHECK();
     return 0;
 }
@@ -648,7 +684,7 @@ extern "C" int seqrec_sqnorm_multi(int count, const float* const* g, const int64
     if (count == 0) return 0;
     DenseMulti m = {};
     for (int i = 0; i < count; ++i) { if (n[i] < 0 || (n[i] > 0 && !g[i])) return SEQREC_E_ARG; m.g[i] = g[i]; m.n[i] = n[i]; }
-    hipLaunchKernelGGL(sqnorm_multi_kernel, dim3(128, count), dim3(256), 0, as_stream(stream), m, sq_accum);
+    hipLaunchKernelGGL(sqnorm_multi_kernel, dim3(32, count), dim3(256), 0, as_stream(stream), m, sq_accum);
     SEQREC_LAUNCH_CHECK();
     return 0;
 }
@@ -693,7 +729,7 @@ extern "C" int seqrec_rows_sqnorm_multi(const seqrec_rows_job* jobs, int count, 
     int rc = fill_rows_multi(jobs, count, m, maxn);
     if (rc || maxn == 0) return rc;
     if (!sq_accum) return SEQREC_E_ARG;
-    hipLaunchKernelGGL(rows_sqnorm_multi_kernel, dim3((unsigned)((maxn + 3) / 4), count), dim3(256), 0, as_stream(stream), m, sq_accum);
+    hipLaunchKernelGGL(rows_sqnorm_multi_kernel, dim3((unsigned)((maxn + 15) / 16), count), dim3(256), 0, as_stream(stream), m, sq_accum);
     SEQREC_LAUNCH_CHECK();
     return 0;
 }
