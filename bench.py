@@ -103,6 +103,29 @@ def kernel_model(cfgd, n_tok, K, B):
     return m
 
 
+def pmc_traffic(kernel, t_mean, a):
+    """HBM bytes per call of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_v2_c3_pmc_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of
+    this same command; FETCH_SIZE doubled per the gfx950 correction for wide coalesced reads).
+    Only valid for the workload those passes profiled (c3, MSNBC-shaped); None otherwise."""
+    path = os.path.join(ROOT, "profiles", "r01_v2_c3_pmc_hbm_traffic.json")
+    if a.config != "c3" or a.saturated or not os.path.exists(path):
+        return None
+    pm = json.load(open(path))
+    pick = {"seqrec_rnn_fwd_stepwise": ("gru_step_fwd<4, 0, 0>", "gru_step_fwd<4, 0, 1>"),
+            "seqrec_rnn_bwd_stepwise": ("gru_step_bwd<4, 0, 0>", "gru_step_bwd<4, 0, 1>")}.get(kernel)
+    if not pick:
+        return None
+    tot = 0.0
+    for i, frag in enumerate(pick):
+        ent = next((v for k, v in pm.items() if frag in k), None)
+        if ent is None:
+            return None
+        launches = t_mean - (1 if (i == 1 and "bwd" in kernel) else 0)     # bwd phase 1 is skipped at t = 0
+        tot += launches * (ent["fetch_kib_x2"] + ent["write_kib"]) * 1024.0
+    return {"bytes_per_call": round(tot), "source": "profiles/r01_v2_c3_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+
+
 def main():
     a = parse()
     import torch
@@ -221,8 +244,10 @@ def main():
         dom = next((k for k in kern if "bound" in kern[k]), None)
         if dom:
             e = kern[dom]
+            t_mean = float(np.mean([b["T"] for b in batches]))
             roof = {"kernel": dom, "bound": e["bound"], "achieved": e["achieved"], "peak": e["peak"], "unit": e["unit"],
-                    "frac": e["frac"], "traffic": None, "avg_us": e["avg_us"], "share_of_step": e["share"]}
+                    "frac": e["frac"], "traffic": pmc_traffic(dom, t_mean, a), "avg_us": e["avg_us"],
+                    "share_of_step": e["share"]}
 
     # ---- Recall@20 on held-out sessions after some more training
     recall = None
