@@ -355,6 +355,15 @@ class OracleNet:
             logits = hrows @ p["Wout"]
             if cfg.get("out_bias", False):
                 logits = logits + p["bout"]
+            # RNNFullModel side branches (model.py:375-392): history features straight into the output
+            # layer (x_to_y; same Dense as z, kernel rows [z_dim:]) and the direct y_{t-1} -> y_t term
+            # (y_to_y: TimeDistributed(Dense) on the UNmasked one-hot input = a row of Wyy)
+            if "Wxy" in p:
+                logits = logits + batch["xs"][bi, ti].astype(dt) @ p["Wxy"]
+            if "Wyy" in p:
+                logits = logits + p["Wyy"][batch["ids"][bi, ti]]
+                if "byy" in p:
+                    logits = logits + p["byy"]
             if tgt is not None:
                 ce, dlog, pr = full_softmax_ce(logits, tgt, max(n_tok, 1))
                 st["dlog"] = dlog
@@ -383,6 +392,12 @@ class OracleNet:
         logits = hs @ p["Wout"]
         if cfg.get("out_bias", False):
             logits = logits + p["bout"]
+        if "Wxy" in p:
+            logits = logits + batch["xs"].astype(self.dtype) @ p["Wxy"]
+        if "Wyy" in p:                       # unmasked one-hot input: pad rows contribute only the bias
+            logits = logits + p["Wyy"][batch["ids"]] * batch["mask"][:, :, None]
+            if "byy" in p:
+                logits = logits + p["byy"]
         m = logits.max(axis=2, keepdims=True)
         e = np.exp(logits - m)
         return e / e.sum(axis=2, keepdims=True)
@@ -407,6 +422,12 @@ class OracleNet:
             g["Wout"] = hrows.T @ dlog
             if cfg.get("out_bias", False):
                 g["bout"] = dlog.sum(axis=0)
+            if "Wxy" in p:
+                g["Wxy"] = batch["xs"][bi, ti].astype(dt).T @ dlog
+            if "Wyy" in p:
+                sparse["Wyy"] = (batch["ids"][bi, ti].astype(np.int64), dlog)
+                if "byy" in p:
+                    g["byy"] = dlog.sum(axis=0)
             dhd[bi, ti] = dlog @ p["Wout"].T
         else:
             neg = st["negatives"]

@@ -24,6 +24,7 @@ class RaggedBatch:
     step_off   int32[T+1]
     ids, tgt   int32[N_tok]   (ids may be None when dense features are used)
     x          float32[N_tok, F] dense features or None
+    xs         float32[N_tok, Fx] history features for the x_to_y branch or None
     prev       int32[N_tok]
     tok_b      int32[N_tok]   original batch index of the token's session
     tok_s      int32[N_tok]   step index t of the token
@@ -32,7 +33,7 @@ class RaggedBatch:
                weights epoch losses by this batch size.
     """
 
-    __slots__ = ("order", "lengths", "step_off", "ids", "tgt", "x", "prev", "tok_b", "tok_s", "tok_row",
+    __slots__ = ("order", "lengths", "step_off", "ids", "tgt", "x", "prev", "tok_b", "tok_s", "tok_row", "xs",
                  "n_sessions", "B", "T", "n_tok")
 
 
@@ -82,6 +83,7 @@ def pack_sessions(sessions):
     rb.ids = flat[src].astype(np.int32)
     rb.tgt = flat[src + 1].astype(np.int32)
     rb.x = None
+    rb.xs = None
     return _finish(rb, order, ls, step_off, tok_t, tok_bs, B, T, n_tok, n_sessions)
 
 
@@ -97,10 +99,11 @@ def pack_flat(flat, starts, sel):
     rb.ids = flat[src].astype(np.int32)
     rb.tgt = flat[src + 1].astype(np.int32)
     rb.x = None
+    rb.xs = None
     return _finish(rb, order, ls, step_off, tok_t, tok_bs, B, T, n_tok, len(sel))
 
 
-def pack_padded(mask, ids=None, tgt=None, x=None):
+def pack_padded(mask, ids=None, tgt=None, x=None, xs=None):
     """From the reference's padded view: mask (B,T) bool marks real steps (any position --
     masked steps simply carry state, so only the order of the real steps matters);
     ids/tgt (B,T) ints and/or x (B,T,F) float features."""
@@ -116,6 +119,7 @@ def pack_padded(mask, ids=None, tgt=None, x=None):
     rb.ids = None if ids is None else np.asarray(ids)[rows, tcol].astype(np.int32)
     rb.tgt = None if tgt is None else np.asarray(tgt)[rows, tcol].astype(np.int32)
     rb.x = None if x is None else np.ascontiguousarray(np.asarray(x)[rows, tcol], dtype=np.float32)
+    rb.xs = None if xs is None else np.ascontiguousarray(np.asarray(xs)[rows, tcol], dtype=np.float32)
     rb = _finish(rb, order, ls, step_off, tok_t, tok_bs, B, T, n_tok, n_sessions)
     return rb, tcol.astype(np.int64)
 

@@ -95,7 +95,13 @@ class NetConfig:
     drop_out: float = 0.0         # z_to_y_dropout
     logq: bool = False            # subtract log Q(item) from sampled logits
     seed: int = 0                 # counter-RNG seed (negatives, dropout)
-    scan: str = "auto"            # 'persistent' (rnn.hip) | 'stepwise' (rnn_step.hip, GRU) | 'auto'
+    scan: str = "auto"            # 'persistent' (rnn.hip) | 'stepwise' (rnn_step.hip) | 'auto'
+    # RNNFullModel side branches (model.py:375-392; full softmax only, small vocabularies)
+    y_to_y: bool = False          # logits += Wyy[id_t] (+ byy): direct term on the one-hot input
+    yy_bias: bool = False
+    x_to_y: bool = False          # logits += xs_t . Wxy   (history features, x_dim wide)
+    x_dim: int = 0
+    diag_b: bool = True           # OnlyNonZeroDiagonal on Wxy (model.py:48-66): re-applied after every update
 
     @property
     def G(self):
@@ -134,10 +140,25 @@ class Engine:
         P["U"] = z(self.Hp, self.GHp)
         if c.use_bias:
             P["b"] = z(self.GHp)
+        if (c.y_to_y or c.x_to_y) and c.output != "full":
+            raise ValueError("the y_to_y / x_to_y branches are dense V x V terms: full softmax only")
+        self.Fxp = _ceil4(c.x_dim) if c.x_to_y else 0
         if c.output == "full":
             P["Wout"] = z(self.Hp, self.Vp)
             if c.out_bias:
                 P["bout"] = z(self.Vp)
+            if c.y_to_y:
+                P["Wyy"] = z(c.V_out, self.Vp)       # row per input item (y_dim == n_classes)
+                if c.yy_bias:
+                    P["byy"] = z(self.Vp)
+            if c.x_to_y:
+                P["Wxy"] = z(self.Fxp, self.Vp)
+                if c.diag_b:
+                    if c.x_dim != c.V_out:
+                        raise ValueError("diag_b needs x_dim == y_dim")
+                    m = torch.zeros(self.Fxp, self.Vp, **f32)
+                    m[torch.arange(c.x_dim), torch.arange(c.x_dim)] = 1.0
+                    self.diag_mask = m
         else:
             if not c.tied:
                 P["Eout"] = z(c.V_out, self.Hp)
@@ -149,6 +170,8 @@ class Engine:
             self.table_params.add("E")
         if c.input == "onehot":
             self.table_params.add("Wk")
+        if c.y_to_y:
+            self.table_params.add("Wyy")
         if c.output == "sampled":
             if not c.tied:
                 self.table_params.add("Eout")
@@ -244,9 +267,12 @@ class Engine:
         elif name == "Eout":
             arr = np.zeros((c.V_out, self.Hp), np.float32)
             arr[:, : c.H] = v
-        elif name == "bout":
+        elif name in ("bout", "byy"):
             arr = np.zeros(tuple(tgt[name].shape), np.float32)
             arr[: c.V_out] = v
+        elif name in ("Wyy", "Wxy"):
+            arr = np.zeros(tuple(tgt[name].shape), np.float32)
+            arr[: v.shape[0], : c.V_out] = v
         else:
             raise KeyError(name)
         tgt[name].copy_(torch.from_numpy(arr))
@@ -273,8 +299,12 @@ class Engine:
             return a[: c.H, : c.V_out].copy()
         if name == "Eout":
             return a[:, : c.H].copy()
-        if name == "bout":
+        if name in ("bout", "byy"):
             return a[: c.V_out].copy()
+        if name == "Wyy":
+            return a[:, : c.V_out].copy()
+        if name == "Wxy":
+            return a[: c.x_dim, : c.V_out].copy()
         raise KeyError(name)
 
     def set_sampler(self, thresh, alias, logq=None):
@@ -307,6 +337,10 @@ class Engine:
             x = np.zeros((n, self.Fp), np.float32)
             x[:, : rb.x.shape[1]] = rb.x
             d["x"] = torch.from_numpy(x).to(self.dev, non_blocking=True)
+        if getattr(rb, "xs", None) is not None and c.x_to_y:
+            xs = np.zeros((n, self.Fxp), np.float32)
+            xs[:, : rb.xs.shape[1]] = rb.xs
+            d["xs"] = torch.from_numpy(xs).to(self.dev, non_blocking=True)
         d["blob"] = blob
         return d
 
@@ -454,7 +488,13 @@ class Engine:
         if c.output == "full":
             Vp = self.Vp
             logits = self.buf("logits", n, Vp)
+            if c.y_to_y and Vp != c.V_out:
+                logits.zero_()                      # the row scatter of dlogits below is Vp wide
             self.gemm(1, 0, n, c.V_out, Hp, Hd, Hp, P["Wout"], Vp, logits, Vp, bias=P.get("bout"), tag="logits")
+            if c.x_to_y:
+                self.gemm(1, 0, n, c.V_out, self.Fxp, d["xs"], self.Fxp, P["Wxy"], Vp, logits, Vp, accumulate=1, tag="x_to_y")
+            if c.y_to_y:
+                call("seqrec_gather_rows", ptr(P["Wyy"]), ptr(d["ids"]), ptr(logits), n, Vp, None, ptr(P.get("byy")), 1, st)
             probs = self.buf("probs", n, c.V_out) if want_probs else None
             call("seqrec_full_softmax_ce", ptr(logits), Vp, ptr(tgt), n, c.V_out, inv, ptr(loss_rows), ptr(probs), st)
             r["dlogits"] = logits
@@ -519,6 +559,14 @@ class Engine:
                 self.gemm(0, 0, Hp, c.V_out, n, Hd, Hp, dl, Vp, Gd["Wout"], Vp, splitk=self._splitk(Hp, c.V_out, n), tag="dWout")
             if c.out_bias and tr["bout"]:
                 call("seqrec_colsum", ptr(dl), n, c.V_out, Vp, ptr(Gd["bout"]), 0, ptr(cs_ws), st)
+            if c.x_to_y and tr["Wxy"]:
+                self.gemm(0, 0, self.Fxp, c.V_out, n, d["xs"], self.Fxp, dl, Vp, Gd["Wxy"], Vp,
+                          splitk=self._splitk(self.Fxp, c.V_out, n), tag="dWxy")
+            if c.y_to_y:
+                if tr["Wyy"]:
+                    sparse_jobs.append(self._job("Wyy", d["ids"], dl, Vp, None, n, Vp, 0))
+                if c.yy_bias and tr["byy"]:
+                    call("seqrec_colsum", ptr(dl), n, c.V_out, Vp, ptr(Gd["byy"]), 0, ptr(cs_ws), st)
             self.gemm(1, 1, n, Hp, c.V_out, dl, Vp, P["Wout"], Vp, dHd, Hp, splitk=self._splitk(n, Hp, c.V_out), tag="dH")
         else:
             K = c.K
@@ -619,6 +667,9 @@ class Engine:
             call("seqrec_rows_adagrad_multi", arr, cnt, lr, eps, ptr(self.scale), st)
         if tr["U"]:
             self.upack_dirty = True
+        if c.x_to_y and c.diag_b and tr["Wxy"]:
+            # Keras applies a kernel constraint AFTER the optimizer update: w *= mask (model.py:64)
+            call("seqrec_mul", ptr(P["Wxy"]), ptr(self.diag_mask), ptr(P["Wxy"]), P["Wxy"].numel(), st)
         return self.loss_sum / n
 
     def grads(self, d, step=0, negatives=None):

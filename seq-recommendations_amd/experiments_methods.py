@@ -7,7 +7,7 @@ function names and keyword arguments, running on the HIP engine.
   evaluate_full_model         :80-88
   analyze_history             :91-97
   run_multinomial/run_markov  :100-127
-  run_model_with_recurrence   :188-249 (RNNFullModel; only the y_to_z wiring runs on the GPU)
+  run_model_with_recurrence   :188-249 (RNNFullModel, every y_to_z / y_to_y / x_to_y / x_to_z flag set)
 """
 import numpy as np
 
@@ -139,6 +139,8 @@ def run_model_with_recurrence(x_train, y_train, train_xs, x_val, y_val, val_xs, 
         results.val_loss = scores[0]
         print("train loss: %f, val loss: %f" % (results.train_loss, results.val_loss))
         return model, results
+    if y_to_y:
+        model.set_layer_weights_trainable("y_to_y_output", trainable=y_to_y_trainable)
     if train_gen is not None and val_gen is not None:
         history = run_model_with_generator(model, train_gen, val_gen, orig_seqs_lengths=orig_seqs_lengths,
                                            model_checkpoint=model_checkpoint, n_epochs=n_epochs, batch_size=batch_size,

@@ -4,10 +4,13 @@ Same class names, constructor arguments, method names and return conventions as 
 reference, so its callers (experiments_methods.py, the L5 scripts) work unchanged:
 
   RNNBaseline(timesteps, features, n_classes, ...)                     model.py:241-258
-  RNNFullModel(timesteps, x_dim, y_dim, z_dim, ..., y_to_z=True, ...)   model.py:322-403
+  RNNFullModel(timesteps, x_dim, y_dim, z_dim, ..., y_to_z, y_to_y, x_to_y, x_to_z, ...)   model.py:322-403
       -- the "ytoz" wiring (y_to_z only) is the hot path, with all three dropouts (y_to_z,
-         z_to_z = Keras recurrent_dropout, z_to_y); the x_to_y / y_to_y / x_to_z side branches
-         raise NotImplementedError
+         z_to_z = Keras recurrent_dropout, z_to_y); the side branches are dense V x V terms for the
+         reference's small vocabularies: y_to_y (row of a V x V kernel added to the logits, optionally
+         frozen at a log-transition-count initialisation), x_to_y (history features through the same
+         output Dense as z, OnlyNonZeroDiagonal re-applied after every update), x_to_z (history
+         features concatenated into the cell input).  Kernel regularizers raise NotImplementedError.
   BaseRNNModel.compile_model / fit_model / fit_generator / predict / evaluate /
       save_model_weights / load_model_weights / get_layer_weights / set_layer_weights_trainable /
       set_layer_weights / get_model_weights / get_activations              model.py:170-238
@@ -132,7 +135,8 @@ class SeqModel:
 
     def __init__(self, timesteps, in_dim, n_classes, z_dim, rnn_type, activation, rnn_name, out_name, use_bias=True,
                  out_bias=False, drop_in=0.0, drop_rec=0.0, drop_out=0.0, kernel_initializer="glorot_uniform",
-                 device="cuda:0"):
+                 device="cuda:0", y_dim=None, x_dim=0, y_to_z=True, x_to_z=False, y_to_y=False, x_to_y=False,
+                 diag_b=True, ytoy_bias=False, y_to_y_w_initializer="glorot_uniform"):
         cell = {"simpleRNN": "simplernn", "LSTM": "lstm", "GRU": "gru"}.get(rnn_type)
         if cell is None:
             raise ValueError("rnn_type must be 'simpleRNN', 'LSTM' or 'GRU' (got %r)" % (rnn_type,))
@@ -143,6 +147,14 @@ class SeqModel:
         self.use_bias, self.out_bias = use_bias, out_bias
         self.drop_in, self.drop_rec, self.drop_out = float(drop_in), float(drop_rec), float(drop_out)
         self.device = device
+        # RNNFullModel wiring (model.py:322-403): which inputs feed the cell (y_to_z / x_to_z) and
+        # which terms are added to the logits (x_to_y through the same Dense as z; y_to_y directly)
+        self.y_dim = in_dim if y_dim is None else y_dim
+        self.x_dim = x_dim
+        self.y_to_z, self.x_to_z, self.y_to_y, self.x_to_y = y_to_z, x_to_z, y_to_y, x_to_y
+        self.diag_b, self.ytoy_bias = diag_b, ytoy_bias
+        self.uses_y = y_to_y or y_to_z
+        self.uses_x = x_to_y or x_to_z
         G = {"simplernn": 1, "gru": 3, "lstm": 4}[cell]
         H = z_dim
         w = {"Wk": initialize(kernel_initializer, (in_dim, G * H)), "U": self._recurrent_init(G, H)}
@@ -151,13 +163,25 @@ class SeqModel:
             if cell == "lstm":
                 b[H:2 * H] = 1.0                       # unit_forget_bias=True
             w["b"] = b
-        w["Wout"] = initialize("glorot_uniform", (H, n_classes))
+        if x_to_y:      # ONE Dense over concat([z, x]) (model.py:375-384): glorot over the joint fan-in
+            k = initialize("glorot_uniform", (H + x_dim, n_classes))
+            w["Wout"], w["Wxy"] = k[:H].copy(), k[H:].copy()
+            if diag_b:
+                w["Wxy"] = w["Wxy"] * np.eye(x_dim, n_classes, dtype=np.float32)
+        else:
+            w["Wout"] = initialize("glorot_uniform", (H, n_classes))
         if out_bias:
             w["bout"] = np.zeros(n_classes, np.float32)
+        if y_to_y:
+            w["Wyy"] = initialize(y_to_y_w_initializer, (self.y_dim, n_classes))
+            if ytoy_bias:
+                w["byy"] = np.zeros(n_classes, np.float32)
         self.w = w
         rk = ["Wk", "U"] + (["b"] if use_bias else [])
-        ok = ["Wout"] + (["bout"] if out_bias else [])
+        ok = [("Wout+Wxy" if x_to_y else "Wout")] + (["bout"] if out_bias else [])
         self.layers = [Layer(self, rnn_name, rk), Layer(self, out_name, ok)]
+        if y_to_y:
+            self.layers.append(Layer(self, "y_to_y_output", ["Wyy"] + (["byy"] if ytoy_bias else [])))
         self.engine = None
         self.input_mode = None
         self.optimizer = None
@@ -175,10 +199,16 @@ class SeqModel:
 
     # ---- weights -------------------------------------------------------------------------------
     def _get(self, k):
+        if k == "Wout+Wxy":
+            return np.concatenate([self._get("Wout"), self._get("Wxy")], axis=0)
         return self.engine.get_param(k) if self.engine is not None else self.w[k].copy()
 
     def _set(self, k, v):
         v = np.asarray(v, dtype=np.float32)
+        if k == "Wout+Wxy":
+            self._set("Wout", v[: self.z_dim])
+            self._set("Wxy", v[self.z_dim:])
+            return
         if v.shape != self.w[k].shape:
             raise ValueError("weight %s: shape %s expected, got %s" % (k, self.w[k].shape, v.shape))
         self.w[k] = v.copy()
@@ -189,7 +219,8 @@ class SeqModel:
         if self.engine is not None:
             for l in self.layers:
                 for k in l.keys:
-                    self.engine.trainable[k] = l.trainable
+                    for kk in k.split("+"):
+                        self.engine.trainable[kk] = l.trainable
 
     def get_layer(self, name=None, index=None):
         if index is not None:
@@ -237,7 +268,9 @@ class SeqModel:
                 self.w[k] = self.engine.get_param(k)
         cfg = E.NetConfig(cell=self.cell, act=self.activation, H=self.z_dim, V_in=self.in_dim, V_out=self.n_classes,
                           input=input_mode, output="full", use_bias=self.use_bias, out_bias=self.out_bias,
-                          drop_in=self.drop_in, drop_rec=self.drop_rec, drop_out=self.drop_out, seed=self.seed)
+                          drop_in=self.drop_in, drop_rec=self.drop_rec, drop_out=self.drop_out, seed=self.seed,
+                          y_to_y=self.y_to_y, yy_bias=self.ytoy_bias, x_to_y=self.x_to_y, x_dim=self.x_dim,
+                          diag_b=self.diag_b)
         self.engine = E.Engine(cfg, self.device)
         self.input_mode = input_mode
         for k, v in self.w.items():
@@ -251,22 +284,43 @@ class SeqModel:
         return x[0] if isinstance(x, (list, tuple)) else x
 
     def _prepare(self, x, y=None):
-        """Reference tensors -> (mask, ids|None, feats|None, tgt|None, input_mode)."""
-        x = np.asarray(self._first(x))
-        if x.ndim != 3 or x.shape[2] != self.in_dim:
-            raise ValueError("expected input of shape (N, T, %d), got %s" % (self.in_dim, x.shape))
-        mask, ids, exact = batching.onehot_to_ids(x)
-        mode = "onehot" if exact else "dense"
+        """Reference tensors -> (mask, ids|None, feats|None, tgt|None, input_mode, xs|None).
+        ``x`` is the Keras input list: [y_input] and/or [x_input] in that order (model.py:398-402)."""
+        xl = list(x) if isinstance(x, (list, tuple)) else [x]
+        want = int(self.uses_y) + int(self.uses_x)
+        if len(xl) != want:
+            raise ValueError("this model takes %d input array(s), got %d" % (want, len(xl)))
+        y_in = np.asarray(xl[0]) if self.uses_y else None
+        x_in = np.asarray(xl[-1]) if self.uses_x else None
+        if y_in is not None and (y_in.ndim != 3 or y_in.shape[2] != self.y_dim):
+            raise ValueError("expected y input of shape (N, T, %d), got %s" % (self.y_dim, y_in.shape))
+        if x_in is not None and (x_in.ndim != 3 or x_in.shape[2] != self.x_dim):
+            raise ValueError("expected x input of shape (N, T, %d), got %s" % (self.x_dim, x_in.shape))
+        ids = None
+        exact = False
+        if y_in is not None:
+            mask, ids, exact = batching.onehot_to_ids(y_in)
+        else:
+            mask = np.any(x_in != 0, axis=2)
+        if self.y_to_y and not exact:
+            raise NotImplementedError("the y_to_y branch needs one-hot y inputs")
+        if self.y_to_z and not self.x_to_z:
+            feats = None if exact else y_in
+        elif self.x_to_z and not self.y_to_z:
+            feats = x_in
+        else:
+            feats = np.concatenate([y_in, x_in], axis=2)          # concatenate([masked_y, masked_x]) (model.py:354)
+        mode = "onehot" if feats is None else "dense"
         tgt = None
         if y is not None:
             y = np.asarray(y)
             tgt = y[:, :, 0].astype(np.int64) if y.shape[2] == 1 and self.n_classes != 1 else np.argmax(y, axis=2)
-        return mask, (ids if exact else None), (None if exact else x), tgt, mode
+        return mask, (ids if exact else None), feats, tgt, mode, (x_in if self.x_to_y else None)
 
     def _batch(self, prep, idx):
-        mask, ids, feats, tgt, _ = prep
+        mask, ids, feats, tgt, _, xs = prep
         rb, tcol = batching.pack_padded(mask[idx], None if ids is None else ids[idx], None if tgt is None else tgt[idx],
-                                        None if feats is None else feats[idx])
+                                        None if feats is None else feats[idx], None if xs is None else xs[idx])
         return rb, tcol
 
     # ---- Keras Model API -----------------------------------------------------------------------
@@ -508,19 +562,22 @@ class RNNFullModel(BaseRNNModel):
                  y_to_y=True, x_to_y=True, x_to_z=False, z_to_y_dropout=0.0, diag_b=True, y_to_z_dropout=0.0,
                  z_to_z_dropout=0.0):
         BaseRNNModel.__init__(self, y_dim, model_name=model_name, rnn_type=rnn_type)
-        if not y_to_z or y_to_y or x_to_y or x_to_z:
-            raise NotImplementedError(
-                "only the y_to_z ('ytoz') wiring of RNNFullModel runs on the HIP path; the y_to_y / x_to_y / x_to_z "
-                "side branches (dense VxV terms, model.py:375-392) are listed as next in DESIGN.md")
-        if out_activation != "softmax" or xz_to_y_activation != "linear":
+        if not (y_to_z or x_to_z):
+            raise ValueError("ERROR: the model needs an input into z's! either x or y should be added.")
+        if out_activation != "softmax" or xz_to_y_activation != "linear" or y_to_y_activation != "linear":
             raise NotImplementedError("output activations other than linear->softmax")
-        if toy_regularizer is not None:
-            raise NotImplementedError("toy_regularizer")
+        if toy_regularizer is not None or y_to_y_regularizer is not None:
+            raise NotImplementedError("kernel regularizers (GaussPriorRegularizer, model.py:71-91) are not implemented")
+        if y_to_y_w_initializer is None:
+            y_to_y_w_initializer = "glorot_uniform"
         # the reference passes kernel_initializer only to the LSTM (model.py:345-352)
         kinit = y_to_z_initializer if rnn_type == "LSTM" else "glorot_uniform"
-        self.model = SeqModel(timesteps, y_dim, y_dim, z_dim, rnn_type, z_to_z_activation, "z_to_z_output", "to_y_output",
+        in_dim = (y_dim if y_to_z else 0) + (x_dim if x_to_z else 0)
+        self.model = SeqModel(timesteps, in_dim, y_dim, z_dim, rnn_type, z_to_z_activation, "z_to_z_output", "to_y_output",
                               use_bias=z_bias, out_bias=toy_bias, drop_in=max(y_to_z_dropout, 0.0),
-                              drop_rec=z_to_z_dropout, drop_out=max(z_to_y_dropout, 0.0), kernel_initializer=kinit)
+                              drop_rec=z_to_z_dropout, drop_out=max(z_to_y_dropout, 0.0), kernel_initializer=kinit,
+                              y_dim=y_dim, x_dim=x_dim, y_to_z=y_to_z, x_to_z=x_to_z, y_to_y=y_to_y, x_to_y=x_to_y,
+                              diag_b=diag_b, ytoy_bias=ytoy_bias, y_to_y_w_initializer=y_to_y_w_initializer)
 
 
 class ValLossHistoryCut(Callback):

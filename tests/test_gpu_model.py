@@ -170,3 +170,106 @@ def test_val_loss_history_cut_and_generator_path():
     vgen = pre.gen_data(seqs, xs, with_xs=False, with_x=True, batch_size=30)
     h2 = em.run_model_with_generator(m, gen, vgen, n_epochs=3, batch_size=30, verbose=0)
     assert len(h2.history["loss"]) == 3 and len(h2.history["val_loss"]) == 3
+
+
+def build_xs_like_reference(seqs, V, T):
+    """datasets.build_xs (datasets.py:97-113, freq=False): indicator of the items seen so far, then the
+    FullModelPreprocessor's pairing (xs[:-1]) and pre-padding."""
+    out = np.zeros((len(seqs), T, V))
+    for b, s in enumerate(seqs):
+        seen = np.zeros(V)
+        rows = []
+        for v in s:
+            seen[v] = 1
+            rows.append(seen.copy())
+        rows = rows[:-1]
+        if rows:
+            out[b, T - len(rows):] = np.array(rows)
+    return out
+
+
+@pytest.mark.parametrize("flags", [dict(y_to_z=True, y_to_y=True, x_to_y=True, x_to_z=False),       # reference default
+                                   dict(y_to_z=True, y_to_y=True, x_to_y=False, x_to_z=False),
+                                   dict(y_to_z=True, y_to_y=False, x_to_y=True, x_to_z=True),
+                                   dict(y_to_z=False, y_to_y=True, x_to_y=False, x_to_z=True)])
+def test_full_model_side_branches_match_oracle(flags):
+    """The seven recurrent variants of experiments_server.py differ only in these flags: losses of a
+    2-epoch run (with the OnlyNonZeroDiagonal constraint re-applied after every update and a frozen or
+    trainable y_to_y kernel) against the oracle."""
+    rng = np.random.default_rng(31)
+    V, H, B = 11, 16, 40
+    vocab = {i: i for i in range(V)}
+    seqs = markov_sessions(rng, 160, V, 3, 10)
+    T = max(len(s) for s in seqs) - 1
+    pre = pp.FullModelPreprocessor(vocab, 0., T)
+    xs_lists = [[[0.0] * V for _ in s] for s in seqs]
+    x, y, _ = pre.transform_data(seqs, xs_lists)
+    xs = build_xs_like_reference(seqs, V, T)
+    np.random.seed(8)
+    logA = np.log(np.random.dirichlet(np.ones(V), size=V)).astype(np.float32)     # "log transition counts" init
+    m = model.RNNFullModel(timesteps=T, x_dim=V, y_dim=V, z_dim=H, rnn_type="LSTM", model_name="side",
+                           y_to_y_w_initializer=model.ArrayInitializer(logA), **flags)
+    w = m.model.get_weights()
+    p = {"Wk": w[0], "U": w[1], "b": w[2]}
+    i = 3
+    if flags["x_to_y"]:
+        p["Wout"], p["Wxy"] = w[i][:H].copy(), w[i][H:].copy()
+    else:
+        p["Wout"] = w[i]
+    i += 1
+    if flags["y_to_y"]:
+        p["Wyy"] = w[i]
+        np.testing.assert_array_equal(p["Wyy"], logA)
+    dense_in = flags["x_to_z"]
+    cfg = dict(cell="lstm", act="relu", input="dense" if dense_in else "onehot", output="full", use_bias=True,
+               out_bias=False, tied=False)
+    frozen = ("Wyy",) if flags["y_to_y"] and flags["x_to_y"] else ()              # the "fixed-A" variant
+    if frozen:
+        m.set_layer_weights_trainable("y_to_y_output", False)
+    mask = onehot_mask(x)
+    ids, tgt = np.argmax(x, axis=2), np.argmax(y, axis=2)
+    if dense_in:
+        feats = np.concatenate([x, xs], axis=2) if flags["y_to_z"] else xs
+    op = {k: v.copy() for k, v in p.items()}
+    acc = {k: np.zeros_like(v) for k, v in op.items()}
+    net = onn.OracleNet(cfg, op)
+
+    def ob(idx):
+        b = {"ids": ids[idx], "tgt": tgt[idx], "mask": mask[idx], "xs": xs[idx]}
+        if dense_in:
+            b["x"] = feats[idx].astype(np.float32)
+        return b
+
+    np.random.seed(3)
+    index = np.arange(len(x))
+    ref_hist = []
+    for ep in range(2):
+        np.random.shuffle(index)
+        tot = 0.0
+        for s0 in range(0, len(x), B):
+            idx = index[s0:s0 + B]
+            out = net.forward(ob(idx))
+            onn.adagrad_step(op, acc, net.backward(), lr=0.01, eps=1e-8, clipnorm=1.0, frozen=frozen)
+            if "Wxy" in op:
+                op["Wxy"] *= np.eye(V, dtype=np.float32)
+            tot += out["loss"] * len(idx)
+        ref_hist.append(tot / len(x))
+    inputs = ([x] if (flags["y_to_z"] or flags["y_to_y"]) else []) + ([xs] if (flags["x_to_y"] or flags["x_to_z"]) else [])
+    m.compile_model(optimizer=kc.Adagrad(lr=0.01, epsilon=1e-8, clipnorm=1.0))
+    np.random.seed(3)
+    h = m.fit_model(inputs, y, n_epochs=2, batch_size=B, verbose=0)
+    got = np.array(h.history["loss"])
+    assert np.all(np.abs(got - np.array(ref_hist)) <= 1e-3 * np.array(ref_hist)), (got, ref_hist)
+    if frozen:
+        np.testing.assert_array_equal(m.get_layer_weights("y_to_y_output")[0], logA)
+    if flags["x_to_y"]:
+        kxy = m.get_layer_weights("to_y_output")[0][H:]
+        assert np.count_nonzero(kxy - np.diag(np.diag(kxy))) == 0
+    # prediction parity with the oracle holding the oracle's weights
+    m.model.set_weights([op[k] if k in op else None for k in ["Wk", "U", "b"]] +
+                        [np.concatenate([op["Wout"], op["Wxy"]]) if flags["x_to_y"] else op["Wout"]] +
+                        ([op["Wyy"]] if flags["y_to_y"] else []))
+    pred = m.predict([a[:20] for a in inputs], batch_size=20)
+    ref = net.predict_dense(ob(np.arange(20)))
+    real = mask[:20]
+    np.testing.assert_allclose(pred[real], ref[real], atol=5e-6)

@@ -291,3 +291,27 @@ def test_predict_dense_pad_positions_are_softmax_of_bias():
     sb = np.exp(p["bout"] - p["bout"].max()); sb /= sb.sum()
     np.testing.assert_allclose(pr[0, 0], sb, atol=1e-14)       # leading pad: h = 0
     np.testing.assert_allclose(pr.sum(axis=2), 1.0, atol=1e-13)
+
+
+def test_finite_differences_side_branches():
+    """y_to_y (direct one-hot term), x_to_y (history features into the output Dense) and x_to_z
+    (history features concatenated into the RNN input, i.e. dense input)."""
+    rng = np.random.default_rng(21)
+    V, H = 9, 5
+    batch = pad_batch(make_sessions(rng, 6, V))
+    B, T = batch["mask"].shape
+    xs = rng.random((B, T, V)) * batch["mask"][:, :, None]
+    batch["xs"] = xs
+    cfg = cfg_of("lstm", "onehot", "full", act="tanh")
+    p = init_params(rng, cfg, V, H)
+    p["Wyy"] = rng.normal(0, 0.3, (V, V))
+    p["byy"] = rng.normal(0, 0.3, (V,))
+    p["Wxy"] = rng.normal(0, 0.3, (V, V))
+    fd_check(cfg, p, batch, {}, list(p.keys()), rng)
+    # x_to_z: the RNN input is [one-hot(y), xs] -> dense mode with F = 2V
+    cfgd = cfg_of("gru", "dense", "full", act="tanh")
+    pd = init_params(rng, cfgd, 2 * V, H)
+    pd["Wout"] = rng.normal(0, 0.3, (H, V))
+    oh = np.zeros((B, T, V)); oh[np.arange(B)[:, None], np.arange(T)[None, :], batch["ids"]] = 1.0
+    bd = dict(batch, x=np.concatenate([oh * batch["mask"][:, :, None], xs], axis=2))
+    fd_check(cfgd, pd, bd, {}, list(pd.keys()), rng)

@@ -134,8 +134,17 @@ def test_model_surface_without_gpu(tmp_path):
         np.testing.assert_array_equal(a, b_)
     base = model.RNNBaseline(9, 17, 17, rnn_type="simpleRNN", z_dim=5)
     assert [l.name for l in base.model.layers] == ["rnn", "output"] and len(base.get_layer_weights("output")) == 2
+    full = model.RNNFullModel(9, 17, 17, z_dim=10, rnn_type="LSTM")       # default flags: y_to_z + y_to_y + x_to_y
+    assert [l.name for l in full.model.layers] == ["z_to_z_output", "to_y_output", "y_to_y_output"]
+    kxy = full.get_layer_weights("to_y_output")[0]
+    assert kxy.shape == (10 + 17, 17) and np.count_nonzero(kxy[10:] - np.diag(np.diag(kxy[10:]))) == 0   # diag_b
+    assert full.get_layer_weights("y_to_y_output")[0].shape == (17, 17)
+    xz = model.RNNFullModel(9, 5, 17, z_dim=10, rnn_type="simpleRNN", x_to_z=True, y_to_y=False, x_to_y=False)
+    assert xz.get_layer_weights("z_to_z_output")[0].shape == (17 + 5, 10)
+    with pytest.raises(ValueError):
+        model.RNNFullModel(9, 17, 17, y_to_z=False, x_to_z=False)         # no input into z
     with pytest.raises(NotImplementedError):
-        model.RNNFullModel(9, 17, 17)                                     # default flags use the side branches
+        model.RNNFullModel(9, 17, 17, toy_regularizer=object())
     with pytest.raises(ValueError):
         model.RNNBaseline(9, 17, 17, rnn_type="nope")
     with pytest.raises(RuntimeError):
