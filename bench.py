@@ -40,6 +40,9 @@ CONFIGS = {
                desc="c3: |items|=1M seq_len<=50 GRU hidden=256 embed=256 sampled-softmax K=2000 batch 512/GPU"),
     "c2": dict(V=100_000, H=128, D=128, K=1000, cell="gru",
                desc="c2: |items|=100k seq_len<=50 GRU hidden=128 embed=128 sampled-softmax K=1000 batch 512/GPU"),
+    # c4's model (LSTM 512, K=4000) -- the reference's own cell type at catalogue scale
+    "c4": dict(V=1_000_000, H=512, D=512, K=4000, cell="lstm",
+               desc="c4: |items|=1M seq_len<=50 LSTM hidden=512 embed=512 sampled-softmax K=4000 batch 512/GPU"),
 }
 
 
