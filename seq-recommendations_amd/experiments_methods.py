@@ -7,13 +7,15 @@ function names and keyword arguments, running on the HIP engine.
   evaluate_full_model         :80-88
   analyze_history             :91-97
   run_multinomial/run_markov  :100-127
+  run_model_no_recurrence     :130-185 (NoRecurrenceModel: the same logit terms, no recurrent state)
   run_model_with_recurrence   :188-249 (RNNFullModel, every y_to_z / y_to_y / x_to_y / x_to_z flag set)
 """
 import numpy as np
 
 from . import utils
 from .keras_compat import Adagrad, EarlyStopping, ModelCheckpoint
-from .model import (RNNBaseline, RNNFullModel, ValLossHistoryCut, MultinomialModel, MarkovModel, ModelResults)
+from .model import (RNNBaseline, RNNFullModel, NoRecurrenceModel, ValLossHistoryCut, MultinomialModel, MarkovModel,
+                    ModelResults)
 from .preprocessor import FullModelPreprocessor, BaselinePreprocessor
 
 
@@ -101,6 +103,46 @@ def run_markov(seqs_train, val_seqs, n_classes, wrt_time=False, k=1.0):
     model = MarkovModel(n_classes, model_name="markov", order=1, k=k)
     model.fit_model(seqs_train)
     return model, _count_model_results(model, seqs_train, val_seqs, wrt_time, "Markov")
+
+
+def run_model_no_recurrence(x_train, y_train, train_xs, x_val, y_val, val_xs, vocab, timesteps=None, x_dim=None, y_dim=None,
+                            train_gen=None, val_gen=None, orig_seqs_lengths=None, wrt_time=False, read_file=None,
+                            model_checkpoint=False, early_stopping=False, n_epochs=50, batch_size=10, y_to_y_trainable=True,
+                            y_to_y_w_initializer=None, y_to_y_regularizer=None, verbose=1, model_name="test_model",
+                            connect_x=True, connect_y=True, mask_value=0.0, lr=0.01, xy_bias=False, y_bias=False,
+                            embed_y=False, z_dim=10, diag_b=True, loss="categorical_crossentropy"):
+    """experiments_methods.py:130-185."""
+    timesteps = x_train.shape[1] if timesteps is None else timesteps
+    x_dim = x_train.shape[2] if x_dim is None else x_dim
+    y_dim = x_train.shape[2] if y_dim is None else y_dim
+    model = NoRecurrenceModel(timesteps=timesteps, x_dim=x_dim, y_dim=y_dim, model_name=model_name,
+                              y_to_y_w_initializer=y_to_y_w_initializer, y_bias=y_bias, xy_bias=xy_bias, connect_x=connect_x,
+                              y_to_y_regularizer=y_to_y_regularizer, connect_y=connect_y, embed_y=embed_y, z_dim=z_dim,
+                              diag_b=diag_b, mask_value=mask_value)
+    if connect_x and connect_y:
+        train, validation = [x_train, train_xs], [x_val, val_xs]
+    elif connect_x:
+        train, validation = [train_xs], [val_xs]
+    else:
+        train, validation = [x_train], [x_val]
+    if read_file:
+        model.compile_model(loss=loss, metrics=[], optimizer=Adagrad(lr=lr, epsilon=1e-08, decay=0.0, clipnorm=1.))
+        model.load_model_weights(read_file)
+        results = ModelResults()
+        results.train_loss = model.evaluate(train, y_train, batch_size=batch_size)[1][0]
+        results.val_loss = model.evaluate(validation, y_val, batch_size=batch_size)[1][0]
+        return model, results
+    if connect_y:
+        model.set_layer_weights_trainable("y_output", trainable=y_to_y_trainable)
+    if train_gen is not None and val_gen is not None:
+        history = run_model_with_generator(model, train_gen, val_gen, model_checkpoint=model_checkpoint, n_epochs=n_epochs,
+                                           batch_size=batch_size, verbose=verbose, early_stopping=early_stopping,
+                                           wrt_time=wrt_time, loss=loss, lr=lr)
+    else:
+        history = run_model(model, train, y_train, validation_data=(validation, y_val), orig_seqs_lengths=orig_seqs_lengths,
+                            model_checkpoint=model_checkpoint, n_epochs=n_epochs, batch_size=batch_size, verbose=verbose,
+                            early_stopping=early_stopping, wrt_time=wrt_time, loss=loss, lr=lr)
+    return model, analyze_history(history)
 
 
 def run_model_with_recurrence(x_train, y_train, train_xs, x_val, y_val, val_xs, vocab, timesteps=None, x_dim=None,

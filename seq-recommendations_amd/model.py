@@ -220,7 +220,7 @@ class SeqModel:
             for l in self.layers:
                 for k in l.keys:
                     for kk in k.split("+"):
-                        self.engine.trainable[kk] = l.trainable
+                        self.engine.trainable[kk] = l.trainable and kk not in getattr(self, "frozen_keys", ())
 
     def get_layer(self, name=None, index=None):
         if index is not None:
@@ -552,6 +552,41 @@ class RNNBaseline(BaseRNNModel):
         rnn_name = {"simpleRNN": "rnn", "LSTM": "lstm", "GRU": "gru"}.get(rnn_type, "rnn")
         self.model = SeqModel(timesteps, features, n_classes, z_dim, rnn_type, z_activation, rnn_name, "output",
                               use_bias=True, out_bias=True, drop_out=z_to_y_drop)
+
+
+class NoRecurrenceModel(BaseRNNModel):
+    """model.py:264-319: softmax(B x_t + A y_{t-1} (+ c)) -- the same logit terms as RNNFullModel's
+    y_to_y / x_to_y branches with no recurrent state.  Runs on the same engine with the cell's
+    weights frozen at zero (h == 0, so the z -> y Dense contributes nothing and receives no
+    gradient); ``embed_y`` (a rank-z_dim factorisation of A) is not implemented."""
+
+    def __init__(self, timesteps, x_dim, y_dim, model_name="y_to_y_model", y_to_y_activation="linear",
+                 x_to_y_activation="linear", y_to_y_w_initializer=None, out_activation="softmax", mask_value=0.0,
+                 y_bias=False, xy_bias=False, y_to_y_regularizer=None, z_dim=10, z_bias=True, connect_x=True,
+                 connect_y=True, embed_y=False, diag_b=True):
+        BaseRNNModel.__init__(self, y_dim, model_name=model_name, rnn_type=None)
+        if not (connect_x or connect_y):
+            raise ValueError("ERROR: the model needs an input! either x or y should be added.")
+        if embed_y:
+            raise NotImplementedError("embed_y (Dense(z_dim) before the y -> y Dense) is not implemented")
+        if y_to_y_regularizer is not None or mask_value != 0.0:
+            raise NotImplementedError("kernel regularizers / non-zero mask values")
+        if out_activation != "softmax" or y_to_y_activation != "linear" or x_to_y_activation != "linear":
+            raise NotImplementedError("output activations other than linear->softmax")
+        if y_to_y_w_initializer is None:
+            y_to_y_w_initializer = "random_uniform"
+        m = SeqModel(timesteps, y_dim if connect_y else x_dim, y_dim, 8, "simpleRNN", "relu", "unused_rnn", "x_to_y_output",
+                     use_bias=False, out_bias=xy_bias, y_dim=y_dim, x_dim=x_dim, y_to_z=connect_y, x_to_z=not connect_y,
+                     y_to_y=connect_y, x_to_y=connect_x, diag_b=diag_b, ytoy_bias=y_bias,
+                     y_to_y_w_initializer=y_to_y_w_initializer)
+        # no recurrent path: zero, frozen cell and zero z -> y kernel
+        for k in ("Wk", "U", "Wout"):
+            m.w[k] = np.zeros_like(m.w[k])
+        m.layers[0].trainable = False
+        m.frozen_keys = {"Wout"}
+        if connect_y:
+            m.get_layer("y_to_y_output").name = "y_output"
+        self.model = m
 
 
 class RNNFullModel(BaseRNNModel):

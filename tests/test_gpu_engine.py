@@ -168,3 +168,19 @@ def test_sharded_engine_single_rank_equals_oracle():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_sharded_engine_two_ranks_one_gpu_vs_global_oracle():
+    """Two processes share cuda:0 (collectives staged through gloo) and train the row-sharded model
+    for two steps; rank 0 checks global loss, replicated weights and every table shard against the
+    oracle run on the global model with the same stratified negatives (tests/dist_gpu_worker.py)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29641", os.path.join(here, "dist_gpu_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
+    assert r.stdout.count("case ok") == 2 and r.stdout.count("rank") >= 2

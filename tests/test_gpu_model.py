@@ -273,3 +273,65 @@ def test_full_model_side_branches_match_oracle(flags):
     ref = net.predict_dense(ob(np.arange(20)))
     real = mask[:20]
     np.testing.assert_allclose(pred[real], ref[real], atol=5e-6)
+
+
+@pytest.mark.parametrize("connect_x,connect_y", [(True, True), (False, True), (True, False)])
+def test_no_recurrence_model_matches_oracle(connect_x, connect_y):
+    """NoRecurrenceModel (model.py:264-319) = the y_to_y / x_to_y logit terms without a cell."""
+    rng = np.random.default_rng(41)
+    V, B = 9, 30
+    vocab = {i: i for i in range(V)}
+    seqs = markov_sessions(rng, 90, V, 3, 9)
+    T = max(len(s) for s in seqs) - 1
+    pre = pp.FullModelPreprocessor(vocab, 0., T)
+    x, y, _ = pre.transform_data(seqs, [[[0.0] * V for _ in s] for s in seqs])
+    xs = build_xs_like_reference(seqs, V, T)
+    np.random.seed(12)
+    m = model.NoRecurrenceModel(T, V, V, connect_x=connect_x, connect_y=connect_y, y_bias=True)
+    w = m.model.get_weights()
+    H = 8
+    op = {"Wk": w[0], "U": w[1]}
+    if connect_x:
+        op["Wout"], op["Wxy"] = w[2][:H].copy(), w[2][H:].copy()
+    else:
+        op["Wout"] = w[2]
+    if connect_y:
+        op["Wyy"], op["byy"] = w[3], w[4]
+    assert not op["Wk"].any() and not op["U"].any() and not op["Wout"].any()
+    dense_in = not connect_y
+    cfg = dict(cell="simplernn", act="relu", input="dense" if dense_in else "onehot", output="full", use_bias=False,
+               out_bias=False, tied=False)
+    frozen = ("Wk", "U", "Wout")
+    acc = {k: np.zeros_like(v) for k, v in op.items()}
+    net = onn.OracleNet(cfg, op)
+    mask = onehot_mask(x) if connect_y else np.any(xs != 0, axis=2)
+    ids, tgt = np.argmax(x, axis=2), np.argmax(y, axis=2)
+
+    def ob(idx):
+        b = {"ids": ids[idx], "tgt": tgt[idx], "mask": mask[idx], "xs": xs[idx]}
+        if dense_in:
+            b["x"] = xs[idx].astype(np.float32)
+        return b
+
+    np.random.seed(6)
+    index = np.arange(len(x))
+    ref = []
+    for ep in range(2):
+        np.random.shuffle(index)
+        tot = 0.0
+        for s0 in range(0, len(x), B):
+            idx = index[s0:s0 + B]
+            out = net.forward(ob(idx))
+            onn.adagrad_step(op, acc, net.backward(), lr=0.05, eps=1e-8, clipnorm=1.0, frozen=frozen)
+            if "Wxy" in op:
+                op["Wxy"] *= np.eye(V, dtype=np.float32)
+            tot += out["loss"] * len(idx)
+        ref.append(tot / len(x))
+    inputs = ([x] if connect_y else []) + ([xs] if connect_x else [])
+    m.compile_model(optimizer=kc.Adagrad(lr=0.05, epsilon=1e-8, clipnorm=1.0))
+    np.random.seed(6)
+    h = m.fit_model(inputs, y, n_epochs=2, batch_size=B, verbose=0)
+    got = np.array(h.history["loss"])
+    assert np.all(np.abs(got - np.array(ref)) <= 1e-3 * np.array(ref)), (got, ref)
+    assert got[1] < got[0]
+    assert not m.get_layer_weights("unused_rnn")[0].any()           # the frozen zero cell stayed zero
