@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""GEMM kernel micro-benchmark (developer tool, GPU box)."""
+import importlib, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+L = importlib.import_module("seq-recommendations_amd._lib")
+ptr, call = L.ptr, L.call
+st = torch.cuda.current_stream().cuda_stream
+shapes = [(4096, 4096, 4096, 1, 0, 1), (8192, 8192, 1024, 1, 0, 1), (2546, 2000, 256, 1, 1, 1), (2546, 256, 2000, 1, 0, 4),
+          (2000, 256, 2546, 0, 0, 4), (2546, 768, 256, 1, 0, 1), (256, 768, 2546, 0, 0, 11), (25088, 2000, 256, 1, 1, 1)]
+for (M, N, K, akc, bkc, sk) in shapes:
+    A = torch.randn((M, K) if akc else (K, M), device="cuda")
+    B = torch.randn((N, K) if bkc else (K, N), device="cuda")
+    C = torch.empty(M, N, device="cuda")
+    ws = torch.empty(max(1, sk * M * N), device="cuda") if sk > 1 else None
+    def f(): call("seqrec_gemm_f32", akc, bkc, M, N, K, ptr(A), K if akc else M, ptr(B), K if bkc else N, ptr(C), N, None, 0, sk, ptr(ws), st)
+    f(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 20
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1000 / n
+    print("M=%5d N=%5d K=%5d akc=%d bkc=%d splitk=%2d : %8.1f us  %6.1f TFLOP/s" % (M, N, K, akc, bkc, sk, us, 2.0 * M * N * K / us / 1e6))
