@@ -101,6 +101,7 @@ def kernel_model(cfgd, n_tok, K, B):
         "seqrec_gemm_f32[dW]": ("mfma", 2.0 * n_tok * D * G * H),
         "seqrec_gemm_f32[dX]": ("mfma", 2.0 * n_tok * D * G * H),
         "seqrec_gemm_f32[dU]": ("mfma", 2.0 * n_tok * H * G * H / (2 if G == 3 else 1)),   # GRU: two launches
+        "seqrec_gemm_f32_grouped[dW+dU]": ("mfma", 2.0 * n_tok * G * H * (D + H)),          # dW and dU in one launch
         "seqrec_gather_rows[E]": ("hbm", 8.0 * D * n_tok),                                   # 4 B read + 4 B written / elt
     }
     return m
@@ -131,6 +132,11 @@ def pmc_traffic(kernel, t_mean, a):
 
 def main():
     a = parse()
+    # stdout carries exactly ONE line (the JSON): everything libraries print while we run (RCCL's
+    # version banner, warnings) is sent to stderr by pointing fd 1 at fd 2 until the final print.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -283,7 +289,10 @@ def main():
             "tokens_per_s": round(tokens_per_s, 1), "final_loss": round(last_loss, 5), "recall_at_20": recall,
             "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -66,6 +66,18 @@ int seqrec_gemm_f32(int a_kcontig, int b_kcontig, int64_t M, int64_t N, int64_t 
                     float* C, int64_t ldc, const float* bias, int accumulate,
                     int splitk, float* workspace, void* stream);
 int64_t seqrec_gemm_workspace_floats(int64_t M, int64_t N, int splitk);
+/*      grouped form: up to 4 independent problems that share the layout flags, K and the split count
+ *      in ONE launch (the weight-gradient GEMMs dW / dU all reduce over K = N_tok).
+ *      workspace (splitk > 1): sum_i splitk * M_i * N_i floats. */
+typedef struct seqrec_gemm_desc {
+    int64_t M, N, K;
+    const float* A; int64_t lda;
+    const float* B; int64_t ldb;
+    float* C; int64_t ldc;
+    const float* bias; int32_t accumulate;
+} seqrec_gemm_desc;
+int seqrec_gemm_f32_grouped(int count, int a_kcontig, int b_kcontig, const seqrec_gemm_desc* descs_host,
+                            int splitk, float* workspace, void* stream);
 
 /* ---- recurrent scan over the ragged batch (Keras K.rnn under Masking).
  *      H must be 64, 128, 256 or 512 (callers zero-pad); H_real <= H are the live units.

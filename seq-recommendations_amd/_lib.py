@@ -38,6 +38,7 @@ _SIGS = {
     "seqrec_gather_rows": [P, P, P, L, I, P, P, I, P],
     "seqrec_gemm_f32": [I, I, L, L, L, P, L, P, L, P, L, P, I, I, P, P],
     "seqrec_gemm_workspace_floats": [L, L, I],
+    "seqrec_gemm_f32_grouped": [I, I, I, P, I, P, P],
     "seqrec_rnn_upack_floats": [I, I],
     "seqrec_rnn_pack_u": [I, I, P, P, P],
     "seqrec_rnn_fwd": [I, I, I, I, I, I, P, P, P, P, P, P, P],
@@ -93,6 +94,22 @@ def rows_jobs(jobs):
             setattr(arr[i], k, None if t is None else t.data_ptr())
         arr[i].ldv, arr[i].n, arr[i].width, arr[i].base = int(j["ldv"]), int(j["n"]), int(j["width"]), int(j["base"])
     return arr, len(jobs)
+
+
+class GemmDesc(C.Structure):
+    """seqrec_gemm_desc (include/seqrec_hip.h)."""
+    _fields_ = [("M", L), ("N", L), ("K", L), ("A", P), ("lda", L), ("B", P), ("ldb", L), ("C", P), ("ldc", L),
+                ("bias", P), ("accumulate", C.c_int32)]
+
+
+def gemm_descs(items):
+    """items: list of (M, N, K, A, lda, B, ldb, C, ldc) with torch tensors -> ctypes array."""
+    arr = (GemmDesc * len(items))()
+    for i, (M, N, K, A, lda, B, ldb, Cm, ldc) in enumerate(items):
+        arr[i].M, arr[i].N, arr[i].K = int(M), int(N), int(K)
+        arr[i].A, arr[i].lda, arr[i].B, arr[i].ldb = A.data_ptr(), int(lda), B.data_ptr(), int(ldb)
+        arr[i].C, arr[i].ldc, arr[i].bias, arr[i].accumulate = Cm.data_ptr(), int(ldc), None, 0
+    return arr
 
 
 def ptr_array(tensors):

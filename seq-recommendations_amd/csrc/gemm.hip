@@ -81,7 +81,7 @@ __device__ __forceinline__ void store_tile4(float* __restrict__ S, int idx, floa
 }
 
 template <int BM, int BN, int BKT, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int tile, const int zsplit, const int nsplits) {
     constexpr int LDA = BM + 2, LDB = BN + 2;
     constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 MFMA tiles per wave
     constexpr int NA = BM * BKT / 1024, NB = BN * BKT / 1024;     // float4 loads per thread per operand
@@ -90,9 +90,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile = blockIdx.x;
     const long m0 = (long)(tile / g.tiles_n) * BM, n0 = (long)(tile % g.tiles_n) * BN;
-    const long kbeg = (long)blockIdx.z * g.k_per_split;
+    const long kbeg = (long)zsplit * g.k_per_split;
     const long kend = min(g.K, kbeg + g.k_per_split);
     const int nk = (int)((kend - kbeg + BKT - 1) / BKT);
 
@@ -175,8 +174,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         return;
     }
     // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float* Cb = g.C + (long)blockIdx.z * g.M * g.ldc;   // split-K slabs use ldc = N
-    const bool splits = gridDim.z > 1;
+    float* Cb = g.C + (long)zsplit * g.M * g.ldc;   // split-K slabs use ldc = N
+    const bool splits = nsplits > 1;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -195,6 +194,35 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
                 }
             }
         }
+}
+
+template <int BM, int BN, int BKT, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+    gemm_tile_body<BM, BN, BKT, A_KC, B_KC>(g, blockIdx.x, blockIdx.z, gridDim.z);
+}
+
+// grouped launch: blockIdx.y picks one of up to 4 independent problems of the same layout
+struct GemmGroup { GemmArgs g[4]; int ntiles[4]; };
+template <int BM, int BN, int BKT, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(GemmGroup gg) {
+    const int p = blockIdx.y;
+    if ((int)blockIdx.x >= gg.ntiles[p]) return;
+    gemm_tile_body<BM, BN, BKT, A_KC, B_KC>(gg.g[p], blockIdx.x, blockIdx.z, gridDim.z);
+}
+
+struct ReduceGroup { const float* ws[4]; float* C[4]; const float* bias[4]; long M[4], N[4], ldc[4]; int accumulate[4]; };
+__global__ void splitk_reduce_grouped_kernel(ReduceGroup r, int splits) {
+    const int p = blockIdx.y;
+    const long total = r.M[p] * r.N[p];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < splits; ++z) s += r.ws[p][(long)z * total + i];
+        const long row = i / r.N[p], col = i % r.N[p];
+        if (r.bias[p]) s += r.bias[p][col];
+        float* o = r.C[p] + row * r.ldc[p] + col;
+        if (r.accumulate[p]) s += *o;
+        *o = s;
+    }
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long M, long N,
@@ -319,4 +347,50 @@ extern "C" int seqrec_rank_count(const float* hd, int H, const float* Eout, cons
     g.b_vec = ((reinterpret_cast<uintptr_t>(Eout) & 15) == 0) && (H % 4 == 0);
     g.epi = 1; g.tgt = tgt; g.thr = thr_workspace; g.rank = rank;
     return launch_gemm<128, 128>(1, 1, g, 1, st);
+}
+
+// ---- grouped form: up to 4 problems with the same layout flags and split count in ONE launch
+// (used for the weight gradients dW, dU_zr, dU_h that share K = N_tok)
+extern "C" int seqrec_gemm_f32_grouped(int count, int a_kcontig, int b_kcontig, const seqrec_gemm_desc* d,
+                                       int splitk, float* workspace, void* stream) {
+    if (count < 1 || count > 4 || !d || splitk < 1) return SEQREC_E_ARG;
+    hipStream_t st = as_stream(stream);
+    GemmGroup gg = {};
+    ReduceGroup rg = {};
+    long K = d[0].K, maxtiles = 0, wsoff = 0;
+    long kps = (K + splitk - 1) / splitk;
+    kps = (kps + 31) / 32 * 32;
+    if (kps == 0) kps = 32;
+    const int splits = (int)((K + kps - 1) / kps) < 1 ? 1 : (int)((K + kps - 1) / kps);
+    if (splits > 1 && !workspace) return SEQREC_E_ARG;
+    for (int i = 0; i < count; ++i) {
+        if (d[i].K != K || d[i].M <= 0 || d[i].N <= 0 || !d[i].A || !d[i].B || !d[i].C) return SEQREC_E_ARG;
+        GemmArgs& g = gg.g[i];
+        g.A = d[i].A; g.B = d[i].B; g.bias = splits > 1 ? nullptr : d[i].bias;
+        g.M = d[i].M; g.N = d[i].N; g.K = K; g.lda = d[i].lda; g.ldb = d[i].ldb;
+        g.accumulate = d[i].accumulate;
+        g.epi = 0; g.tgt = nullptr; g.thr = nullptr; g.rank = nullptr;
+        g.a_vec = ((reinterpret_cast<uintptr_t>(d[i].A) & 15) == 0) && (d[i].lda % 4 == 0);
+        g.b_vec = ((reinterpret_cast<uintptr_t>(d[i].B) & 15) == 0) && (d[i].ldb % 4 == 0);
+        g.k_per_split = kps;
+        const long tm = (g.M + 63) / 64, tn = (g.N + 63) / 64;
+        g.tiles_n = (int)tn;
+        gg.ntiles[i] = (int)(tm * tn);
+        if (tm * tn > maxtiles) maxtiles = tm * tn;
+        if (splits > 1) { g.C = workspace + wsoff; g.ldc = g.N; } else { g.C = d[i].C; g.ldc = d[i].ldc; }
+        rg.ws[i] = workspace + wsoff; rg.C[i] = d[i].C; rg.bias[i] = d[i].bias; rg.M[i] = g.M; rg.N[i] = g.N;
+        rg.ldc[i] = d[i].ldc; rg.accumulate[i] = d[i].accumulate;
+        wsoff += (long)splits * g.M * g.N;
+    }
+    dim3 grid((unsigned)maxtiles, (unsigned)count, (unsigned)splits), block(256);
+    if (a_kcontig && b_kcontig) hipLaunchKernelGGL((gemm_f32_grouped_kernel<64, 64, 16, true, true>), grid, block, 0, st, gg);
+    else if (a_kcontig && !b_kcontig) hipLaunchKernelGGL((gemm_f32_grouped_kernel<64, 64, 16, true, false>), grid, block, 0, st, gg);
+    else if (!a_kcontig && b_kcontig) hipLaunchKernelGGL((gemm_f32_grouped_kernel<64, 64, 16, false, true>), grid, block, 0, st, gg);
+    else hipLaunchKernelGGL((gemm_f32_grouped_kernel<64, 64, 16, false, false>), grid, block, 0, st, gg);
+    SEQREC_LAUNCH_CHECK();
+    if (splits > 1) {
+        hipLaunchKernelGGL(splitk_reduce_grouped_kernel, dim3(256, count), dim3(256), 0, st, rg, splits);
+        SEQREC_LAUNCH_CHECK();
+    }
+    return 0;
 }

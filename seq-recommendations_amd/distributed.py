@@ -135,8 +135,25 @@ class ShardedEngine(Engine):
 
     def set_sampler(self, thresh, alias, logq=None):
         """Shard-LOCAL alias table (proposal restricted to this rank's rows) and the log of the
-        EFFECTIVE proposal Q(v) = Q_shard(v) / R for the local rows."""
+        EFFECTIVE proposal Q(v) = Q_shard(v) / R for the local rows.  The per-item log-Q values are
+        then replicated (V floats) so that no step needs a log-Q exchange."""
         Engine.set_sampler(self, thresh, alias, logq)
+        self.logq_global = None
+        if logq is not None:
+            R = self.R
+            mine = self.sampler[2]
+            nmax = shard_size(self.V_global, 0, R)
+            pad = torch.zeros(nmax, dtype=torch.float32, device=self.dev)
+            pad[: mine.numel()] = mine
+            allq = [torch.empty_like(pad) for _ in range(R)]
+            if R > 1:
+                self.dist.all_gather(allq, pad, group=self.group)
+            else:
+                allq = [pad]
+            g = torch.zeros(self.V_global, dtype=torch.float32, device=self.dev)
+            for j in range(R):
+                g[j::R] = allq[j][: shard_size(self.V_global, j, R)]
+            self.logq_global = g
 
     def upload(self, rb):
         d = Engine.upload(self, rb)
@@ -145,6 +162,8 @@ class ShardedEngine(Engine):
         nt = torch.tensor([d["n"]], dtype=torch.float64, device=self.dev)
         self.dist.all_reduce(nt, group=self.group)
         d["n_total"] = float(nt.item())
+        if self.cfg.logq and self.logq_global is not None:
+            d["lq_tgt"] = self.logq_global[d["tgt"].long()]         # fixed per batch
         return d
 
     # ---- one training step ----------------------------------------------------------------------------
@@ -165,13 +184,15 @@ class ShardedEngine(Engine):
         th, al, lq = self.sampler
         negl = self.buf("negl", R * Kr, dtype=torch.int32)             # local rows I draw for every requester
         call("seqrec_sample_negatives", int(c.seed), int(step) * R + self.rank, R * Kr, ptr(th), ptr(al), c.V_out, ptr(negl), st)
-        rows_out = self._take(P[tname], negl).view(R, Kr, Hp)
-        ids_out = (negl.long() * R + self.rank).to(torch.int32).view(R, Kr)   # global ids of my draws
-        Eneg = self.ex.swap_fixed(rows_out).view(K, Hp)
-        neg = self.ex.swap_fixed(ids_out).view(K)
-        lq_neg = None
-        if c.logq:
-            lq_neg = self.ex.swap_fixed(lq[negl.long()].view(R, Kr)).view(K)
+        # rows and their global ids travel together: [R, Kr, Hp + 1] with the id bit-cast into the last column
+        ids_out = (negl.long() * R + self.rank).to(torch.int32)                # global ids of my draws
+        pay = torch.empty((R * Kr, Hp + 1), dtype=torch.float32, device=self.dev)
+        pay[:, :Hp] = self._take(P[tname], negl)
+        pay[:, Hp] = ids_out.view(torch.float32)
+        got = self.ex.swap_fixed(pay.view(R, Kr, Hp + 1)).view(K, Hp + 1)
+        Eneg = got[:, :Hp].contiguous()
+        neg = got[:, Hp].contiguous().view(torch.int32)
+        lq_neg = self.logq_global[neg.long()] if c.logq else None
         XW = self.buf("XW", n, GHp)
         self.gemm(1, 0, n, GHp, Dp, X, Dp, P["W"], GHp, XW, GHp, bias=P.get("b"), tag="xw")
         Hout = self.buf("Hout", n, Hp); gates = self.buf("gates", n, GHp); aux = self.buf("aux", n, Hp)
@@ -185,9 +206,7 @@ class ShardedEngine(Engine):
         loss_rows = self.buf("loss_rows", n)
         ar = self.buf("arange", n, dtype=torch.int32)
         ar.copy_(torch.arange(n, device=self.dev, dtype=torch.int32))
-        lq_tgt = None
-        if c.logq:
-            lq_tgt = self.ex.fetch(d["plan_tgt"], lambda idx: lq[idx.long()].view(-1, 1), 1, self._take).view(n)
+        lq_tgt = d.get("lq_tgt")
         call("seqrec_sampled_softmax_ce_rows", ptr(ln), K, ptr(Hd), Hp, ptr(Etgt), ptr(lq_tgt), ptr(lq_neg), ptr(d["tgt"]),
              ptr(neg), n, K, inv, ptr(loss_rows), ptr(dlt), st)
         call("seqrec_reduce_sum", ptr(loss_rows), n, ptr(self.loss_sum), 0, st)

@@ -549,6 +549,7 @@ class Engine:
         Gd, Gt = self.Gd, self.Gt
         tr = self.trainable
         sparse_jobs = []     # scatter lists of this step (see _job)
+        wgrad = []           # deferred weight-gradient GEMMs (M, N, K, A, lda, B, ldb, C, ldc), launched grouped
         forked = False
         dHd = self.buf("dHd", n, Hp)
         cs_ws = self.buf("colsum_ws", 64 * max(GHp, self.Vp, c.K if c.output == "sampled" else 1))
@@ -621,10 +622,10 @@ class Engine:
                     self.gemm(0, 0, Hp, Hp, n, Am, Hp, dPre[:, g * Hp:], GHp, Gd["U"][:, g * Hp:], GHp,
                               splitk=self._splitk(Hp, Hp, n), tag="dU")
             elif c.cell == "gru":
-                self.gemm(0, 0, Hp, 2 * Hp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp, splitk=sk, tag="dU")
-                self.gemm(0, 0, Hp, Hp, n, r["aux"], Hp, dPre[:, 2 * Hp:], GHp, Gd["U"][:, 2 * Hp:], GHp, splitk=sk, tag="dU")
+                wgrad.append((Hp, 2 * Hp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp))
+                wgrad.append((Hp, Hp, n, r["aux"], Hp, dPre[:, 2 * Hp:], GHp, Gd["U"][:, 2 * Hp:], GHp))
             else:
-                self.gemm(0, 0, Hp, GHp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp, splitk=sk, tag="dU")
+                wgrad.append((Hp, GHp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp))
         if c.input == "onehot":
             if tr["Wk"]:
                 sparse_jobs.append(self._job("Wk", d["ids"], dPre, GHp, drops.get("in"), n, GHp, 0))
@@ -633,7 +634,7 @@ class Engine:
             Kd = X.shape[1]
             wname = "W" if c.input == "embed" else "Wk"
             if tr[wname]:
-                self.gemm(0, 0, Kd, GHp, n, X, Kd, dPre, GHp, Gd[wname], GHp, splitk=self._splitk(Kd, GHp, n), tag="dW")
+                wgrad.append((Kd, GHp, n, X, Kd, dPre, GHp, Gd[wname], GHp))
             if c.input == "embed" and tr["E"]:
                 dX = self.buf("dX", n, self.Dp)
                 self.gemm(1, 1, n, self.Dp, GHp, dPre, GHp, P["W"], GHp, dX, self.Dp, splitk=self._splitk(n, self.Dp, GHp), tag="dX")
@@ -641,6 +642,13 @@ class Engine:
                     call("seqrec_mul", ptr(dX), ptr(drops["in"]), ptr(dX), n * self.Dp, st)
                 base_i = (n + c.K) if c.tied else 0
                 sparse_jobs.append(self._job("E", d["ids"], dX, self.Dp, None, n, self.Dp, base_i))
+        if wgrad:
+            # the weight gradients A^T . dPre all reduce over the tokens: one grouped split-K launch
+            tiles = sum(((m + 63) // 64) * ((nn_ + 63) // 64) for (m, nn_, *_rest) in wgrad)
+            sk = int(max(1, min(32, -(-512 // max(tiles, 1)), n // 128)))
+            wsz = sum(sk * m * nn_ for (m, nn_, *_rest) in wgrad)
+            wsp = self.buf("gemm_ws", wsz) if sk > 1 else None
+            call("seqrec_gemm_f32_grouped", len(wgrad), 0, 0, _lib.gemm_descs(wgrad), sk, ptr(wsp), st, tag="dW+dU")
         if forked:
             torch.cuda.current_stream(self.dev).wait_event(self.ev_join)
         # ---- row-sparse contributions: one launch for (up to 4) scatter lists

@@ -40,6 +40,12 @@ class CpuStagedDist:
         dist.all_reduce(c)
         t.copy_(c)
 
+    def all_gather(self, outs, t, group=None):
+        cs = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+        dist.all_gather(cs, t.detach().cpu())
+        for o, c in zip(outs, cs):
+            o.copy_(c)
+
     def barrier(self):
         dist.barrier()
 
