@@ -164,12 +164,19 @@ int seqrec_mul(const float* x, const float* m, float* y, int64_t n, void* stream
 /* ---- fill n floats / n int32 */
 int seqrec_fill_f32(float* x, float v, int64_t n, void* stream);
 int seqrec_fill_i32(int32_t* x, int32_t v, int64_t n, void* stream);
+/*      dst[dst_pos ? dst_pos[i] : i] = src[src_pos ? src_pos[i] : i] * mul + add   (int32; an entry with a
+ *      negative position is skipped).  Index plumbing of the row exchange (distributed.py): places the
+ *      per-step negative draws into the batch's routing lists and moves item ids through float
+ *      buffers bit-exactly (no float arithmetic ever touches them). */
+int seqrec_index_affine_i32(int32_t* dst, const int32_t* dst_pos, const int32_t* src, const int32_t* src_pos,
+                            int64_t n, int32_t mul, int32_t add, void* stream);
 
 /* ---- row-sparse gradient path for the item tables (E, Eout, Wk, bout) -- the exact sparse
  *      equivalent of Keras' dense Adagrad (experiments_methods.py:41): a row with zero gradient is
  *      left untouched by the dense rule.  `gtab` is a table-shaped gradient accumulator that is all
  *      zero between steps; `slot` (int32[rows of table], all INT32_MAX between steps) elects one
  *      owner per touched row (the smallest contribution index).
+ *      A contribution with rows[i] < 0 is a filler and is ignored by all three kernels.
  *      scatter_add: gtab[rows[i],:] += vals[i,:] * (row_scale ? row_scale[i] : 1)  (float atomics),
  *                   slot[rows[i]] = min(slot[rows[i]], base + i)
  *      sqnorm:      partial[blockIdx] = sum over owned rows of |gtab[row,:]|^2  (added to sq_accum)

@@ -55,6 +55,7 @@ _SIGS = {
     "seqrec_mul": [P, P, P, L, P],
     "seqrec_fill_f32": [P, F, L, P],
     "seqrec_fill_i32": [P, I, L, P],
+    "seqrec_index_affine_i32": [P, P, P, P, L, I, I, P],
     "seqrec_rows_scatter_add": [P, P, P, P, L, P, L, I, I, P],
     "seqrec_rows_sqnorm": [P, P, P, L, I, I, P, P],
     "seqrec_rows_adagrad": [P, P, P, P, P, L, I, I, F, F, P, P],

@@ -189,6 +189,7 @@ __global__ void rows_scatter_add_kernel(float* __restrict__ gtab, int* __restric
     const long i = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= n) return;
     const int r = rows[i];
+    if (r < 0) return;                              // filler contribution (wave-uniform)
     const float s = row_scale ? row_scale[i] : 1.f;
     float* g = gtab + (long)r * width;
     const float* v = vals + i * ldv;
@@ -204,7 +205,7 @@ __global__ void rows_sqnorm_kernel(const float* __restrict__ gtab, const int* __
     float s = 0.f;
     if (i < n) {
         const int r = rows[i];
-        if (slot[r] == base + (int)i) {
+        if (r >= 0 && slot[r] == base + (int)i) {
             const float* g = gtab + (long)r * width;
             for (int c = lane; c < width; c += 64) s += g[c] * g[c];
         }
@@ -226,7 +227,7 @@ __global__ void rows_adagrad_kernel(float* __restrict__ table, float* __restrict
     const long i = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= n) return;
     const int r = rows[i];
-    if (slot[r] != base + (int)i) return;          // wave-uniform: exactly one owner per touched row
+    if (r < 0 || slot[r] != base + (int)i) return;  // wave-uniform: exactly one owner per touched row
     const float sc = scale[0];
     const long o = (long)r * width;
     for (int c = lane; c < width; c += 64) {
@@ -301,6 +302,7 @@ __global__ void rows_scatter_add_multi_kernel(RowsMulti m) {
     const long i = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= J.n) return;
     const int r = J.rows[i];
+    if (r < 0) return;
     const float s = J.row_scale ? J.row_scale[i] : 1.f;
     float* g = J.gtab + (long)r * J.width;
     const float* v = J.vals + i * J.ldv;
@@ -344,7 +346,7 @@ __global__ void rows_adagrad_multi_kernel(RowsMulti m, float lr, float eps, cons
     const long i = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= J.n) return;
     const int r = J.rows[i];
-    if (J.slot[r] != J.base + (int)i) return;
+    if (r < 0 || J.slot[r] != J.base + (int)i) return;
     const float sc = scale[0];
     const long o = (long)r * J.width;
     for (int c = lane; c < J.width; c += 64) {
@@ -585,6 +587,25 @@ extern "C" int seqrec_fill_f32(float* x, float v, int64_t n, void* stream) {
     if (n == 0) return 0;
     if (!x) return SEQREC_E_ARG;
     hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), x, v, (long)n);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+namespace {
+__global__ void index_affine_i32_kernel(int* __restrict__ dst, const int* __restrict__ dpos, const int* __restrict__ src,
+                                        const int* __restrict__ spos, long n, int mul, int add) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long d = dpos ? dpos[i] : i, q = spos ? spos[i] : i;
+        if (d >= 0 && q >= 0) dst[d] = src[q] * mul + add;
+    }
+}
+}  // namespace
+extern "C" int seqrec_index_affine_i32(int32_t* dst, const int32_t* dst_pos, const int32_t* src, const int32_t* src_pos,
+                                       int64_t n, int32_t mul, int32_t add, void* stream) {
+    if (n < 0) return SEQREC_E_ARG;
+    if (n == 0) return 0;
+    if (!dst || !src) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(index_affine_i32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), dst, dst_pos, src,
+                       src_pos, (long)n, mul, add);
     SEQREC_LAUNCH_CHECK();
     return 0;
 }

@@ -17,6 +17,16 @@ Partitioning -- the reference is single-process, so this is the b
   * the global gradient norm is  sum_ranks |owned table-row grads|^2 + |dense grads|^2  (one small
     all-reduce), so every rank applies the same Keras clip scale.
 
+Collectives per training step when E and Eout rows have the same padded width (every BASELINE
+config: D == H) -- the "unified" path: THREE.  Both tables live in one local allocation, so one
+routing plan covers input rows, target rows and the stratified negatives:
+      forward   ONE all-to-all: [requested E rows | requested Eout rows | K/R negative rows | their ids]
+      backward  ONE all-to-all of the matching row gradients (same routes reversed), one scatter list
+      update    ONE all-reduce of [flat dense gradients | squared norm of the owned row gradients]
+No step contains a host synchronisation: the per-batch routing (counts, positions) is exchanged at
+upload time.  With D != H the tables keep separate widths and the step uses one exchange per table
+(seven collectives).
+
 ``RowExchange`` is device-agnostic torch code (unit-tested with gloo on CPU, world size 2 and 3);
 ``ShardedEngine`` wires it to the HIP kernels.
 """
@@ -31,6 +41,21 @@ from .engine import Engine, call, CELL, ACT, INT32_MAX
 class RowPlan:
     """Routing of one list of global row ids (fixed per batch): who owns what, in which order."""
     __slots__ = ("n", "send_counts", "recv_counts", "perm", "inv_perm", "recv_local", "m")
+
+
+class SegPlan:
+    """Routing of one batch's row requests with `extra` owner-chosen rows per peer (see plan_seg).
+
+    requester-side buffer (n_tot rows): segment j = [rows I asked rank j for | extra rows from j]
+    owner-side buffer     (m_tot rows): segment j = [rows rank j asked me for | extra rows for j]
+      req_split / own_split   per-peer row counts of the two layouts (python lists)
+      req_pos   int32[n]      row of request i in the requester-side buffer
+      req_extra int32[R,extra]  rows of the extras there
+      own_rows  int32[m_tot]  owner-local row index of every owner-side row (-1 at the extras)
+      own_extra int32[R,extra]  rows of the extras in the owner-side buffer
+      back_src  int32[n_tot]  request index of every requester-side row (-1 at the extras)"""
+    __slots__ = ("n", "extra", "n_tot", "m_tot", "req_split", "own_split", "req_pos", "req_extra", "own_rows",
+                 "own_extra", "back_src")
 
 
 class RowExchange:
@@ -66,6 +91,61 @@ class RowExchange:
         p.inv_perm = inv.to(torch.int32)
         p.recv_local = got                      # local row index of every row peers asked me for
         return p
+
+    def plan_seg(self, owner, want, extra=0):
+        """Request i asks rank owner[i] for its local row want[i]; in addition every (owner, requester)
+        pair moves `extra` rows chosen by the owner (stratified negatives).  Collective (tiny, at
+        batch-upload time).  The same plan routes the gradients back (push_seg)."""
+        R, dist, dev = self.R, self.dist, self.dev
+        owner = owner.to(dev).long()
+        want = want.to(dev).to(torch.int32)
+        n = owner.numel()
+        perm = torch.argsort(owner, stable=True)
+        send_counts = torch.bincount(owner, minlength=R)
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts, group=self.group)
+        sc, rc = send_counts.tolist(), recv_counts.tolist()
+        m = int(sum(rc))
+        got = torch.empty(m, dtype=torch.int32, device=dev)
+        dist.all_to_all_single(got, want[perm].contiguous(), output_split_sizes=rc, input_split_sizes=sc, group=self.group)
+        p = SegPlan()
+        p.n, p.extra = n, extra
+        p.req_split = [c + extra for c in sc]
+        p.own_split = [c + extra for c in rc]
+        p.n_tot, p.m_tot = n + R * extra, m + R * extra
+        ar_r = torch.arange(R, device=dev)
+        ar_e = torch.arange(extra, device=dev)
+        # requester side
+        req_pos = torch.empty(n, dtype=torch.long, device=dev)
+        req_pos[perm] = torch.arange(n, device=dev) + extra * owner[perm]
+        p.req_pos = req_pos.to(torch.int32)
+        sc_end = torch.cumsum(send_counts, 0)
+        p.req_extra = (sc_end[:, None] + extra * ar_r[:, None] + ar_e[None, :]).to(torch.int32)
+        back = torch.full((p.n_tot,), -1, dtype=torch.int32, device=dev)
+        back[req_pos] = torch.arange(n, device=dev, dtype=torch.int32)
+        p.back_src = back
+        # owner side
+        seg = torch.repeat_interleave(ar_r, recv_counts)
+        own_rows = torch.full((p.m_tot,), -1, dtype=torch.int32, device=dev)
+        own_rows[torch.arange(m, device=dev) + extra * seg] = got
+        p.own_rows = own_rows
+        rc_end = torch.cumsum(recv_counts, 0)
+        p.own_extra = (rc_end[:, None] + extra * ar_r[:, None] + ar_e[None, :]).to(torch.int32)
+        return p
+
+    def fetch_seg(self, plan, rows):
+        """rows [m_tot, w] in the owner-side layout -> [n_tot, w] in the requester-side layout."""
+        out = torch.empty((plan.n_tot,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=self.dev)
+        self.dist.all_to_all_single(out, rows, output_split_sizes=plan.req_split, input_split_sizes=plan.own_split,
+                                    group=self.group)
+        return out
+
+    def push_seg(self, plan, grads):
+        """grads [n_tot, w] in the requester-side layout -> [m_tot, w] in the owner-side layout."""
+        out = torch.empty((plan.m_tot,) + tuple(grads.shape[1:]), dtype=grads.dtype, device=self.dev)
+        self.dist.all_to_all_single(out, grads, output_split_sizes=plan.own_split, input_split_sizes=plan.req_split,
+                                    group=self.group)
+        return out
 
     # -- forward: fetch rows ------------------------------------------------------------------------
     def fetch(self, plan, gather_local, width, take):
@@ -110,6 +190,8 @@ class ShardedEngine(Engine):
     def __init__(self, cfg, device, dist, group=None):
         if cfg.input != "embed" or cfg.output != "sampled":
             raise ValueError("ShardedEngine shards item tables: it needs input='embed', output='sampled'")
+        if cfg.out_bias or cfg.drop_in or cfg.drop_out or cfg.drop_rec:
+            raise NotImplementedError("ShardedEngine: output bias / dropout are not wired into the sharded step")
         self.dist, self.group = dist, group
         self.R = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -122,11 +204,39 @@ class ShardedEngine(Engine):
         Engine.__init__(self, local, device)
         self.gcfg = cfg
         self.ex = RowExchange(dist, group, self.dev)
-        self.n_total = {}
+        # dense gradients live in ONE flat buffer (+1 slot for the squared norm of the owned row
+        # gradients): the step's only all-reduce runs in place on it
+        names = sorted(self.Gd)
+        tot = sum(self.Gd[k].numel() for k in names)
+        self.gflat = torch.zeros(tot + 1, dtype=torch.float32, device=self.dev)
+        o = 0
+        for k in names:
+            nk = self.Gd[k].numel()
+            self.Gd[k] = self.gflat[o:o + nk].view_as(self.Gd[k])
+            o += nk
+        self.sq = self.gflat[tot:tot + 1]
+        # unified item table: E rows then Eout rows in one allocation (same padded width)
+        self.unified = self.Dp == self.Hp
+        if self.unified:
+            w, P = self.Hp, self.P
+            nE = P["E"].shape[0]
+            nO = 0 if cfg.tied else P["Eout"].shape[0]
+            self.off_out = 0 if cfg.tied else nE
+            f32 = dict(dtype=torch.float32, device=self.dev)
+            self.TT = torch.zeros(nE + nO, w, **f32)
+            self.TA = torch.zeros(nE + nO, w, **f32)
+            self.TG = torch.zeros(nE + nO, w, **f32)
+            self.TS = torch.full((nE + nO,), INT32_MAX, dtype=torch.int32, device=self.dev)
+            for name, lo, hi in (("E", 0, nE),) + ((("Eout", nE, nE + nO),) if not cfg.tied else ()):
+                P[name] = self.TT[lo:hi]
+                self.A[name] = self.TA[lo:hi]
+                self.Gt[name] = self.TG[lo:hi]
+                self.slot[name] = self.TS[lo:hi]
 
     # ---- helpers -----------------------------------------------------------------------------------
-    def _take(self, src, idx):
-        out = torch.empty((idx.numel(), src.shape[1]), dtype=src.dtype, device=self.dev)
+    def _take(self, src, idx, out=None):
+        if out is None:
+            out = torch.empty((idx.numel(), src.shape[1]), dtype=src.dtype, device=self.dev)
         call("seqrec_gather_rows", ptr(src), ptr(idx), ptr(out), idx.numel(), src.shape[1], None, None, 0, self._stream())
         return out
 
@@ -157,42 +267,60 @@ class ShardedEngine(Engine):
 
     def upload(self, rb):
         d = Engine.upload(self, rb)
-        d["plan_in"] = self.ex.plan(d["ids"])
-        d["plan_tgt"] = self.ex.plan(d["tgt"])
-        nt = torch.tensor([d["n"]], dtype=torch.float64, device=self.dev)
+        c, R, n = self.cfg, self.R, d["n"]
+        if n == 0:
+            raise ValueError("ShardedEngine: every rank needs at least one transition per step (collectives are unconditional)")
+        nt = torch.tensor([n], dtype=torch.float64, device=self.dev)
         self.dist.all_reduce(nt, group=self.group)
         d["n_total"] = float(nt.item())
-        if self.cfg.logq and self.logq_global is not None:
+        if c.logq and self.logq_global is not None:
             d["lq_tgt"] = self.logq_global[d["tgt"].long()]         # fixed per batch
+        d["arange"] = torch.arange(n, device=self.dev, dtype=torch.int32)
+        if not self.unified:
+            d["plan_in"] = self.ex.plan(d["ids"])
+            d["plan_tgt"] = self.ex.plan(d["tgt"])
+            return d
+        # ---- unified routing: requests = [input rows ; target rows], extras = Kr negatives + id rows
+        w, Kr = self.Hp, c.K // R
+        nid = -(-Kr // w)                                            # rows that carry the negatives' ids
+        ids, tgt = d["ids"].long(), d["tgt"].long()
+        o_in, o_tg = ids % R, tgt % R
+        off = torch.zeros_like(o_tg) if c.tied else (self.gcfg.V_in - o_tg + R - 1) // R     # E rows held by the owner
+        plan = self.ex.plan_seg(torch.cat([o_in, o_tg]), torch.cat([ids // R, tgt // R + off]), extra=Kr + nid)
+        d["plan"] = plan
+        i32 = lambda t: t.to(torch.int32).contiguous()
+        q = torch.arange(Kr, device=self.dev)
+        d["send_idx"] = plan.own_rows.clone()                        # negatives' rows are written per step
+        d["neg_slots"] = i32(plan.own_extra[:, :Kr].reshape(-1))
+        d["id_slots"] = i32((plan.own_extra.long()[:, Kr + q // w] * w + (q % w)[None, :]).reshape(-1))
+        d["take_idx"] = i32(torch.cat([plan.req_pos.long(), plan.req_extra.long()[:, :Kr].reshape(-1)]))
+        d["negid_idx"] = i32((plan.req_extra.long()[:, Kr + q // w] * w + (q % w)[None, :]).reshape(-1))
+        back = plan.back_src.clone().long()
+        back[plan.req_extra.long()[:, :Kr].reshape(-1)] = 2 * n + torch.arange(R * Kr, device=self.dev)
+        d["back_idx"] = i32(back)
         return d
 
     # ---- one training step ----------------------------------------------------------------------------
     def train_step(self, d, lr=0.01, eps=1e-8, clipnorm=1.0, step=None, negatives=None, apply_update=True):
-        c, P, R = self.cfg, self.P, self.R
         if step is None:
             step = self.step_count
         self.step_count = step + 1
+        if self.unified:
+            return self._step_unified(d, lr, eps, clipnorm, step, apply_update)
+        return self._step_split(d, lr, eps, clipnorm, step, apply_update)
+
+    def _cell_and_loss(self, d, X, Etgt, Eneg, neg, dX, dEtgt, dEneg):
+        """Everything between the two exchanges: x.W, scan, sampled softmax CE, BPTT, dense weight
+        gradients; writes the three row-gradient blocks."""
+        c, P = self.cfg, self.P
         st = self._stream()
-        n, T, B = d["n"], d["T"], d["B"]
-        Hp, GHp, Dp = self.Hp, self.GHp, self.Dp
-        K, Kr = c.K, c.K // R
-        tname = "E" if c.tied else "Eout"
+        n, Hp, GHp, Dp, K = d["n"], self.Hp, self.GHp, self.Dp, c.K
         inv = 1.0 / d["n_total"]
-        # -- forward: remote rows in
-        X = self.ex.fetch(d["plan_in"], self._gather_from(P["E"]), Dp, self._take)
-        Etgt = self.ex.fetch(d["plan_tgt"], self._gather_from(P[tname]), Hp, self._take)
-        th, al, lq = self.sampler
-        negl = self.buf("negl", R * Kr, dtype=torch.int32)             # local rows I draw for every requester
-        call("seqrec_sample_negatives", int(c.seed), int(step) * R + self.rank, R * Kr, ptr(th), ptr(al), c.V_out, ptr(negl), st)
-        # rows and their global ids travel together: [R, Kr, Hp + 1] with the id bit-cast into the last column
-        ids_out = (negl.long() * R + self.rank).to(torch.int32)                # global ids of my draws
-        pay = torch.empty((R * Kr, Hp + 1), dtype=torch.float32, device=self.dev)
-        pay[:, :Hp] = self._take(P[tname], negl)
-        pay[:, Hp] = ids_out.view(torch.float32)
-        got = self.ex.swap_fixed(pay.view(R, Kr, Hp + 1)).view(K, Hp + 1)
-        Eneg = got[:, :Hp].contiguous()
-        neg = got[:, Hp].contiguous().view(torch.int32)
-        lq_neg = self.logq_global[neg.long()] if c.logq else None
+        Gd = self.Gd
+        lq_neg = None
+        if c.logq:
+            lq_neg = self.buf("lq_neg", K)
+            call("seqrec_gather_rows", ptr(self.logq_global), ptr(neg), ptr(lq_neg), K, 1, None, None, 0, st)
         XW = self.buf("XW", n, GHp)
         self.gemm(1, 0, n, GHp, Dp, X, Dp, P["W"], GHp, XW, GHp, bias=P.get("b"), tag="xw")
         Hout = self.buf("Hout", n, Hp); gates = self.buf("gates", n, GHp); aux = self.buf("aux", n, Hp)
@@ -200,42 +328,113 @@ class ShardedEngine(Engine):
         Hd = Hout
         ln = self.buf("ln", n, K)
         self.gemm(1, 1, n, K, Hp, Hd, Hp, Eneg, Hp, ln, K, tag="logits")
-        # log-Q correction and hit masking need per-candidate vectors here (rows are remote): fold the
-        # negatives' logq into the logits, the targets' logq into a per-token vector
+        # rows are remote: the softmax kernel takes the target rows and the candidates' log-Q as vectors
         dlt = self.buf("dlt", n)
         loss_rows = self.buf("loss_rows", n)
-        ar = self.buf("arange", n, dtype=torch.int32)
-        ar.copy_(torch.arange(n, device=self.dev, dtype=torch.int32))
-        lq_tgt = d.get("lq_tgt")
-        call("seqrec_sampled_softmax_ce_rows", ptr(ln), K, ptr(Hd), Hp, ptr(Etgt), ptr(lq_tgt), ptr(lq_neg), ptr(d["tgt"]),
-             ptr(neg), n, K, inv, ptr(loss_rows), ptr(dlt), st)
+        call("seqrec_sampled_softmax_ce_rows", ptr(ln), K, ptr(Hd), Hp, ptr(Etgt), ptr(d.get("lq_tgt")), ptr(lq_neg),
+             ptr(d["tgt"]), ptr(neg), n, K, inv, ptr(loss_rows), ptr(dlt), st)
         call("seqrec_reduce_sum", ptr(loss_rows), n, ptr(self.loss_sum), 0, st)
         # -- backward
+        ar = d["arange"]
         dHd = self.buf("dHd", n, Hp)
         self.gemm(1, 0, n, Hp, K, ln, K, Eneg, Hp, dHd, Hp, splitk=self._splitk(n, Hp, K), tag="dH")
         call("seqrec_gather_rows", ptr(Etgt), ptr(ar), ptr(dHd), n, Hp, ptr(dlt), None, 1, st)
-        dEneg = self.buf("dEneg", K, Hp)
         self.gemm(0, 0, K, Hp, n, ln, K, Hd, Hp, dEneg, Hp, splitk=self._splitk(K, Hp, n), tag="dEneg")
-        dEtgt = self.buf("dEtgt", n, Hp)
-        call("seqrec_fill_f32", ptr(dEtgt), 0.0, n * Hp, st)
         call("seqrec_gather_rows", ptr(Hd), ptr(ar), ptr(dEtgt), n, Hp, ptr(dlt), None, 0, st)
         dPre = self.buf("dPre", n, GHp)
         self._scan_bwd(d, dHd, Hout, gates, aux, dPre)
-        Gd, Gt = self.Gd, self.Gt
-        cs_ws = self.buf("colsum_ws", 64 * GHp)
-        call("seqrec_colsum", ptr(dPre), n, GHp, GHp, ptr(Gd["b"]), 0, ptr(cs_ws), st)
+        if c.use_bias:
+            cs_ws = self.buf("colsum_ws", 64 * GHp)
+            call("seqrec_colsum", ptr(dPre), n, GHp, GHp, ptr(Gd["b"]), 0, ptr(cs_ws), st)
         Hprev = self.buf("Hprev", n, Hp)
         call("seqrec_gather_rows", ptr(Hout), ptr(d["prev"]), ptr(Hprev), n, Hp, None, None, 0, st)
-        sk = self._splitk(Hp, GHp, n)
         if c.cell == "gru":
-            self.gemm(0, 0, Hp, 2 * Hp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp, splitk=sk, tag="dU")
-            self.gemm(0, 0, Hp, Hp, n, aux, Hp, dPre[:, 2 * Hp:], GHp, Gd["U"][:, 2 * Hp:], GHp, splitk=sk, tag="dU")
+            wgrad = [(Hp, 2 * Hp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp),
+                     (Hp, Hp, n, aux, Hp, dPre[:, 2 * Hp:], GHp, Gd["U"][:, 2 * Hp:], GHp)]
         else:
-            self.gemm(0, 0, Hp, GHp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp, splitk=sk, tag="dU")
-        self.gemm(0, 0, Dp, GHp, n, X, Dp, dPre, GHp, Gd["W"], GHp, splitk=self._splitk(Dp, GHp, n), tag="dW")
-        dX = self.buf("dX", n, Dp)
+            wgrad = [(Hp, GHp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp)]
+        wgrad.append((Dp, GHp, n, X, Dp, dPre, GHp, Gd["W"], GHp))
+        tiles = sum(((m + 63) // 64) * ((nn_ + 63) // 64) for (m, nn_, *_r) in wgrad)
+        sk = int(max(1, min(32, -(-512 // max(tiles, 1)), n // 128)))
+        wsp = self.buf("gemm_ws", sum(sk * m * nn_ for (m, nn_, *_r) in wgrad)) if sk > 1 else None
+        call("seqrec_gemm_f32_grouped", len(wgrad), 0, 0, _lib.gemm_descs(wgrad), sk, ptr(wsp), st, tag="dW+dU")
         self.gemm(1, 1, n, Dp, GHp, dPre, GHp, P["W"], GHp, dX, Dp, splitk=self._splitk(n, Dp, GHp), tag="dX")
-        # -- row gradients back to their owners, scatter-add into the local gradient tables
+
+    def _dense_update(self, lr, eps, clipnorm):
+        """After the owned row norms were added into self.sq: ONE all-reduce of [dense grads | sq],
+        dense norms on top (identical on every rank), Keras clip scale, dense Adagrad."""
+        st = self._stream()
+        P, Gd = self.P, self.Gd
+        self.dist.all_reduce(self.gflat, group=self.group)
+        dk = sorted(Gd)
+        gp = _lib.ptr_array([Gd[k] for k in dk])
+        nn = _lib.i64_array([Gd[k].numel() for k in dk])
+        call("seqrec_sqnorm_multi", len(dk), gp, nn, ptr(self.sq), st)
+        call("seqrec_clip_scale", ptr(self.sq), float(clipnorm if clipnorm else 0.0), ptr(self.scale), st)
+        call("seqrec_adagrad_dense_multi", len(dk), _lib.ptr_array([P[k] for k in dk]),
+             _lib.ptr_array([self.A[k] for k in dk]), gp, nn, lr, eps, ptr(self.scale), st)
+        self.upack_dirty = True
+
+    def _step_unified(self, d, lr, eps, clipnorm, step, apply_update):
+        c, R = self.cfg, self.R
+        st = self._stream()
+        n, w, K = d["n"], self.Hp, c.K
+        Kr = K // R
+        plan = d["plan"]
+        th, al, _ = self.sampler
+        # -- my stratified draws for every requester, placed into the batch's routing list
+        negl = self.buf("negl", R * Kr, dtype=torch.int32)
+        call("seqrec_sample_negatives", int(c.seed), int(step) * R + self.rank, R * Kr, ptr(th), ptr(al), c.V_out, ptr(negl), st)
+        send_idx = d["send_idx"]
+        call("seqrec_index_affine_i32", ptr(send_idx), ptr(d["neg_slots"]), ptr(negl), None, R * Kr, 1, self.off_out, st)
+        sendbuf = self.buf("sendbuf", plan.m_tot, w)
+        self._take(self.TT, send_idx, sendbuf)                                  # id rows (index -1) come out zero
+        call("seqrec_index_affine_i32", ptr(sendbuf), ptr(d["id_slots"]), ptr(negl), None, R * Kr, R, self.rank, st)
+        recv = self.ex.fetch_seg(plan, sendbuf)                                 # collective 1
+        xen = self.buf("xen", 2 * n + K, w)
+        self._take(recv, d["take_idx"], xen)
+        neg = self.buf("neg", K, dtype=torch.int32)
+        call("seqrec_index_affine_i32", ptr(neg), None, ptr(recv), ptr(d["negid_idx"]), K, 1, 0, st)
+        gall = self.buf("gall", 2 * n + K, w)
+        self._cell_and_loss(d, xen[:n], xen[n:2 * n], xen[2 * n:], neg, gall[:n], gall[n:2 * n], gall[2 * n:])
+        # -- row gradients travel the same routes back; one scatter list into the unified gradient table
+        backbuf = self.buf("backbuf", plan.n_tot, w)
+        self._take(gall, d["back_idx"], backbuf)
+        gback = self.ex.push_seg(plan, backbuf)                                 # collective 2
+        job, cnt = _lib.rows_jobs([dict(table=self.TT, accum=self.TA, gtab=self.TG, slot=self.TS, rows=send_idx, vals=gback,
+                                        ldv=w, row_scale=None, n=plan.m_tot, width=w, base=0)])
+        call("seqrec_rows_scatter_add_multi", job, cnt, st)
+        if not apply_update:
+            return None
+        call("seqrec_fill_f32", ptr(self.sq), 0.0, 1, st)
+        call("seqrec_rows_sqnorm_multi", job, cnt, ptr(self.sq), st)
+        self._dense_update(lr, eps, clipnorm)                                   # collective 3
+        call("seqrec_rows_adagrad_multi", job, cnt, lr, eps, ptr(self.scale), st)
+        return self.loss_sum * (self.R / d["n_total"])      # this rank's share, scaled so the mean over ranks is the global loss
+
+    def _step_split(self, d, lr, eps, clipnorm, step, apply_update):
+        """D != H: the two tables have different row widths, one exchange per table."""
+        c, P, R = self.cfg, self.P, self.R
+        st = self._stream()
+        n, Hp, Dp, K = d["n"], self.Hp, self.Dp, c.K
+        Kr = K // R
+        tname = "E" if c.tied else "Eout"
+        X = self.ex.fetch(d["plan_in"], self._gather_from(P["E"]), Dp, self._take)
+        Etgt = self.ex.fetch(d["plan_tgt"], self._gather_from(P[tname]), Hp, self._take)
+        th, al, _ = self.sampler
+        negl = self.buf("negl", R * Kr, dtype=torch.int32)             # local rows I draw for every requester
+        call("seqrec_sample_negatives", int(c.seed), int(step) * R + self.rank, R * Kr, ptr(th), ptr(al), c.V_out, ptr(negl), st)
+        # rows and their global ids travel together: [R, Kr, Hp + 1] with the id bit-cast into the last column
+        ids_out = (negl.long() * R + self.rank).to(torch.int32)
+        pay = torch.empty((R * Kr, Hp + 1), dtype=torch.float32, device=self.dev)
+        pay[:, :Hp] = self._take(P[tname], negl)
+        pay[:, Hp] = ids_out.view(torch.float32)
+        got = self.ex.swap_fixed(pay.view(R, Kr, Hp + 1)).view(K, Hp + 1)
+        Eneg = got[:, :Hp].contiguous()
+        neg = got[:, Hp].contiguous().view(torch.int32)
+        dX = self.buf("dX", n, Dp); dEtgt = self.buf("dEtgt", n, Hp); dEneg = self.buf("dEneg", K, Hp)
+        self._cell_and_loss(d, X, Etgt, Eneg, neg, dX, dEtgt, dEneg)
+        Gt = self.Gt
         jobs = []
         g_in, r_in = self.ex.push(d["plan_in"], dX, self._take)
         g_tg, r_tg = self.ex.push(d["plan_tgt"], dEtgt, self._take)
@@ -250,25 +449,11 @@ class ShardedEngine(Engine):
             base += m
         if not apply_update:
             return jobs
-        # -- dense gradients: one flat all-reduce; global norm; update
-        flat = torch.cat([Gd[k].reshape(-1) for k in sorted(Gd)])
-        self.dist.all_reduce(flat, group=self.group)
-        o = 0
-        for k in sorted(Gd):
-            nk = Gd[k].numel()
-            Gd[k].copy_(flat[o:o + nk].view_as(Gd[k]))
-            o += nk
-        self.sq.zero_()
+        call("seqrec_fill_f32", ptr(self.sq), 0.0, 1, st)
         for (tab, rows, m, w, b, _) in jobs:
             call("seqrec_rows_sqnorm", ptr(Gt[tab]), ptr(self.slot[tab]), ptr(rows), m, w, b, ptr(self.sq), st)
-        self.dist.all_reduce(self.sq, group=self.group)
-        for k in sorted(Gd):
-            call("seqrec_sqnorm", ptr(Gd[k]), Gd[k].numel(), ptr(self.sq), st)
-        call("seqrec_clip_scale", ptr(self.sq), float(clipnorm if clipnorm else 0.0), ptr(self.scale), st)
-        for k in sorted(Gd):
-            call("seqrec_adagrad_dense", ptr(P[k]), ptr(self.A[k]), ptr(Gd[k]), Gd[k].numel(), lr, eps, ptr(self.scale), st)
-        self.upack_dirty = True
+        self._dense_update(lr, eps, clipnorm)
         for (tab, rows, m, w, b, _) in jobs:
             call("seqrec_rows_adagrad", ptr(P[tab]), ptr(self.A[tab]), ptr(Gt[tab]), ptr(self.slot[tab]), ptr(rows), m, w, b,
                  lr, eps, ptr(self.scale), st)
-        return self.loss_sum * (self.R / d["n_total"])      # this rank's share, scaled so the mean over ranks is the global loss
+        return self.loss_sum * (self.R / d["n_total"])

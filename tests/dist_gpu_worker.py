@@ -57,7 +57,8 @@ def main():
     D = importlib.import_module("seq-recommendations_amd.distributed")
     Bt = importlib.import_module("seq-recommendations_amd.batching")
     Sm = importlib.import_module("seq-recommendations_amd.sampling")
-    for case in (dict(cell="gru", V=1501, H=128, Dm=64, K=64 * R, tied=False),
+    for case in (dict(cell="gru", V=1501, H=128, Dm=64, K=64 * R, tied=False),      # D != H: one exchange per table
+                 dict(cell="gru", V=1201, H=128, Dm=128, K=160 * R, tied=False),    # unified tables, ids span 2 id rows
                  dict(cell="lstm", V=900, H=64, Dm=64, K=32 * R, tied=True)):
         V, H, Dm, K, tied, cell = case["V"], case["H"], case["Dm"], case["K"], case["tied"], case["cell"]
         G = onn.N_GATES[cell]

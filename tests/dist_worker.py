@@ -10,6 +10,70 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def seg_plan_checks(D, ex, E, rank, R):
+    """plan_seg / fetch_seg / push_seg: requests against TWO stacked tables plus `extra` owner-chosen
+    rows per peer, forward rows and reverse gradients against a dense single-process reference."""
+    V, w = E.shape
+    g2 = torch.Generator().manual_seed(2)
+    F = torch.randn(V, w, generator=g2, dtype=torch.float64)               # second table (Eout), same width
+    nE = D.shard_size(V, rank, R)
+    uni = torch.cat([D.shard_rows(E, rank, R), D.shard_rows(F, rank, R)])  # my unified shard: E rows then F rows
+    gr = torch.Generator().manual_seed(300 + rank)
+    for case, extra in enumerate((0, 3, 5)):
+        n1 = 0 if (case == 2 and rank == 0) else 40 + 9 * rank
+        n2 = 25 + 4 * rank
+        a = torch.randint(0, V, (n1,), generator=gr)
+        b = torch.randint(0, V, (n2,), generator=gr)
+        if n1 > 5:
+            a[:5] = 11
+        owner = torch.cat([a % R, b % R])
+        off = (V - (b % R) + R - 1) // R                                     # E rows held by the owner of b
+        plan = ex.plan_seg(owner, torch.cat([a // R, b // R + off]), extra=extra)
+        n = n1 + n2
+        assert plan.n_tot == n + R * extra and sum(plan.req_split) == plan.n_tot and sum(plan.own_split) == plan.m_tot
+        # owner side: requested rows + `extra` rows I pick per peer (here: F rows of my shard, ids known to me)
+        idx = plan.own_rows.clone().long()
+        pick = torch.randint(0, uni.shape[0] - nE, (R, extra), generator=gr) + nE
+        if extra:
+            idx[plan.own_extra.long().reshape(-1)] = pick.reshape(-1)
+        assert (idx >= 0).all()
+        recv = ex.fetch_seg(plan, uni[idx].contiguous())
+        got = recv[plan.req_pos.long()]
+        assert torch.equal(got[:n1], E[a]) and torch.equal(got[n1:], F[b]), "fetch_seg mismatch (case %d)" % case
+        picks = [None] * R
+        dist.all_gather_object(picks, pick)
+        for j in range(R):                                                   # extras from owner j: its picks for me
+            want = D.shard_rows(F, j, R)[picks[j][rank] - D.shard_size(V, j, R)]
+            assert torch.equal(recv[plan.req_extra.long()[j]], want), "extras mismatch (case %d)" % case
+        # reverse: gradients for requests and extras
+        gq = torch.randn(n, w, generator=gr, dtype=torch.float64)
+        gx = torch.randn(R * extra, w, generator=gr, dtype=torch.float64)
+        src = torch.cat([gq, gx])
+        back = plan.back_src.clone().long()
+        if extra:
+            back[plan.req_extra.long().reshape(-1)] = n + torch.arange(R * extra)
+        assert sorted(back.tolist()) == list(range(n + R * extra))
+        gown = ex.push_seg(plan, src[back].contiguous())
+        acc = torch.zeros_like(uni)
+        acc.index_add_(0, idx, gown)
+        everything = [None] * R
+        dist.all_gather_object(everything, (a, b, gq, gx, pick))
+        refE = torch.zeros(V, w, dtype=torch.float64)
+        for aj, bj, gqj, gxj, pj in everything:
+            refE.index_add_(0, aj, gqj[: aj.numel()])
+        assert torch.allclose(acc[:nE], D.shard_rows(refE, rank, R), atol=1e-12), "push_seg E mismatch (case %d)" % case
+        # second table: target-row gradients of every rank + the extras every owner picked for every requester
+        refF2 = torch.zeros(V, w, dtype=torch.float64)
+        for j, (aj, bj, gqj, gxj, pj) in enumerate(everything):
+            refF2.index_add_(0, bj, gqj[aj.numel():])
+        for o in range(R):                                                   # owner o, requester j
+            for j in range(R):
+                if extra:
+                    rows_global = (everything[o][4][j] - D.shard_size(V, o, R)) * R + o
+                    refF2.index_add_(0, rows_global, everything[j][3].view(R, extra, w)[o])
+        assert torch.allclose(acc[nE:], D.shard_rows(refF2, rank, R), atol=1e-12), "push_seg F mismatch (case %d)" % case
+
+
 def main():
     dist.init_process_group("gloo")
     rank, R = dist.get_rank(), dist.get_world_size()
@@ -51,6 +115,7 @@ def main():
         for i, gg in zip(all_ids, all_g):
             ref.index_add_(0, i, gg)
         assert torch.allclose(gshard, D.shard_rows(ref, rank, R), atol=1e-12), "push mismatch (case %d)" % case
+    seg_plan_checks(D, ex, E, rank, R)
     x = torch.arange(R * 3, dtype=torch.float32).view(R, 3) + 100 * rank
     y = ex.swap_fixed(x)
     for i in range(R):

@@ -183,4 +183,4 @@ def test_sharded_engine_two_ranks_one_gpu_vs_global_oracle():
            "--master-port", "29641", os.path.join(here, "dist_gpu_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
-    assert r.stdout.count("case ok") == 2 and r.stdout.count("rank") >= 2
+    assert r.stdout.count("case ok") == 3 and r.stdout.count("rank") >= 2

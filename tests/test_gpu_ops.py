@@ -315,6 +315,60 @@ def test_sparse_rows_path_equals_dense_adagrad_with_duplicates():
     np.testing.assert_array_equal(Pd.cpu().numpy()[untouched], P0[untouched])
 
 
+def test_index_affine_and_filler_rows():
+    """seqrec_index_affine_i32 (bit-exact int plumbing, negative positions skipped) and the
+    rows[i] < 0 filler convention of the row-sparse kernels (single and multi-list forms)."""
+    rng = np.random.default_rng(31)
+    n = 5000
+    src = rng.integers(0, 2 ** 20, size=n).astype(np.int32)
+    dpos = rng.permutation(3 * n)[:n].astype(np.int32)
+    dpos[::7] = -1
+    dst = torch.full((3 * n,), -5, dtype=torch.int32, device="cuda")
+    call("seqrec_index_affine_i32", ptr(dst), ptr(dev(dpos)), ptr(dev(src)), None, n, 3, 11, st())
+    ref = np.full(3 * n, -5, np.int32)
+    ok = dpos >= 0
+    ref[dpos[ok]] = src[ok] * 3 + 11
+    np.testing.assert_array_equal(dst.cpu().numpy(), ref)
+    spos = rng.integers(0, n, size=777).astype(np.int32)
+    out = torch.zeros(777, dtype=torch.int32, device="cuda")
+    # ids parked in a FLOAT buffer (small ints = denormal bit patterns) must come back bit-exact
+    fbuf = dev(src).view(torch.float32)
+    call("seqrec_index_affine_i32", ptr(out), None, ptr(fbuf), ptr(dev(spos)), 777, 1, 0, st())
+    np.testing.assert_array_equal(out.cpu().numpy(), src[spos])
+    # filler rows
+    V, W, m = 500, 64, 300
+    rows = rng.integers(0, V, size=m).astype(np.int32)
+    rows[::5] = -1
+    vals = rng.normal(size=(m, W)).astype(np.float32)
+    keep = rows >= 0
+    gref = np.zeros((V, W), np.float64)
+    np.add.at(gref, rows[keep], vals[keep].astype(np.float64))
+    for multi in (False, True):
+        P0 = rng.normal(size=(V, W)).astype(np.float32)
+        Pd, Ad = dev(P0), torch.zeros((V, W), device="cuda")
+        gt = torch.zeros((V, W), device="cuda")
+        slot = torch.full((V,), 2 ** 31 - 1, dtype=torch.int32, device="cuda")
+        rd, vd = dev(rows), dev(vals)
+        sq = torch.zeros(1, device="cuda"); scale = torch.ones(1, device="cuda")
+        if multi:
+            arr, cnt = L.rows_jobs([dict(table=Pd, accum=Ad, gtab=gt, slot=slot, rows=rd, vals=vd, ldv=W, row_scale=None, n=m,
+                                         width=W, base=0)])
+            call("seqrec_rows_scatter_add_multi", arr, cnt, st())
+            call("seqrec_rows_sqnorm_multi", arr, cnt, ptr(sq), st())
+        else:
+            call("seqrec_rows_scatter_add", ptr(gt), ptr(slot), ptr(rd), ptr(vd), W, None, m, W, 0, st())
+            call("seqrec_rows_sqnorm", ptr(gt), ptr(slot), ptr(rd), m, W, 0, ptr(sq), st())
+        np.testing.assert_allclose(gt.cpu().numpy(), gref, atol=1e-4)
+        assert abs(sq.item() - (gref ** 2).sum()) <= 1e-4 * (gref ** 2).sum()
+        if multi:
+            call("seqrec_rows_adagrad_multi", arr, cnt, 0.01, 1e-8, ptr(scale), st())
+        else:
+            call("seqrec_rows_adagrad", ptr(Pd), ptr(Ad), ptr(gt), ptr(slot), ptr(rd), m, W, 0, 0.01, 1e-8, ptr(scale), st())
+        Pref = P0 - 0.01 * gref / (np.sqrt(gref * gref) + 1e-8)
+        np.testing.assert_allclose(Pd.cpu().numpy(), Pref, rtol=1e-5, atol=1e-6)
+        assert torch.all(gt == 0) and torch.all(slot == 2 ** 31 - 1)
+
+
 def test_dense_adagrad_and_norm():
     rng = np.random.default_rng(4)
     n = 200003
