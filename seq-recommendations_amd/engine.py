@@ -210,7 +210,9 @@ class Engine:
 
     def buf(self, name, *shape, dtype=torch.float32):
         """Grow-only named workspace."""
-        n = int(np.prod(shape)) if shape else 1
+        n = 1
+        for v in shape:
+            n *= int(v)
         t = self.ws.get(name)
         if t is None or t.numel() < n or t.dtype != dtype:
             t = torch.empty(max(n, 1), dtype=dtype, device=self.dev)

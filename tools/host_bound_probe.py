@@ -31,3 +31,4 @@ pr = cProfile.Profile(); pr.enable()
 for i in range(50): eng.train_step(bs[i % 32], step=300 + i)
 pr.disable(); torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)
