@@ -222,6 +222,19 @@ int seqrec_sample_negatives(uint64_t seed, uint64_t step, int K, const uint32_t*
 int seqrec_dropout_mask(uint64_t seed, uint64_t stream_id, const int64_t* rowkey, int64_t n_rows,
                         int width, int64_t ld, double rate, float* out, void* stream);
 
+/* ---- device-side ragged batcher: counterpart of the pairing x = s[i], y = s[i+1] of
+ *      FullModelPreprocessor.transform_data (preprocessor.py:67-94) on ids, and of datasets.build_xs
+ *      (datasets.py:97-113), for a dataset that lives in HBM as one flat id array
+ *      (session i = flat[starts[i] .. starts[i+1])).  `sess[r]` = dataset index of the batch's r-th
+ *      session in DESCENDING length order, `step_off` = device int32[T+1] packed-token offsets (the
+ *      host computes both from the lengths alone; no item id crosses PCIe).
+ *      pack_batch:        ids[p] = s[t], tgt[p] = s[t+1], prev[p] = token of the same session at t-1 (-1 at t = 0)
+ *      history_features:  xs[p, v] = [v in s[0..t]]  (freq != 0: number of occurrences), row stride ld >= x_dim */
+int seqrec_pack_batch(const int32_t* flat, const int64_t* starts, const int32_t* sess, const int32_t* step_off,
+                      int B, int T, int32_t* ids, int32_t* tgt, int32_t* prev, void* stream);
+int seqrec_history_features(const int32_t* flat, const int64_t* starts, const int32_t* sess, const int32_t* step_off,
+                            int B, int T, int x_dim, int64_t ld, int freq, float* xs, void* stream);
+
 /* ---- Recall@K support (extension): rank[i] = #{v : score(i,v) > score(i,tgt_i)},
  *      score(i,v) = hd[i,:] . Eout[v,:] (+ bout[v]).  rank must be zeroed by the caller. */
 int seqrec_rank_count(const float* hd, int H, const float* Eout, const float* bout,

@@ -103,6 +103,18 @@ def pack_flat(flat, starts, sel):
     return _finish(rb, order, ls, step_off, tok_t, tok_bs, B, T, n_tok, len(sel))
 
 
+def index_flat(starts, sel):
+    """Index-only packing for the device-side batcher (engine.Engine.upload_device): everything the
+    host needs (order, lengths, step offsets, token coordinates) from the session LENGTHS alone; the
+    item ids are gathered on the GPU by seqrec_pack_batch, so rb.ids / rb.tgt stay None."""
+    sel = np.asarray(sel, dtype=np.int64)
+    lengths = np.maximum(starts[sel + 1] - starts[sel] - 1, 0)
+    order, ls, step_off, tok_t, tok_bs, B, T, n_tok = _pack_index(lengths)
+    rb = RaggedBatch()
+    rb.ids = rb.tgt = rb.x = rb.xs = None
+    return _finish(rb, order, ls, step_off, tok_t, tok_bs, B, T, n_tok, len(sel))
+
+
 def pack_padded(mask, ids=None, tgt=None, x=None, xs=None):
     """From the reference's padded view: mask (B,T) bool marks real steps (any position --
     masked steps simply carry state, so only the order of the real steps matters);

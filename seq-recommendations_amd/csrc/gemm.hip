@@ -10,6 +10,7 @@
 // Roofline: MFMA-bound, 157.3 TFLOP/s fp32; algorithmic flops = 2*M*N*K.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -64,6 +65,18 @@ __device__ __forceinline__ float4 load_tile4(const float* __restrict__ X, long l
     return v;
 }
 
+// interior tiles (whole tile inside the matrix, 16-byte loads legal): no predicates, one dwordx4 per thread
+template <int BR, int BKT, bool KCONTIG>
+__device__ __forceinline__ float4 load_tile4_fast(const float* __restrict__ X, long ld, long r0, long k0, int idx) {
+    if (KCONTIG) {
+        const int r = idx / (BKT / 4), kq = idx % (BKT / 4);
+        return *reinterpret_cast<const float4*>(X + (r0 + r) * ld + k0 + 4 * kq);
+    } else {
+        const int k = idx / (BR / 4), rq = idx % (BR / 4);
+        return *reinterpret_cast<const float4*>(X + (k0 + k) * ld + r0 + 4 * rq);
+    }
+}
+
 template <int BR, int BKT, bool KCONTIG>
 __device__ __forceinline__ void store_tile4(float* __restrict__ S, int idx, float4 v) {
     constexpr int LD = BR + 2;
@@ -103,56 +116,67 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int tile
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[NA], rb[NB];
-    auto gload = [&](int kt) {
-        const long k0 = kbeg + (long)kt * BKT;
+    // workgroup-uniform: the whole tile is inside A, B and this split's K range and 16-byte loads are
+    // legal -> a main loop without any predicate (one dwordx4 per operand piece); else the guarded loop
+    const bool interior = g.a_vec && g.b_vec && m0 + BM <= g.M && n0 + BN <= g.N && (kend - kbeg) % BKT == 0;
+    auto main_loop = [&](auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        float4 ra[NA], rb[NB];
+        auto gload = [&](int kt) {
+            const long k0 = kbeg + (long)kt * BKT;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) ra[i] = load_tile4<BM, BKT, A_KC>(g.A, g.lda, m0, k0, g.M, kend, tid + 256 * i, g.a_vec);
+            for (int i = 0; i < NA; ++i)
+                ra[i] = FAST ? load_tile4_fast<BM, BKT, A_KC>(g.A, g.lda, m0, k0, tid + 256 * i)
+                             : load_tile4<BM, BKT, A_KC>(g.A, g.lda, m0, k0, g.M, kend, tid + 256 * i, g.a_vec);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) rb[i] = load_tile4<BN, BKT, B_KC>(g.B, g.ldb, n0, k0, g.N, kend, tid + 256 * i, g.b_vec);
-    };
-    auto sstore = [&](int buf) {
+            for (int i = 0; i < NB; ++i)
+                rb[i] = FAST ? load_tile4_fast<BN, BKT, B_KC>(g.B, g.ldb, n0, k0, tid + 256 * i)
+                             : load_tile4<BN, BKT, B_KC>(g.B, g.ldb, n0, k0, g.N, kend, tid + 256 * i, g.b_vec);
+        };
+        auto sstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) store_tile4<BM, BKT, A_KC>(As[buf], tid + 256 * i, ra[i]);
+            for (int i = 0; i < NA; ++i) store_tile4<BM, BKT, A_KC>(As[buf], tid + 256 * i, ra[i]);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) store_tile4<BN, BKT, B_KC>(Bs[buf], tid + 256 * i, rb[i]);
-    };
-
-    if (nk > 0) {
-        gload(0);
-        sstore(0);
-    }
-    __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload(kt + 1);
-        const float* as = As[cur] + wm * (BM / 2) + (lane & 31);
-        const float* bs = Bs[cur] + wn * (BN / 2) + (lane & 31);
-        // all MFMA operand fragments of this K tile first (one ds_read_b32 each), then the MFMAs
-        // back to back: hipcc otherwise pairs every read with its use and exposes the LDS latency
-        // in front of each MFMA (lgkmcnt(0) per pair).
-        float a[BKT / 2][TM], b[BKT / 2][TN];
-#pragma unroll
-        for (int ks = 0; ks < BKT / 2; ++ks) {
-            const int kk = 2 * ks + (lane >> 5);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[ks][i] = as[kk * LDA + 32 * i];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[ks][j] = bs[kk * LDB + 32 * j];
+            for (int i = 0; i < NB; ++i) store_tile4<BN, BKT, B_KC>(Bs[buf], tid + 256 * i, rb[i]);
+        };
+        if (nk > 0) {
+            gload(0);
+            sstore(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < BKT / 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) sstore(cur ^ 1);
         __syncthreads();
-        cur ^= 1;
-    }
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) gload(kt + 1);
+            const float* as = As[cur] + wm * (BM / 2) + (lane & 31);
+            const float* bs = Bs[cur] + wn * (BN / 2) + (lane & 31);
+            // all MFMA operand fragments of this K tile first (one ds_read_b32 each), then the MFMAs
+            // back to back: hipcc otherwise pairs every read with its use and exposes the LDS latency
+            // in front of each MFMA (lgkmcnt(0) per pair).
+            float a[BKT / 2][TM], b[BKT / 2][TN];
+#pragma unroll
+            for (int ks = 0; ks < BKT / 2; ++ks) {
+                const int kk = 2 * ks + (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[ks][i] = as[kk * LDA + 32 * i];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[ks][j] = bs[kk * LDB + 32 * j];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < BKT / 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) sstore(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    };
+    if (interior) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
 
     if (g.epi == 1) {
 #pragma unroll

@@ -590,6 +590,67 @@ extern "C" int seqrec_fill_f32(float* x, float v, int64_t n, void* stream) {
     SEQREC_LAUNCH_CHECK();
     return 0;
 }
+// ---------------------------------------------------------------------------------------------
+// device-side ragged batcher: the dataset stays in HBM as one flat id array
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ void pack_batch_kernel(const int* __restrict__ flat, const long* __restrict__ starts, const int* __restrict__ sess,
+                                  const int* __restrict__ step_off, int* __restrict__ ids, int* __restrict__ tgt,
+                                  int* __restrict__ prev) {
+    const int t = blockIdx.y;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p0 = step_off[t];
+    if (r >= step_off[t + 1] - p0) return;
+    const long base = starts[sess[r]] + t;
+    const int p = p0 + r;
+    ids[p] = flat[base];
+    tgt[p] = flat[base + 1];
+    prev[p] = t > 0 ? step_off[t - 1] + r : -1;
+}
+// xs[p, v] = 1 (or the count, freq != 0) for every item v among the session's items 0..t  (datasets.py:97-113)
+__global__ void history_features_kernel(const int* __restrict__ flat, const long* __restrict__ starts,
+                                        const int* __restrict__ sess, const int* __restrict__ step_off, int x_dim, long ld,
+                                        int freq, float* __restrict__ xs) {
+    const int t = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int p0 = step_off[t];
+    if (r >= step_off[t + 1] - p0) return;
+    float* row = xs + (long)(p0 + r) * ld;
+    for (int c = lane; c < (int)ld; c += 64) row[c] = 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    const long base = starts[sess[r]];
+    for (int j = lane; j <= t; j += 64) {
+        const int v = flat[base + j];
+        if (v >= 0 && v < x_dim) {
+            if (freq) atomicAdd(row + v, 1.f);
+            else row[v] = 1.f;
+        }
+    }
+}
+}  // namespace
+extern "C" int seqrec_pack_batch(const int32_t* flat, const int64_t* starts, const int32_t* sess, const int32_t* step_off,
+                                 int B, int T, int32_t* ids, int32_t* tgt, int32_t* prev, void* stream) {
+    if (B < 0 || T < 0) return SEQREC_E_ARG;
+    if (B == 0 || T == 0) return 0;
+    if (!flat || !starts || !sess || !step_off || !ids || !tgt || !prev) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)((B + 255) / 256), (unsigned)T), dim3(256), 0, as_stream(stream), flat,
+                       reinterpret_cast<const long*>(starts), sess, step_off, ids, tgt, prev);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int seqrec_history_features(const int32_t* flat, const int64_t* starts, const int32_t* sess,
+                                       const int32_t* step_off, int B, int T, int x_dim, int64_t ld, int freq, float* xs,
+                                       void* stream) {
+    if (B < 0 || T < 0 || x_dim <= 0 || ld < x_dim) return SEQREC_E_ARG;
+    if (B == 0 || T == 0) return 0;
+    if (!flat || !starts || !sess || !step_off || !xs) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(history_features_kernel, dim3((unsigned)((B + 3) / 4), (unsigned)T), dim3(256), 0, as_stream(stream), flat,
+                       reinterpret_cast<const long*>(starts), sess, step_off, x_dim, (long)ld, freq, xs);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+
 namespace {
 __global__ void index_affine_i32_kernel(int* __restrict__ dst, const int* __restrict__ dpos, const int* __restrict__ src,
                                         const int* __restrict__ spos, long n, int mul, int add) {

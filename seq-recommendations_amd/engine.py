@@ -346,6 +346,39 @@ class Engine:
         d["blob"] = blob
         return d
 
+    def put_dataset(self, flat, starts):
+        """Park a whole dataset in HBM (flat item ids + session offsets) for upload_device()."""
+        flat = np.ascontiguousarray(flat, dtype=np.int32)
+        starts = np.ascontiguousarray(starts, dtype=np.int64)
+        return {"flat": torch.from_numpy(flat).to(self.dev), "starts": torch.from_numpy(starts).to(self.dev),
+                "starts_host": starts}
+
+    def upload_device(self, ds, sel, history=False, freq=False):
+        """Device-side batcher: like upload(batching.pack_flat(flat, starts, sel)) but only
+        the batch's session indices and step offsets (a few KB) cross PCIe; ids / targets / prev links
+        -- and, with history=True, the x_to_y history features of datasets.build_xs -- are produced
+        by seqrec_pack_batch / seqrec_history_features from the HBM-resident dataset."""
+        from .batching import index_flat
+        c = self.cfg
+        rb = index_flat(ds["starts_host"], sel)
+        n, T, B = rb.n_tok, rb.T, rb.B
+        sess = np.asarray(sel, dtype=np.int64)[rb.order].astype(np.int32)
+        blob = torch.from_numpy(np.concatenate([rb.step_off.astype(np.int32), sess])).to(self.dev, non_blocking=True)
+        out = torch.empty(3 * max(n, 1), dtype=torch.int32, device=self.dev)
+        d = {"n": n, "T": T, "B": B, "rb": rb, "blob": blob, "step_off": blob[: T + 1], "sess": blob[T + 1:],
+             "ids": out[:n], "tgt": out[n:2 * n], "prev": out[2 * n:3 * n], "_out": out}
+        st = self._stream()
+        call("seqrec_pack_batch", ptr(ds["flat"]), ptr(ds["starts"]), ptr(d["sess"]), ptr(d["step_off"]), B, T, ptr(d["ids"]),
+             ptr(d["tgt"]), ptr(d["prev"]), st)
+        if history:
+            if not c.x_to_y:
+                raise ValueError("history features feed the x_to_y branch (NetConfig.x_to_y)")
+            xs = torch.empty((max(n, 1), self.Fxp), dtype=torch.float32, device=self.dev)
+            call("seqrec_history_features", ptr(ds["flat"]), ptr(ds["starts"]), ptr(d["sess"]), ptr(d["step_off"]), B, T,
+                 c.x_dim, self.Fxp, int(bool(freq)), ptr(xs), st)
+            d["xs"] = xs[:n]
+        return d
+
     def _drop_masks(self, d, step):
         """Inverted-dropout multipliers for this step (counter RNG; oracle/rng.py)."""
         c = self.cfg
@@ -360,7 +393,8 @@ class Engine:
         if c.drop_in > 0:
             sid = _lib.STREAM_DROP_IN + 16 * (step + 1)
             if c.input == "onehot":
-                rk = torch.from_numpy(key * c.V_in + rb.ids.astype(np.int64)).to(self.dev)
+                ids_host = rb.ids if rb.ids is not None else d["ids"].cpu().numpy()     # device-packed batch
+                rk = torch.from_numpy(key * c.V_in + ids_host.astype(np.int64)).to(self.dev)
                 m = self.buf("in_scale", n)
                 call("seqrec_dropout_mask", c.seed, sid, ptr(rk), n, 1, 1, float(c.drop_in), ptr(m), st)
             else:

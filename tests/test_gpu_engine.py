@@ -136,6 +136,45 @@ def test_eval_predict_and_recall_paths():
     assert abs(om.recall_at_k(scores, rb.tgt, 20) - float((rank < 20).mean())) < 0.05
 
 
+def test_device_batcher_equals_host_packing():
+    """Engine.upload_device (seqrec_pack_batch / seqrec_history_features on an HBM-resident dataset)
+    must produce bit-for-bit the index arrays of upload(batching.pack_flat(...)), the history features
+    of datasets.build_xs, and hence the same training loss."""
+    import importlib
+    import torch
+    E = importlib.import_module("seq-recommendations_amd.engine")
+    Bt = importlib.import_module("seq-recommendations_amd.batching")
+    DS = importlib.import_module("seq-recommendations_amd.datasets")
+    rng = np.random.default_rng(12)
+    V = 23
+    seqs = make_sessions(rng, 300, V, 1, 30) + [[], [3]]
+    flat, starts = DS.to_flat(seqs)
+    cfg = E.NetConfig(cell="lstm", act="relu", H=64, V_in=V, V_out=V, input="onehot", output="full", x_to_y=True, x_dim=V,
+                      diag_b=False, seed=3)
+    eng = E.Engine(cfg)
+    for k, t in eng.P.items():
+        t.copy_(torch.from_numpy((rng.normal(size=tuple(t.shape)) * 0.1).astype(np.float32)))
+    eng.upack_dirty = True
+    ds = eng.put_dataset(flat, starts)
+    for freq in (False, True):
+        xs_all = DS.build_xs(seqs, {i: i for i in range(V)}, freq=freq)
+        for sel in (np.arange(0, 100), rng.permutation(len(seqs))[:128], np.array([300, 301, 5])):
+            rb = Bt.pack_flat(flat, starts, sel)
+            dh = eng.upload(rb)
+            dd = eng.upload_device(ds, sel, history=True, freq=freq)
+            assert (dd["n"], dd["T"], dd["B"]) == (dh["n"], dh["T"], dh["B"])
+            for k in ("ids", "tgt", "prev", "step_off"):
+                assert torch.equal(dd[k], dh[k]), k
+            ref = np.zeros((rb.n_tok, V), np.float32)
+            for p in range(rb.n_tok):
+                ref[p] = xs_all[int(sel[rb.tok_b[p]])][int(rb.tok_s[p])]
+            np.testing.assert_array_equal(dd["xs"].cpu().numpy()[:, :V], ref)
+            dh["xs"] = dd["xs"]
+            l1 = float(eng.eval_loss(dh).item())
+            l2 = float(eng.eval_loss(dd).item())
+            assert l1 == l2
+
+
 def test_sharded_engine_single_rank_equals_oracle():
     """ShardedEngine over a 1-rank RCCL group: every exchange degenerates to a local copy, so losses
     and gradients must equal the oracle exactly like the plain engine (the N>1 routing itself is

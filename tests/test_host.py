@@ -83,3 +83,53 @@ def test_pack_edge_cases():
     assert exact and m.tolist() == [[False, False, True, True], [False, False, False, True]] and ids[0, 3] == 4
     x[1, 3, 2] = 0.5
     assert not B.onehot_to_ids(x)[2]
+
+
+def test_msnbc_text_format_and_history_features(tmp_path):
+    """datasets.load_msnbc_data (datasets.py:199-227: 8 header lines, whitespace-separated tokens, ids in
+    order of first appearance, eliminate_repeats) and build_xs (datasets.py:97-113) against literal
+    restatements of the reference loops."""
+    import importlib
+    DS = importlib.import_module("seq-recommendations_amd.datasets")
+    rng = np.random.default_rng(5)
+    lines = ["%% header %d" % i for i in range(8)]
+    raw = []
+    for _ in range(40):
+        toks = [str(int(v)) for v in rng.integers(1, 18, size=int(rng.integers(0, 12)))]
+        if len(toks) > 3:
+            toks[2] = toks[1]                      # a repeat to eliminate
+        raw.append(toks)
+        lines.append(" ".join(toks) + " ")
+    f = tmp_path / "msnbc.txt"
+    f.write_text("\n".join(lines) + "\n")
+    for elim in (False, True):
+        seqs, vocab = DS.load_msnbc_data(eliminate_repeats=elim, path=str(f))
+        ref_vocab, ref = {}, []
+        for toks in raw:                           # the reference's loop, restated
+            seq, prev = [], None
+            for t in toks:
+                if t not in ref_vocab:
+                    ref_vocab[t] = len(ref_vocab)
+                if elim and t != prev:
+                    seq.append(ref_vocab[t]); prev = t
+                elif not elim:
+                    seq.append(ref_vocab[t])
+            ref.append(seq)
+        assert seqs == ref and vocab == ref_vocab and len(seqs) == 40
+    seqs, vocab = DS.load_msnbc_data(path=str(f))
+    for freq in (False, True):
+        xs = DS.build_xs(seqs, vocab, freq=freq)
+        for seq, x in zip(seqs, xs):
+            cur = [0] * len(vocab)
+            assert len(x) == len(seq)
+            for t, v in enumerate(seq):
+                cur[v] = cur[v] + 1 if freq else 1
+                assert x[t] == cur
+    flat, starts = DS.to_flat(seqs)
+    assert flat.dtype == np.int32 and starts[-1] == len(flat) == sum(len(s) for s in seqs)
+    B = importlib.import_module("seq-recommendations_amd.batching")
+    sel = np.arange(len(seqs))
+    a, b = B.pack_flat(flat, starts, sel), B.index_flat(starts, sel)
+    for k in ("order", "lengths", "step_off", "prev", "tok_b", "tok_s", "tok_row"):
+        np.testing.assert_array_equal(getattr(a, k), getattr(b, k))
+    assert b.ids is None and (a.B, a.T, a.n_tok, a.n_sessions) == (b.B, b.T, b.n_tok, b.n_sessions)
