@@ -319,9 +319,10 @@ extern "C" int seqrec_gemm_f32(int a_kcontig, int b_kcontig, int64_t M, int64_t 
     // the c3 shapes, 64x64 beats 128x64 below that (K is short: prologue/epilogue dominate)
     const long t128 = ((M + 127) / 128) * ((N + 127) / 128) * splits;
     const long t12864 = ((M + 127) / 128) * ((N + 63) / 64) * splits;
+    static const long thr = getenv("SEQREC_GEMM_TILE_THR") ? atol(getenv("SEQREC_GEMM_TILE_THR")) : 1024;   // tuning switch
     int rc;
-    if (t128 >= 1024) rc = launch_gemm<128, 128>(a_kcontig, b_kcontig, g, splits, st);
-    else if (t12864 >= 1024) rc = launch_gemm<128, 64>(a_kcontig, b_kcontig, g, splits, st);
+    if (t128 >= thr) rc = launch_gemm<128, 128>(a_kcontig, b_kcontig, g, splits, st);
+    else if (t12864 >= thr) rc = launch_gemm<128, 64>(a_kcontig, b_kcontig, g, splits, st);
     else rc = launch_gemm<64, 64>(a_kcontig, b_kcontig, g, splits, st);
     if (rc) return rc;
     if (splits > 1) {

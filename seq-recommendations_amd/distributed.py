@@ -35,7 +35,7 @@ import torch
 
 from . import _lib
 from ._lib import ptr
-from .engine import Engine, call, CELL, ACT, INT32_MAX
+from .engine import Engine, call, CELL, ACT, INT32_MAX, SPLITK_TARGET_WGS
 
 
 class RowPlan:
@@ -355,7 +355,7 @@ class ShardedEngine(Engine):
             wgrad = [(Hp, GHp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp)]
         wgrad.append((Dp, GHp, n, X, Dp, dPre, GHp, Gd["W"], GHp))
         tiles = sum(((m + 63) // 64) * ((nn_ + 63) // 64) for (m, nn_, *_r) in wgrad)
-        sk = int(max(1, min(32, -(-512 // max(tiles, 1)), n // 128)))
+        sk = int(max(1, min(32, -(-SPLITK_TARGET_WGS // max(tiles, 1)), n // 128)))
         wsp = self.buf("gemm_ws", sum(sk * m * nn_ for (m, nn_, *_r) in wgrad)) if sk > 1 else None
         call("seqrec_gemm_f32_grouped", len(wgrad), 0, 0, _lib.gemm_descs(wgrad), sk, ptr(wsp), st, tag="dW+dU")
         self.gemm(1, 1, n, Dp, GHp, dPre, GHp, P["W"], GHp, dX, Dp, splitk=self._splitk(n, Dp, GHp), tag="dX")

@@ -30,6 +30,10 @@ from ._lib import CELL, ACT, N_GATES, ptr
 from ._lib import call as _raw_call
 
 INT32_MAX = 2 ** 31 - 1
+import os as _os
+# split-K is raised until about this many workgroups are in flight (4 per CU; measured on the c3
+# backward shapes: 512 -> 1024 takes dEneg from 53 to 45 us and dH from 46 to 43 us)
+SPLITK_TARGET_WGS = int(_os.environ.get("SEQREC_SPLITK_WGS", "1024"))
 
 # Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg):
 # _PROF = {"events": [(name, tag, start_event, end_event), ...]} while enabled, else None.
@@ -229,9 +233,9 @@ class Engine:
 
     @staticmethod
     def _splitk(M, N, K):
-        """Split K until ~512 workgroups (2 per CU) are in flight; slabs are reduced deterministically."""
+        """Split K until ~SPLITK_TARGET_WGS workgroups are in flight; slabs are reduced deterministically."""
         tiles = ((M + 63) // 64) * ((N + 63) // 64)
-        return int(max(1, min(32, -(-512 // max(tiles, 1)), K // 128)))
+        return int(max(1, min(32, -(-SPLITK_TARGET_WGS // max(tiles, 1)), K // 128)))
 
     # ------------------------------------------------------------------ parameters (Keras layouts)
     def _gate_pad(self, w, rows_p):
@@ -681,7 +685,7 @@ class Engine:
         if wgrad:
             # the weight gradients A^T . dPre all reduce over the tokens: one grouped split-K launch
             tiles = sum(((m + 63) // 64) * ((nn_ + 63) // 64) for (m, nn_, *_rest) in wgrad)
-            sk = int(max(1, min(32, -(-512 // max(tiles, 1)), n // 128)))
+            sk = int(max(1, min(32, -(-SPLITK_TARGET_WGS // max(tiles, 1)), n // 128)))
             wsz = sum(sk * m * nn_ for (m, nn_, *_rest) in wgrad)
             wsp = self.buf("gemm_ws", wsz) if sk > 1 else None
             call("seqrec_gemm_f32_grouped", len(wgrad), 0, 0, _lib.gemm_descs(wgrad), sk, ptr(wsp), st, tag="dW+dU")
