@@ -14,6 +14,7 @@
 // into registers from a per-(column block, wave) packed layout, all loads issued up front.
 // Exact fp32 (v_mfma_f32_16x16x4_f32).  Needs the step offsets on the HOST to size the launches.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -39,6 +40,7 @@ struct StepArgs {
     const float* dHout; float* dPre; float* dHc; float* tmpc;
     const float* rmask;                       // recurrent-dropout multipliers [G][B][H] (sorted session rows) or null
     int B;
+    int cbn, xcd;                             // column blocks of this launch; XCD-aware tile placement on/off
 };
 
 // per-step geometry from the device-resident step offsets (uniform scalar loads)
@@ -51,6 +53,29 @@ __device__ __forceinline__ StepArgs resolve(StepArgs a) {
     a.bnext = a.t + 1 < a.T ? so[a.t + 2] - so[a.t + 1] : 0;
     a.first = a.t == 0;
     return a;
+}
+
+// Tile placement (speed only, never correctness): the launch is 1-D and workgroup ids are dealt
+// round-robin to the 8 XCDs, each with its own L2.  Row block rb is pinned to XCD rb % 8 with ALL its
+// column blocks, at every step and in both directions: the h / r*h / dpre rows one launch writes are
+// then still in the L2 of the XCD whose workgroups read them in the next launch (instead of being
+// fetched by up to 8 L2s from the Infinity Cache), and every XCD keeps the packed U resident.
+// Grid = 8 * cbn * ceil(rb / 8); workgroups of XCDs without a row block exit at once.
+__device__ __forceinline__ bool tile_of(const StepArgs& a, int& r0, int& cb) {
+    const int L = blockIdx.x;
+    int rbk;
+    if (a.xcd) {
+        const int x = L & 7, s = L >> 3;
+        const int j = s / a.cbn;
+        cb = s - j * a.cbn;
+        rbk = x + 8 * j;
+    } else {                                  // plain order: row blocks fastest
+        const int rbn = gridDim.x / a.cbn;
+        cb = L / rbn;
+        rbk = L - cb * rbn;
+    }
+    r0 = rbk * 16;
+    return r0 < a.bt;
 }
 
 // Workgroup = 16 session rows x 16 output columns; the 4 waves split K (wave w owns k-blocks
@@ -130,14 +155,14 @@ __global__ void pack_lstm_fwd_kernel(const float* __restrict__ U, int H, float* 
 template <int J, int ACT, int PHASE>
 __global__ __launch_bounds__(256) void gru_step_fwd(StepArgs a_in) {
     const StepArgs a = resolve(a_in);
-    if ((int)blockIdx.x * 16 >= a.bt) return;
+    int r0, cb;
+    if (!tile_of(a, r0, cb)) return;
     // PHASE 0: [z|r] = hs(xw + h_prev.U_zr), r*h_prev        grid (rows/16, 2H/16)
     // PHASE 1: h~ = act(xw_h + (r*h_prev).U_h), h = z h_prev + (1-z) h~   grid (rows/16, H/16)
     constexpr int H = 64 * J, LDA = H + 2, GH = 3 * H;
     __shared__ float ab[16 * LDA];
     __shared__ float red[4 * 256];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int r0 = blockIdx.x * 16, cb = blockIdx.y;
     const int nact = min(16, a.bt - r0);
     const int row = tid >> 4, col = 16 * cb + (tid & 15);     // this thread's output element
     const bool ok = row < nact;
@@ -197,7 +222,8 @@ __global__ __launch_bounds__(256) void gru_step_fwd(StepArgs a_in) {
 template <int J, int ACT, int PHASE>
 __global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a_in) {
     const StepArgs a = resolve(a_in);
-    if ((int)blockIdx.x * 16 >= a.bt) return;
+    int r0, cb;
+    if (!tile_of(a, r0, cb)) return;
     // PHASE 0 (grid rows/16 x H/16): d = dh (1-z) act'(h~) for the whole row -> LDS; drh = d . U_h^T (own cols);
     //          dpre_z, dpre_r, dpre_h -> dPre;  dcar = dh z + drh r -> tmpc
     // PHASE 1 (grid rows/16 x H/16, skipped at t = 0): dh_prev = tmpc + [dpre_z|dpre_r] . U_zr^T -> dHc[prev token]
@@ -206,7 +232,6 @@ __global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a_in) {
     __shared__ float ab[16 * LDA];
     __shared__ float red[4 * 256];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int r0 = blockIdx.x * 16, cb = blockIdx.y;
     const int nact = min(16, a.bt - r0);
     const int row = tid >> 4, col = 16 * cb + (tid & 15);
     const bool ok = row < nact;
@@ -283,12 +308,12 @@ __global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a_in) {
 template <int J, int ACT, bool RD>
 __device__ __forceinline__ void lstm_step_fwd_body(const StepArgs& a_in) {
     const StepArgs a = resolve(a_in);
-    if ((int)blockIdx.x * 16 >= a.bt) return;
+    int r0, cb;
+    if (!tile_of(a, r0, cb)) return;
     constexpr int H = 64 * J, LDA = H + 2, GH = 4 * H, G4 = H / 16;
     __shared__ float ab[(RD ? 4 : 1) * 16 * LDA];
     __shared__ float red[4 * 256];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int r0 = blockIdx.x * 16, cb = blockIdx.y;
     const int nact = min(16, a.bt - r0);
     const int row = tid >> 4, col = 16 * cb + (tid & 15);
     const bool ok = row < nact;
@@ -360,12 +385,12 @@ template <int J, int ACT> __global__ __launch_bounds__(256) void lstm_step_fwd_r
 template <int J, int ACT>
 __global__ __launch_bounds__(256) void srnn_step_fwd(StepArgs a_in) {
     const StepArgs a = resolve(a_in);
-    if ((int)blockIdx.x * 16 >= a.bt) return;
+    int r0, cb;
+    if (!tile_of(a, r0, cb)) return;
     constexpr int H = 64 * J, LDA = H + 2;
     __shared__ float ab[16 * LDA];
     __shared__ float red[4 * 256];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int r0 = blockIdx.x * 16, cb = blockIdx.y;
     const int nact = min(16, a.bt - r0);
     const int row = tid >> 4, col = 16 * cb + (tid & 15);
     const bool ok = row < nact;
@@ -439,12 +464,12 @@ __global__ void pointwise_bwd_step(StepArgs a_in) {
 template <int K>
 __global__ __launch_bounds__(256) void gemm_bwd_step(StepArgs a_in, int H, int ldp) {
     const StepArgs a = resolve(a_in);
-    if ((int)blockIdx.x * 16 >= a.bt) return;
+    int r0, cb;
+    if (!tile_of(a, r0, cb)) return;
     constexpr int LDA = K + 2;
     __shared__ float ab[16 * LDA];
     __shared__ float red[4 * 256];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int r0 = blockIdx.x * 16, cb = blockIdx.y;
     const int nact = min(16, a.bt - r0);
     const int row = tid >> 4, col = 16 * cb + (tid & 15);
     const bool ok = row < nact;
@@ -478,8 +503,20 @@ __global__ __launch_bounds__(256) void gemm_bwd_step(StepArgs a_in, int H, int l
     bstore(rC, ok ? (row * H + col) * 4 : INVALID_OFF, (a.pprev0 + r0) * H * 4, acc);
 }
 
-template <typename KF> int launch_step(KF kern, dim3 grid, const StepArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, a);
+bool xcd_placement() {
+    static const bool on = !(getenv("SEQREC_SCAN_XCD") && atoi(getenv("SEQREC_SCAN_XCD")) == 0);   // A/B switch
+    return on;
+}
+// grid = (row blocks, column blocks) -> the 1-D placement grid of tile_of()
+unsigned place_grid(dim3 grid, StepArgs& a) {
+    a.cbn = (int)grid.y;
+    a.xcd = xcd_placement() ? 1 : 0;
+    return a.xcd ? 8u * grid.y * ((grid.x + 7) / 8) : grid.x * grid.y;
+}
+template <typename KF> int launch_step(KF kern, dim3 grid, const StepArgs& a_in, hipStream_t st) {
+    StepArgs a = a_in;
+    const unsigned n = place_grid(grid, a);
+    hipLaunchKernelGGL(kern, dim3(n), dim3(256), 0, st, a);
     SEQREC_LAUNCH_CHECK();
     return 0;
 }
@@ -533,7 +570,9 @@ template <int CELL> int launch_pointwise(int act, const StepArgs& a, hipStream_t
     return 0;
 }
 
-int launch_gemm_bwd(int K, dim3 grid, const StepArgs& a, int H, int ldp, hipStream_t st) {
+int launch_gemm_bwd(int K, dim3 grid2, const StepArgs& a_in, int H, int ldp, hipStream_t st) {
+    StepArgs a = a_in;
+    const dim3 grid(place_grid(grid2, a));
     switch (K) {
         case 64: hipLaunchKernelGGL(gemm_bwd_step<64>, grid, dim3(256), 0, st, a, H, ldp); break;
         case 128: hipLaunchKernelGGL(gemm_bwd_step<128>, grid, dim3(256), 0, st, a, H, ldp); break;
