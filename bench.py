@@ -109,10 +109,10 @@ def kernel_model(cfgd, n_tok, K, B):
 
 def pmc_traffic(kernel, t_mean, a):
     """HBM bytes per call of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_v2_c3_pmc_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of
+    (profiles/r01_v3_c3_pmc_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of
     this same command; FETCH_SIZE doubled per the gfx950 correction for wide coalesced reads).
     Only valid for the workload those passes profiled (c3, MSNBC-shaped); None otherwise."""
-    path = os.path.join(ROOT, "profiles", "r01_v2_c3_pmc_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_v3_c3_pmc_hbm_traffic.json")
     if a.config != "c3" or a.saturated or not os.path.exists(path):
         return None
     pm = json.load(open(path))
@@ -127,7 +127,7 @@ def pmc_traffic(kernel, t_mean, a):
             return None
         launches = t_mean - (1 if (i == 1 and "bwd" in kernel) else 0)     # bwd phase 1 is skipped at t = 0
         tot += launches * (ent["fetch_kib_x2"] + ent["write_kib"]) * 1024.0
-    return {"bytes_per_call": round(tot), "source": "profiles/r01_v2_c3_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+    return {"bytes_per_call": round(tot), "source": "profiles/r01_v3_c3_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
 
 
 def main():
