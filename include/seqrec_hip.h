@@ -222,6 +222,13 @@ int seqrec_sample_negatives(uint64_t seed, uint64_t step, int K, const uint32_t*
 int seqrec_dropout_mask(uint64_t seed, uint64_t stream_id, const int64_t* rowkey, int64_t n_rows,
                         int width, int64_t ld, double rate, float* out, void* stream);
 
+/* ---- kernel regularizer of the y_to_y / to_y Dense layers: GaussPriorRegularizer (model.py:71-91,
+ *      `K.sum(1/(2 var) * K.square(x - means))`) and keras.regularizers.l2 (means == NULL,
+ *      strength = l).  grad (nullable) += 2 strength (w - means);  *loss_accum (nullable) += strength
+ *      sum (w - means)^2 -- Keras adds the penalty to the reported loss, train and validation alike. */
+int seqrec_prior_grad(const float* w, const float* means, int64_t n, float strength, float* grad,
+                      float* loss_accum, void* stream);
+
 /* ---- device-side ragged batcher: counterpart of the pairing x = s[i], y = s[i+1] of
  *      FullModelPreprocessor.transform_data (preprocessor.py:67-94) on ids, and of datasets.build_xs
  *      (datasets.py:97-113), for a dataset that lives in HBM as one flat id array

@@ -489,6 +489,31 @@ def clip_scale(sqnorm, clipnorm):
     return float(clipnorm / n) if n >= clipnorm else 1.0
 
 
+def prior_penalty(w, means, strength):
+    """Kernel regularizer of the y_to_y / to_y Dense layers.  GaussPriorRegularizer (model.py:71-91):
+    ``K.sum(1/(2 var) * K.square(x - means))`` -> strength = 1/(2 var); keras ``l2(l)``: means = 0,
+    strength = l.  Keras adds the value to the loss it reports (train and validation) and to the
+    objective it differentiates.  -> (penalty, d penalty / d w)"""
+    d = np.asarray(w, dtype=np.float64) - (0.0 if means is None else np.asarray(means, dtype=np.float64))
+    return float(strength * np.sum(d * d)), (2.0 * strength * d).astype(np.asarray(w).dtype)
+
+
+def add_priors(params, grads, priors):
+    """grads (from OracleNet.backward) += penalty gradients; row-sparse entries become dense.
+    priors: {name: (means or None, strength)}.  -> total penalty"""
+    total = 0.0
+    for k, (means, strength) in priors.items():
+        pen, g = prior_penalty(params[k], means, strength)
+        total += pen
+        cur = grads.get(k)
+        if isinstance(cur, tuple):
+            dense = np.zeros(params[k].shape, dtype=params[k].dtype)
+            np.add.at(dense, cur[0], cur[1])
+            cur = dense
+        grads[k] = g if cur is None else cur + g
+    return total
+
+
 def adagrad_step(params, accum, grads, lr=0.01, eps=1e-8, clipnorm=1.0, frozen=()):
     """In-place update.  ``accum`` holds one zero-initialised accumulator per param.
     Row-sparse grads touch only their rows -- identical to the dense rule, since a

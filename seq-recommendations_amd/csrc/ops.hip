@@ -591,6 +591,37 @@ extern "C" int seqrec_fill_f32(float* x, float v, int64_t n, void* stream) {
     return 0;
 }
 // ---------------------------------------------------------------------------------------------
+// Gaussian-prior / L2 kernel regularizer (model.py:71-91): R = strength * sum (w - mean)^2
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ void prior_grad_kernel(const float* __restrict__ w, const float* __restrict__ means, long n, float strength,
+                                  float* __restrict__ grad, float* __restrict__ loss) {
+    __shared__ float part[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float d = w[i] - (means ? means[i] : 0.f);
+        s += d * d;
+        if (grad) grad[i] += 2.f * strength * d;
+    }
+    if (!loss) return;
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, strength * (part[0] + part[1] + part[2] + part[3]));
+}
+}  // namespace
+extern "C" int seqrec_prior_grad(const float* w, const float* means, int64_t n, float strength, float* grad,
+                                 float* loss_accum, void* stream) {
+    if (n < 0) return SEQREC_E_ARG;
+    if (n == 0) return 0;
+    if (!w || (!grad && !loss_accum)) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(prior_grad_kernel, dim3(grid_for(n, 1024, 1024)), dim3(256), 0, as_stream(stream), w, means, (long)n,
+                       strength, grad, loss_accum);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // device-side ragged batcher: the dataset stays in HBM as one flat id array
 // ---------------------------------------------------------------------------------------------
 namespace {

@@ -106,6 +106,8 @@ class NetConfig:
     x_to_y: bool = False          # logits += xs_t . Wxy   (history features, x_dim wide)
     x_dim: int = 0
     diag_b: bool = True           # OnlyNonZeroDiagonal on Wxy (model.py:48-66): re-applied after every update
+    priors: tuple = ()            # parameters that carry a kernel regularizer (Engine.set_prior); a table listed
+                                  # here is updated densely (the penalty's gradient touches every row)
 
     @property
     def G(self):
@@ -174,8 +176,13 @@ class Engine:
             self.table_params.add("E")
         if c.input == "onehot":
             self.table_params.add("Wk")
-        if c.y_to_y:
+        if c.y_to_y and "Wyy" not in c.priors:
             self.table_params.add("Wyy")
+        for k in c.priors:
+            if k not in ("Wyy", "Wout", "Wxy"):
+                raise ValueError("kernel regularizers exist on the y_to_y and to_y Dense kernels only (model.py:383,389)")
+        self.priors = {}          # name -> (padded means tensor or None, strength)
+        self.reg_sum = z(1)
         if c.output == "sampled":
             if not c.tied:
                 self.table_params.add("Eout")
@@ -319,6 +326,27 @@ class Engine:
         al = torch.from_numpy(np.asarray(alias, dtype=np.int32).copy()).to(self.dev)
         lq = None if logq is None else torch.from_numpy(np.asarray(logq, dtype=np.float32).copy()).to(self.dev)
         self.sampler = (th, al, lq)
+
+    def set_prior(self, name, means, strength):
+        """Kernel regularizer strength * sum (w - means)^2 on parameter `name` (must be listed in
+        NetConfig.priors): GaussPriorRegularizer(means, var) -> strength = 1 / (2 var) (model.py:80);
+        keras l2(l) -> means None, strength = l."""
+        if name not in self.cfg.priors:
+            raise ValueError("%s is not declared in NetConfig.priors" % name)
+        mt = None
+        if means is not None:
+            mt = torch.zeros_like(self.P[name])
+            m = np.asarray(means, dtype=np.float32)
+            mt[: m.shape[0], : m.shape[1]] = torch.from_numpy(m).to(self.dev)
+        self.priors[name] = (mt, float(strength))
+
+    def _apply_priors(self, with_grad):
+        """reg_sum = sum of the penalties; with_grad: their gradients are added to the dense gradients."""
+        st = self._stream()
+        self.reg_sum.zero_()
+        for name, (mt, strength) in self.priors.items():
+            g = self.Gd[name] if (with_grad and self.trainable[name]) else None
+            call("seqrec_prior_grad", ptr(self.P[name]), ptr(mt), self.P[name].numel(), strength, ptr(g), ptr(self.reg_sum), st)
 
     # ------------------------------------------------------------------ batch upload
     def upload(self, rb):
@@ -604,8 +632,12 @@ class Engine:
                 self.gemm(0, 0, self.Fxp, c.V_out, n, d["xs"], self.Fxp, dl, Vp, Gd["Wxy"], Vp,
                           splitk=self._splitk(self.Fxp, c.V_out, n), tag="dWxy")
             if c.y_to_y:
-                if tr["Wyy"]:
+                if tr["Wyy"] and "Wyy" in self.table_params:
                     sparse_jobs.append(self._job("Wyy", d["ids"], dl, Vp, None, n, Vp, 0))
+                elif tr["Wyy"]:            # regularized: dense gradient = scatter of the batch rows + prior term
+                    Gd["Wyy"].zero_()
+                    sl = self.buf("wyy_slot", c.V_out, dtype=torch.int32)
+                    call("seqrec_rows_scatter_add", ptr(Gd["Wyy"]), ptr(sl), ptr(d["ids"]), ptr(dl), Vp, None, n, Vp, 0, st)
                 if c.yy_bias and tr["byy"]:
                     call("seqrec_colsum", ptr(dl), n, c.V_out, Vp, ptr(Gd["byy"]), 0, ptr(cs_ws), st)
             self.gemm(1, 1, n, Hp, c.V_out, dl, Vp, P["Wout"], Vp, dHd, Hp, splitk=self._splitk(n, Hp, c.V_out), tag="dH")
@@ -696,6 +728,8 @@ class Engine:
         packed = [_lib.rows_jobs(g) for g in groups]
         for arr, cnt in packed:
             call("seqrec_rows_scatter_add_multi", arr, cnt, st)
+        if self.priors:
+            self._apply_priors(True)
         if not apply_update:
             return sparse_jobs
         # ---- global-norm clip over every trainable tensor (Keras clipnorm), then Adagrad
@@ -718,6 +752,8 @@ class Engine:
         if c.x_to_y and c.diag_b and tr["Wxy"]:
             # Keras applies a kernel constraint AFTER the optimizer update: w *= mask (model.py:64)
             call("seqrec_mul", ptr(P["Wxy"]), ptr(self.diag_mask), ptr(P["Wxy"]), P["Wxy"].numel(), st)
+        if self.priors:
+            return self.loss_sum / n + self.reg_sum
         return self.loss_sum / n
 
     def grads(self, d, step=0, negatives=None):
@@ -735,7 +771,8 @@ class Engine:
         for k in self.table_params:
             self.Gt[k].zero_()
             self.slot[k].fill_(INT32_MAX)
-        return float((self.loss_sum / max(n, 1)).item()), out
+        reg = float(self.reg_sum.item()) if self.priors else 0.0
+        return float((self.loss_sum / max(n, 1)).item()) + reg, out
 
     # ------------------------------------------------------------------ evaluation / prediction
     def eval_loss(self, d, negatives=None, step=0):
@@ -743,6 +780,9 @@ class Engine:
         if d["n"] == 0:
             return torch.zeros(1, device=self.dev)
         self.forward(d, train=False, step=step, negatives=negatives)
+        if self.priors:
+            self._apply_priors(False)
+            return self.loss_sum / d["n"] + self.reg_sum
         return self.loss_sum / d["n"]
 
     def predict_rows(self, d):

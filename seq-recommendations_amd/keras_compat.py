@@ -127,6 +127,23 @@ class ModelCheckpoint(Callback):
 
 
 # --------------------------------------------------------------------------- preprocessing helpers
+class l2:
+    """keras.regularizers.l2 (imported by model.py:19, experiments_server.py:7): l * sum(w^2)."""
+
+    def __init__(self, l=0.01):
+        self.l = float(l)
+
+    def terms(self):
+        """-> (means or None, strength) of the penalty strength * sum (w - means)^2"""
+        return None, self.l
+
+    def __call__(self, x):
+        return float(self.l * np.sum(np.square(np.asarray(x, dtype=np.float64))))
+
+    def get_config(self):
+        return {"l2": self.l}
+
+
 def to_categorical(y, num_classes=None):
     y = np.asarray(y, dtype=np.int64).ravel()
     if num_classes is None:

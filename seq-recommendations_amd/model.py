@@ -10,7 +10,8 @@ reference, so its callers (experiments_methods.py, the L5 scripts) work unchange
          reference's small vocabularies: y_to_y (row of a V x V kernel added to the logits, optionally
          frozen at a log-transition-count initialisation), x_to_y (history features through the same
          output Dense as z, OnlyNonZeroDiagonal re-applied after every update), x_to_z (history
-         features concatenated into the cell input).  Kernel regularizers raise NotImplementedError.
+         features concatenated into the cell input); kernel regularizers (GaussPriorRegularizer, l2) on
+         the y_to_y and to_y Dense kernels.
   BaseRNNModel.compile_model / fit_model / fit_generator / predict / evaluate /
       save_model_weights / load_model_weights / get_layer_weights / set_layer_weights_trainable /
       set_layer_weights / get_model_weights / get_activations              model.py:170-238
@@ -50,6 +51,28 @@ class ArrayInitializer:
 
     def get_config(self):
         return {"value": self.values}
+
+
+class GaussPriorRegularizer:
+    """model.py:71-91: penalty sum(1 / (2 var) * (w - means)^2) on a Dense kernel; Keras adds it to the
+    loss it reports and differentiates.  Evaluated on the device by seqrec_prior_grad."""
+
+    def __init__(self, means, var):
+        self.means = np.asarray(means, dtype=np.float32)
+        self.var = var
+
+    def terms(self):
+        return self.means, 1.0 / (2.0 * float(self.var))
+
+    def __call__(self, x):
+        return float(np.sum(1.0 / (2.0 * float(self.var)) * np.square(np.asarray(x, dtype=np.float64) - self.means)))
+
+    def get_config(self):
+        return {"var": float(self.var), "means": self.means}
+
+
+def gauss_prior(means, var):
+    return GaussPriorRegularizer(means, var)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -136,7 +159,8 @@ class SeqModel:
     def __init__(self, timesteps, in_dim, n_classes, z_dim, rnn_type, activation, rnn_name, out_name, use_bias=True,
                  out_bias=False, drop_in=0.0, drop_rec=0.0, drop_out=0.0, kernel_initializer="glorot_uniform",
                  device="cuda:0", y_dim=None, x_dim=0, y_to_z=True, x_to_z=False, y_to_y=False, x_to_y=False,
-                 diag_b=True, ytoy_bias=False, y_to_y_w_initializer="glorot_uniform"):
+                 diag_b=True, ytoy_bias=False, y_to_y_w_initializer="glorot_uniform", y_to_y_regularizer=None,
+                 toy_regularizer=None, frozen_keys=(), toy_reg_on_x=True):
         cell = {"simpleRNN": "simplernn", "LSTM": "lstm", "GRU": "gru"}.get(rnn_type)
         if cell is None:
             raise ValueError("rnn_type must be 'simpleRNN', 'LSTM' or 'GRU' (got %r)" % (rnn_type,))
@@ -182,6 +206,13 @@ class SeqModel:
         self.layers = [Layer(self, rnn_name, rk), Layer(self, out_name, ok)]
         if y_to_y:
             self.layers.append(Layer(self, "y_to_y_output", ["Wyy"] + (["byy"] if ytoy_bias else [])))
+        for r in (y_to_y_regularizer, toy_regularizer):
+            if r is not None and not hasattr(r, "terms"):
+                raise NotImplementedError("kernel regularizer %r: GaussPriorRegularizer and l2 are implemented" % (r,))
+        self.y_to_y_regularizer = y_to_y_regularizer if y_to_y else None
+        self.toy_regularizer = toy_regularizer
+        self.toy_reg_on_x = bool(toy_reg_on_x) and x_to_y      # the penalty covers concat([Wout; Wxy]) (model.py:375-384)
+        self.frozen_keys = set(frozen_keys)
         self.engine = None
         self.input_mode = None
         self.optimizer = None
@@ -215,12 +246,23 @@ class SeqModel:
         if self.engine is not None:
             self.engine.set_param(k, v)
 
+    def _prior_names(self):
+        names = []
+        if self.y_to_y_regularizer is not None:
+            names.append("Wyy")
+        if self.toy_regularizer is not None:
+            names += ["Wout"] + (["Wxy"] if self.toy_reg_on_x else [])
+        return tuple(names)
+
     def _sync_trainable(self):
         if self.engine is not None:
             for l in self.layers:
                 for k in l.keys:
                     for kk in k.split("+"):
                         self.engine.trainable[kk] = l.trainable and kk not in getattr(self, "frozen_keys", ())
+            for kk in getattr(self, "frozen_keys", ()):
+                if kk in self.engine.trainable:
+                    self.engine.trainable[kk] = False
 
     def get_layer(self, name=None, index=None):
         if index is not None:
@@ -270,11 +312,19 @@ class SeqModel:
                           input=input_mode, output="full", use_bias=self.use_bias, out_bias=self.out_bias,
                           drop_in=self.drop_in, drop_rec=self.drop_rec, drop_out=self.drop_out, seed=self.seed,
                           y_to_y=self.y_to_y, yy_bias=self.ytoy_bias, x_to_y=self.x_to_y, x_dim=self.x_dim,
-                          diag_b=self.diag_b)
+                          diag_b=self.diag_b, priors=self._prior_names())
         self.engine = E.Engine(cfg, self.device)
         self.input_mode = input_mode
         for k, v in self.w.items():
             self.engine.set_param(k, v)
+        if self.y_to_y_regularizer is not None:
+            self.engine.set_prior("Wyy", *self.y_to_y_regularizer.terms())
+        if self.toy_regularizer is not None:            # ONE penalty over the to_y kernel concat([Wout; Wxy])
+            means, strength = self.toy_regularizer.terms()
+            H = self.z_dim
+            self.engine.set_prior("Wout", None if means is None else means[:H], strength)
+            if self.toy_reg_on_x:
+                self.engine.set_prior("Wxy", None if means is None else means[H:], strength)
         self._sync_trainable()
         return self.engine
 
@@ -558,7 +608,8 @@ class NoRecurrenceModel(BaseRNNModel):
     """model.py:264-319: softmax(B x_t + A y_{t-1} (+ c)) -- the same logit terms as RNNFullModel's
     y_to_y / x_to_y branches with no recurrent state.  Runs on the same engine with the cell's
     weights frozen at zero (h == 0, so the z -> y Dense contributes nothing and receives no
-    gradient); ``embed_y`` (a rank-z_dim factorisation of A) is not implemented."""
+    gradient).  ``embed_y`` (z = W y_{t-1} + c through Dense(z_dim), then the y -> y Dense on z,
+    model.py:276-288) is a linear-activation cell whose recurrent kernel is frozen at zero."""
 
     def __init__(self, timesteps, x_dim, y_dim, model_name="y_to_y_model", y_to_y_activation="linear",
                  x_to_y_activation="linear", y_to_y_w_initializer=None, out_activation="softmax", mask_value=0.0,
@@ -567,23 +618,41 @@ class NoRecurrenceModel(BaseRNNModel):
         BaseRNNModel.__init__(self, y_dim, model_name=model_name, rnn_type=None)
         if not (connect_x or connect_y):
             raise ValueError("ERROR: the model needs an input! either x or y should be added.")
-        if embed_y:
-            raise NotImplementedError("embed_y (Dense(z_dim) before the y -> y Dense) is not implemented")
-        if y_to_y_regularizer is not None or mask_value != 0.0:
-            raise NotImplementedError("kernel regularizers / non-zero mask values")
+        if mask_value != 0.0:
+            raise NotImplementedError("non-zero mask values")
         if out_activation != "softmax" or y_to_y_activation != "linear" or x_to_y_activation != "linear":
             raise NotImplementedError("output activations other than linear->softmax")
         if y_to_y_w_initializer is None:
             y_to_y_w_initializer = "random_uniform"
+        if embed_y and connect_y:
+            # y_to_z_output = Dense(z_dim)(y): the cell's input kernel (+ bias); y_output = Dense(y_dim)(z): the
+            # output Dense, which carries the y_to_y initializer / regularizer / bias of the reference
+            if y_bias and xy_bias and connect_x:
+                raise NotImplementedError("embed_y with BOTH y_bias and xy_bias (two biases on the same logits)")
+            m = SeqModel(timesteps, y_dim, y_dim, z_dim, "simpleRNN", "linear", "y_to_z_output", "y_output",
+                         use_bias=z_bias, out_bias=y_bias or (xy_bias and connect_x), y_dim=y_dim, x_dim=x_dim, y_to_z=True,
+                         x_to_z=False, y_to_y=False, x_to_y=connect_x, diag_b=diag_b, toy_regularizer=y_to_y_regularizer,
+                         frozen_keys=("U",), toy_reg_on_x=False)       # the x_to_y Dense is a separate, unpenalised layer
+            m.w["U"] = np.zeros_like(m.w["U"])
+            m.w["Wout"] = initialize(y_to_y_w_initializer, (z_dim, y_dim))
+            # the reference's three Dense layers, each with its own weight list
+            m.layers = [Layer(m, "y_to_z_output", ["Wk"] + (["b"] if z_bias else [])),
+                        Layer(m, "y_output", ["Wout"] + (["bout"] if y_bias else []))]
+            if connect_x:
+                k = initialize("glorot_uniform", (x_dim, y_dim))
+                m.w["Wxy"] = k * np.eye(x_dim, y_dim, dtype=np.float32) if diag_b else k
+                m.layers.append(Layer(m, "x_to_y_output", ["Wxy"] + (["bout"] if (xy_bias and not y_bias) else [])))
+            self.model = m
+            return
         m = SeqModel(timesteps, y_dim if connect_y else x_dim, y_dim, 8, "simpleRNN", "relu", "unused_rnn", "x_to_y_output",
                      use_bias=False, out_bias=xy_bias, y_dim=y_dim, x_dim=x_dim, y_to_z=connect_y, x_to_z=not connect_y,
                      y_to_y=connect_y, x_to_y=connect_x, diag_b=diag_b, ytoy_bias=y_bias,
-                     y_to_y_w_initializer=y_to_y_w_initializer)
+                     y_to_y_w_initializer=y_to_y_w_initializer, y_to_y_regularizer=y_to_y_regularizer,
+                     frozen_keys=("Wout",))
         # no recurrent path: zero, frozen cell and zero z -> y kernel
         for k in ("Wk", "U", "Wout"):
             m.w[k] = np.zeros_like(m.w[k])
         m.layers[0].trainable = False
-        m.frozen_keys = {"Wout"}
         if connect_y:
             m.get_layer("y_to_y_output").name = "y_output"
         self.model = m
@@ -601,8 +670,6 @@ class RNNFullModel(BaseRNNModel):
             raise ValueError("ERROR: the model needs an input into z's! either x or y should be added.")
         if out_activation != "softmax" or xz_to_y_activation != "linear" or y_to_y_activation != "linear":
             raise NotImplementedError("output activations other than linear->softmax")
-        if toy_regularizer is not None or y_to_y_regularizer is not None:
-            raise NotImplementedError("kernel regularizers (GaussPriorRegularizer, model.py:71-91) are not implemented")
         if y_to_y_w_initializer is None:
             y_to_y_w_initializer = "glorot_uniform"
         # the reference passes kernel_initializer only to the LSTM (model.py:345-352)
@@ -612,7 +679,8 @@ class RNNFullModel(BaseRNNModel):
                               use_bias=z_bias, out_bias=toy_bias, drop_in=max(y_to_z_dropout, 0.0),
                               drop_rec=z_to_z_dropout, drop_out=max(z_to_y_dropout, 0.0), kernel_initializer=kinit,
                               y_dim=y_dim, x_dim=x_dim, y_to_z=y_to_z, x_to_z=x_to_z, y_to_y=y_to_y, x_to_y=x_to_y,
-                              diag_b=diag_b, ytoy_bias=ytoy_bias, y_to_y_w_initializer=y_to_y_w_initializer)
+                              diag_b=diag_b, ytoy_bias=ytoy_bias, y_to_y_w_initializer=y_to_y_w_initializer,
+                              y_to_y_regularizer=y_to_y_regularizer, toy_regularizer=toy_regularizer)
 
 
 class ValLossHistoryCut(Callback):

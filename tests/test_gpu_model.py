@@ -335,3 +335,112 @@ def test_no_recurrence_model_matches_oracle(connect_x, connect_y):
     assert np.all(np.abs(got - np.array(ref)) <= 1e-3 * np.array(ref)), (got, ref)
     assert got[1] < got[0]
     assert not m.get_layer_weights("unused_rnn")[0].any()           # the frozen zero cell stayed zero
+
+
+def test_kernel_regularizers_match_oracle():
+    """GaussPriorRegularizer on the y_to_y kernel (model.py:71-91,389) + l2 on the to_y kernel
+    (model.py:383): the penalty is part of the reported loss (train and validation) and of the gradient;
+    2-epoch trajectory against the oracle with the penalties restated by oracle.nn.prior_penalty."""
+    rng = np.random.default_rng(51)
+    V, H, B = 10, 16, 32
+    vocab = {i: i for i in range(V)}
+    seqs = markov_sessions(rng, 128, V, 3, 9)
+    T = max(len(s) for s in seqs) - 1
+    pre = pp.FullModelPreprocessor(vocab, 0., T)
+    x, y, _ = pre.transform_data(seqs, [[[0.0] * V for _ in s] for s in seqs])
+    xs = build_xs_like_reference(seqs, V, T)
+    np.random.seed(9)
+    logA = np.log(np.random.dirichlet(np.ones(V), size=V)).astype(np.float32)
+    var, l = 2.0, 0.02
+    m = model.RNNFullModel(timesteps=T, x_dim=V, y_dim=V, z_dim=H, rnn_type="LSTM", model_name="reg",
+                           y_to_y_w_initializer=model.ArrayInitializer(logA + 0.3), y_to_z=True, y_to_y=True, x_to_y=True,
+                           x_to_z=False, y_to_y_regularizer=model.gauss_prior(logA, var), toy_regularizer=kc.l2(l))
+    w = m.model.get_weights()
+    op = {"Wk": w[0], "U": w[1], "b": w[2], "Wout": w[3][:H].copy(), "Wxy": w[3][H:].copy(), "Wyy": w[4]}
+    priors = {"Wyy": (logA, 1.0 / (2.0 * var)), "Wout": (None, l), "Wxy": (None, l)}
+    assert abs(m.model.y_to_y_regularizer(op["Wyy"]) - onn.prior_penalty(op["Wyy"], logA, 1 / (2 * var))[0]) < 1e-4
+    cfg = dict(cell="lstm", act="relu", input="onehot", output="full", use_bias=True, out_bias=False, tied=False)
+    acc = {k: np.zeros_like(v) for k, v in op.items()}
+    net = onn.OracleNet(cfg, op)
+    mask = onehot_mask(x)
+    ids, tgt = np.argmax(x, axis=2), np.argmax(y, axis=2)
+    ob = lambda idx: {"ids": ids[idx], "tgt": tgt[idx], "mask": mask[idx], "xs": xs[idx]}
+    nv = 32
+    np.random.seed(3)
+    index = np.arange(len(x) - nv)
+    ref_hist, ref_val = [], []
+    for ep in range(2):
+        np.random.shuffle(index)
+        tot = 0.0
+        for s0 in range(0, len(index), B):
+            idx = index[s0:s0 + B]
+            out = net.forward(ob(idx))
+            g = net.backward()
+            pen = onn.add_priors(op, g, priors)
+            onn.adagrad_step(op, acc, g, lr=0.01, eps=1e-8, clipnorm=1.0)
+            op["Wxy"] *= np.eye(V, dtype=np.float32)
+            tot += (out["loss"] + pen) * len(idx)
+        ref_hist.append(tot / len(index))
+        vidx = np.arange(len(x) - nv, len(x))
+        ref_val.append(net.forward(ob(vidx))["loss"] + sum(onn.prior_penalty(op[k], mu, st)[0] for k, (mu, st) in priors.items()))
+    m.compile_model(optimizer=kc.Adagrad(lr=0.01, epsilon=1e-8, clipnorm=1.0))
+    np.random.seed(3)
+    tr = slice(0, len(x) - nv)
+    va = slice(len(x) - nv, len(x))
+    h = m.fit_model([x[tr], xs[tr]], y[tr], validation_data=([x[va], xs[va]], y[va]), n_epochs=2, batch_size=B, verbose=0)
+    got, gotv = np.array(h.history["loss"]), np.array(h.history["val_loss"])
+    assert np.all(np.abs(got - np.array(ref_hist)) <= 1e-3 * np.array(ref_hist)), (got, ref_hist)
+    assert np.all(np.abs(gotv - np.array(ref_val)) <= 1e-3 * np.array(ref_val)), (gotv, ref_val)
+    # the penalty is a visible part of the loss (not a rounding-level term)
+    assert onn.prior_penalty(op["Wyy"], logA, 1 / (2 * var))[0] > 0.05
+
+
+@pytest.mark.parametrize("connect_x", [False, True])
+def test_no_recurrence_embed_y_matches_oracle(connect_x):
+    """NoRecurrenceModel(embed_y=True) (model.py:276-288): z = W y_{t-1} + c through Dense(z_dim), then the
+    y -> y Dense on z (+ the diagonal x -> y term) == a linear cell without recurrence."""
+    rng = np.random.default_rng(61)
+    V, Z, B = 9, 6, 30
+    vocab = {i: i for i in range(V)}
+    seqs = markov_sessions(rng, 90, V, 3, 9)
+    T = max(len(s) for s in seqs) - 1
+    pre = pp.FullModelPreprocessor(vocab, 0., T)
+    x, y, _ = pre.transform_data(seqs, [[[0.0] * V for _ in s] for s in seqs])
+    xs = build_xs_like_reference(seqs, V, T)
+    np.random.seed(13)
+    m = model.NoRecurrenceModel(T, V, V, connect_x=connect_x, connect_y=True, embed_y=True, z_dim=Z, y_bias=True)
+    names = [l.name for l in m.model.layers]
+    assert names == ["y_to_z_output", "y_output"] + (["x_to_y_output"] if connect_x else [])
+    wz, bz = m.get_layer_weights("y_to_z_output")
+    wy, by = m.get_layer_weights("y_output")
+    assert wz.shape == (V, Z) and wy.shape == (Z, V) and by.shape == (V,)
+    op = {"Wk": wz, "U": np.zeros((Z, Z), np.float32), "b": bz, "Wout": wy, "bout": by}
+    if connect_x:
+        op["Wxy"] = m.get_layer_weights("x_to_y_output")[0]
+        assert np.count_nonzero(op["Wxy"] - np.diag(np.diag(op["Wxy"]))) == 0
+    cfg = dict(cell="simplernn", act="linear", input="onehot", output="full", use_bias=True, out_bias=True, tied=False)
+    acc = {k: np.zeros_like(v) for k, v in op.items()}
+    net = onn.OracleNet(cfg, op)
+    mask = onehot_mask(x)
+    ids, tgt = np.argmax(x, axis=2), np.argmax(y, axis=2)
+    ob = lambda idx: {"ids": ids[idx], "tgt": tgt[idx], "mask": mask[idx], "xs": xs[idx]}
+    np.random.seed(6)
+    index = np.arange(len(x))
+    ref = []
+    for ep in range(2):
+        np.random.shuffle(index)
+        tot = 0.0
+        for s0 in range(0, len(x), B):
+            idx = index[s0:s0 + B]
+            out = net.forward(ob(idx))
+            onn.adagrad_step(op, acc, net.backward(), lr=0.05, eps=1e-8, clipnorm=1.0, frozen=("U",))
+            if connect_x:
+                op["Wxy"] *= np.eye(V, dtype=np.float32)
+            tot += out["loss"] * len(idx)
+        ref.append(tot / len(x))
+    m.compile_model(optimizer=kc.Adagrad(lr=0.05, epsilon=1e-8, clipnorm=1.0))
+    np.random.seed(6)
+    h = m.fit_model([x, xs] if connect_x else [x], y, n_epochs=2, batch_size=B, verbose=0)
+    got = np.array(h.history["loss"])
+    assert np.all(np.abs(got - np.array(ref)) <= 1e-3 * np.array(ref)), (got, ref)
+    assert not m.model._get("U").any()                      # the recurrent kernel stayed frozen at zero
