@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--recall-steps", type=int, default=1500, help="extra training steps before Recall@20 (0 = skip)")
     ap.add_argument("--recall-sessions", type=int, default=2048)
     ap.add_argument("--force-sharded", action="store_true", help="use the row-sharded engine even on one GPU")
+    ap.add_argument("--sharded-recall", action="store_true",
+                    help="also compute Recall@20 through the sharded rank counting when N > 1 (default: only for N = 1)")
     return ap.parse_args()
 
 
@@ -260,6 +262,20 @@ def main():
 
     # ---- Recall@20 on held-out sessions after some more training
     recall = None
+    if a.recall_steps > 0 and sharded and (world == 1 or a.sharded_recall):
+        for i in range(a.recall_steps):
+            eng.train_step(batches[step % nb], lr=0.01, eps=1e-8, clipnorm=1.0, step=step)
+            step += 1
+        per = a.recall_sessions // world                       # every rank scores the same number of held-out sessions
+        base = world * nb * a.batch + rank * per
+        acc = torch.zeros(2, dtype=torch.float64, device=dev)
+        for s in range(0, per, a.batch):
+            d = eng.upload(Bt.pack_flat(flat, starts, np.arange(base + s, base + min(per, s + a.batch))))
+            rk = eng.rank_counts(d)
+            acc[0] += (rk < 20).sum()
+            acc[1] += d["n"]
+        dist.all_reduce(acc)
+        recall = float(acc[0].item() / max(acc[1].item(), 1.0))
     if a.recall_steps > 0 and not sharded:
         for i in range(a.recall_steps):
             eng.train_step(batches[step % nb], lr=0.01, eps=1e-8, clipnorm=1.0, step=step)

@@ -248,6 +248,16 @@ int seqrec_rank_count(const float* hd, int H, const float* Eout, const float* bo
                       const int32_t* tgt, int64_t n, int V, int32_t* rank, float* thr_workspace /* n floats */,
                       void* stream);
 
+/*      thr[i] = hd[i,:] . Eout[tgt[i],:] (+ bout[tgt[i]])  -- the target score on its own */
+int seqrec_target_score(const float* hd, int H, const float* Eout, const float* bout, const int32_t* tgt,
+                        int64_t n, float* thr, void* stream);
+/*      row-sharded tables: the caller supplies the target scores thr[i] (the target rows live on
+ *      other ranks) and tgt_local[i] = the target's row in THIS shard or -1; rank[i] += the shard's
+ *      count, so an all-reduce over the ranks gives the global rank. */
+int seqrec_rank_count_thr(const float* hd, int H, const float* Eout, const float* bout,
+                          const int32_t* tgt_local, const float* thr, int64_t n, int V, int32_t* rank,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,8 @@ _SIGS = {
     "seqrec_sample_negatives": [U64, U64, I, P, P, I, P, P],
     "seqrec_dropout_mask": [U64, U64, P, L, I, L, D, P, P],
     "seqrec_rank_count": [P, I, P, P, P, L, I, P, P, P],
+    "seqrec_rank_count_thr": [P, I, P, P, P, P, L, I, P, P],
+    "seqrec_target_score": [P, I, P, P, P, L, P, P],
 }
 _RESTYPES = {
     "seqrec_build_arch": C.c_char_p,

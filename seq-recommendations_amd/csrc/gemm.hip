@@ -353,6 +353,21 @@ __global__ void target_score_kernel(const float* __restrict__ hd, int H, const f
 }
 }  // namespace
 
+namespace {
+int rank_count_launch(const float* hd, int H, const float* Eout, const float* bout, const int32_t* tgt, const float* thr,
+                      int64_t n, int V, int32_t* rank, hipStream_t st) {
+    GemmArgs g;
+    g.A = hd; g.B = Eout; g.C = nullptr; g.bias = bout;
+    g.M = n; g.N = V; g.K = H; g.lda = H; g.ldb = H; g.ldc = 0;
+    g.k_per_split = (H + 31) / 32 * 32;
+    g.accumulate = 0;
+    g.a_vec = ((reinterpret_cast<uintptr_t>(hd) & 15) == 0) && (H % 4 == 0);
+    g.b_vec = ((reinterpret_cast<uintptr_t>(Eout) & 15) == 0) && (H % 4 == 0);
+    g.epi = 1; g.tgt = tgt; g.thr = thr; g.rank = rank;
+    return launch_gemm<128, 128>(1, 1, g, 1, st);
+}
+}  // namespace
+
 extern "C" int seqrec_rank_count(const float* hd, int H, const float* Eout, const float* bout,
                                  const int32_t* tgt, int64_t n, int V, int32_t* rank, float* thr_workspace,
                                  void* stream) {
@@ -363,15 +378,29 @@ extern "C" int seqrec_rank_count(const float* hd, int H, const float* Eout, cons
     hipLaunchKernelGGL(target_score_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, hd, H, Eout, bout, tgt, (long)n,
                        thr_workspace);
     SEQREC_LAUNCH_CHECK();
-    GemmArgs g;
-    g.A = hd; g.B = Eout; g.C = nullptr; g.bias = bout;
-    g.M = n; g.N = V; g.K = H; g.lda = H; g.ldb = H; g.ldc = 0;
-    g.k_per_split = (H + 31) / 32 * 32;
-    g.accumulate = 0;
-    g.a_vec = ((reinterpret_cast<uintptr_t>(hd) & 15) == 0) && (H % 4 == 0);
-    g.b_vec = ((reinterpret_cast<uintptr_t>(Eout) & 15) == 0) && (H % 4 == 0);
-    g.epi = 1; g.tgt = tgt; g.thr = thr_workspace; g.rank = rank;
-    return launch_gemm<128, 128>(1, 1, g, 1, st);
+    return rank_count_launch(hd, H, Eout, bout, tgt, thr_workspace, n, V, rank, st);
+}
+
+extern "C" int seqrec_target_score(const float* hd, int H, const float* Eout, const float* bout, const int32_t* tgt,
+                                   int64_t n, float* thr, void* stream) {
+    if (n < 0 || H <= 0) return SEQREC_E_ARG;
+    if (n == 0) return 0;
+    if (!hd || !Eout || !tgt || !thr) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(target_score_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), hd, H, Eout, bout,
+                       tgt, (long)n, thr);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// row-sharded form: thresholds are given (the target rows live on other ranks), `tgt_local` is the
+// target's row in THIS shard or -1; rank accumulates the shard's count.
+extern "C" int seqrec_rank_count_thr(const float* hd, int H, const float* Eout, const float* bout,
+                                     const int32_t* tgt_local, const float* thr, int64_t n, int V, int32_t* rank,
+                                     void* stream) {
+    if (n < 0 || V < 0 || H <= 0) return SEQREC_E_ARG;
+    if (n == 0 || V == 0) return 0;
+    if (!hd || !Eout || !tgt_local || !thr || !rank) return SEQREC_E_ARG;
+    return rank_count_launch(hd, H, Eout, bout, tgt_local, thr, n, V, rank, as_stream(stream));
 }
 
 // ---- grouped form: up to 4 problems with the same layout flags and split count in ONE launch

@@ -309,7 +309,7 @@ class ShardedEngine(Engine):
             return self._step_unified(d, lr, eps, clipnorm, step, apply_update)
         return self._step_split(d, lr, eps, clipnorm, step, apply_update)
 
-    def _cell_and_loss(self, d, X, Etgt, Eneg, neg, dX, dEtgt, dEneg):
+    def _cell_and_loss(self, d, X, Etgt, Eneg, neg, dX, dEtgt, dEneg, train=True):
         """Everything between the two exchanges: x.W, scan, sampled softmax CE, BPTT, dense weight
         gradients; writes the three row-gradient blocks."""
         c, P = self.cfg, self.P
@@ -334,6 +334,8 @@ class ShardedEngine(Engine):
         call("seqrec_sampled_softmax_ce_rows", ptr(ln), K, ptr(Hd), Hp, ptr(Etgt), ptr(d.get("lq_tgt")), ptr(lq_neg),
              ptr(d["tgt"]), ptr(neg), n, K, inv, ptr(loss_rows), ptr(dlt), st)
         call("seqrec_reduce_sum", ptr(loss_rows), n, ptr(self.loss_sum), 0, st)
+        if not train:
+            return
         # -- backward
         ar = d["arange"]
         dHd = self.buf("dHd", n, Hp)
@@ -375,7 +377,9 @@ class ShardedEngine(Engine):
              _lib.ptr_array([self.A[k] for k in dk]), gp, nn, lr, eps, ptr(self.scale), st)
         self.upack_dirty = True
 
-    def _step_unified(self, d, lr, eps, clipnorm, step, apply_update):
+    def _rows_in(self, d, step):
+        """Forward exchange of the unified path (collective 1): -> (xen [2n + K, w] = input rows, target
+        rows, negative rows; neg int32[K] global ids of the negatives)."""
         c, R = self.cfg, self.R
         st = self._stream()
         n, w, K = d["n"], self.Hp, c.K
@@ -395,6 +399,72 @@ class ShardedEngine(Engine):
         self._take(recv, d["take_idx"], xen)
         neg = self.buf("neg", K, dtype=torch.int32)
         call("seqrec_index_affine_i32", ptr(neg), None, ptr(recv), ptr(d["negid_idx"]), K, 1, 0, st)
+        return xen, neg
+
+    def eval_loss(self, d, negatives=None, step=0):
+        """Sampled-softmax CE of this rank's batch (no update), scaled like train_step's return value."""
+        if not self.unified:
+            raise NotImplementedError("sharded evaluation needs the unified tables (D == H)")
+        n = d["n"]
+        xen, neg = self._rows_in(d, step)
+        self._cell_and_loss(d, xen[:n], xen[n:2 * n], xen[2 * n:], neg, None, None, None, train=False)
+        return self.loss_sum * (self.R / d["n_total"])
+
+    def rank_counts(self, d):
+        """Global rank of every target of THIS rank's tokens (Recall@K = mean(rank < K)): hidden rows and
+        target scores of all ranks are all-gathered, every rank counts against its own Eout shard
+        (seqrec_rank_count_thr) and the partial counts are summed with one all-reduce."""
+        if not self.unified:
+            raise NotImplementedError("sharded evaluation needs the unified tables (D == H)")
+        c, R, st = self.cfg, self.R, self._stream()
+        n, w = d["n"], self.Hp
+        xen, _ = self._rows_in(d, 0)
+        Hd = self._hidden(d, xen[:n])
+        thr = self.buf("thr", n)
+        call("seqrec_target_score", ptr(Hd), w, ptr(xen[n:2 * n]), None, ptr(d["arange"]), n, ptr(thr), st)
+        nm = torch.tensor([n], dtype=torch.int64, device=self.dev)
+        self.dist.all_reduce(nm, op=self.dist.ReduceOp.MAX, group=self.group)
+        nmax = int(nm.item())
+        pay = torch.zeros((nmax, w + 2), dtype=torch.float32, device=self.dev)
+        pay[:, w] = float("inf")                                     # padding rows never count
+        pay[:n, :w] = Hd
+        pay[:n, w] = thr
+        pay[:n, w + 1] = d["tgt"].view(torch.float32)
+        pay[n:, w + 1] = torch.full((nmax - n,), -1, dtype=torch.int32, device=self.dev).view(torch.float32)
+        parts = [torch.empty_like(pay) for _ in range(R)]
+        if R > 1:
+            self.dist.all_gather(parts, pay, group=self.group)
+        else:
+            parts = [pay]
+        allp = torch.cat(parts)
+        Hall = allp[:, :w].contiguous()
+        thr_all = allp[:, w].contiguous()
+        tg = allp[:, w + 1].contiguous().view(torch.int32).long()
+        tgt_local = torch.where((tg >= 0) & (tg % R == self.rank), tg // R, torch.full_like(tg, -1)).to(torch.int32)
+        counts = torch.zeros(R * nmax, dtype=torch.int32, device=self.dev)
+        Et = self.P["E" if c.tied else "Eout"]
+        call("seqrec_rank_count_thr", ptr(Hall), w, ptr(Et), None, ptr(tgt_local), ptr(thr_all), R * nmax, Et.shape[0],
+             ptr(counts), st)
+        self.dist.all_reduce(counts, group=self.group)
+        return counts[self.rank * nmax: self.rank * nmax + n].clone()
+
+    def _hidden(self, d, X):
+        P = self.P
+        n, Hp, GHp, Dp = d["n"], self.Hp, self.GHp, self.Dp
+        XW = self.buf("XW", n, GHp)
+        self.gemm(1, 0, n, GHp, Dp, X, Dp, P["W"], GHp, XW, GHp, bias=P.get("b"), tag="xw")
+        Hout = self.buf("Hout", n, Hp); gates = self.buf("gates", n, GHp); aux = self.buf("aux", n, Hp)
+        self._scan_fwd(d, XW, Hout, gates, aux)
+        return Hout
+
+    def _step_unified(self, d, lr, eps, clipnorm, step, apply_update):
+        c, R = self.cfg, self.R
+        st = self._stream()
+        n, w, K = d["n"], self.Hp, c.K
+        Kr = K // R
+        plan = d["plan"]
+        send_idx = d["send_idx"]
+        xen, neg = self._rows_in(d, step)
         gall = self.buf("gall", 2 * n + K, w)
         self._cell_and_loss(d, xen[:n], xen[n:2 * n], xen[2 * n:], neg, gall[:n], gall[n:2 * n], gall[2 * n:])
         # -- row gradients travel the same routes back; one scatter list into the unified gradient table

@@ -35,9 +35,11 @@ class CpuStagedDist:
                                input_split_sizes=input_split_sizes)
         out.copy_(o)
 
-    def all_reduce(self, t, group=None):
+    ReduceOp = dist.ReduceOp
+
+    def all_reduce(self, t, op=dist.ReduceOp.SUM, group=None):
         c = t.detach().cpu()
-        dist.all_reduce(c)
+        dist.all_reduce(c, op=op)
         t.copy_(c)
 
     def all_gather(self, outs, t, group=None):
@@ -91,8 +93,30 @@ def main():
         losses = []
         for s, per_rank in enumerate(steps):
             d = eng.upload(Bt.pack_sessions(per_rank[rank]))
+            if eng.unified and s == 0:
+                ev = float(eng.eval_loss(d, step=s).item())          # forward only, same negatives, same weights
             l = eng.train_step(d, lr=0.01, eps=1e-8, clipnorm=1.0, step=s)
             losses.append(float(l.item()))
+            if eng.unified and s == 0:
+                assert ev == losses[0], (ev, losses[0])
+        if eng.unified:
+            # sharded Recall@K support: global rank of every target, counted shard by shard
+            rk = eng.rank_counts(d).cpu().numpy()
+            xen, _ = eng._rows_in(d, 0)
+            hd = eng._hidden(d, xen[: d["n"]]).cpu().numpy()[:, :H]
+            tname = "E" if tied else "Eout"
+            info = [None] * R
+            dist.all_gather_object(info, (rk, hd, d["tgt"].cpu().numpy(), eng.get_param(tname)))
+            if rank == 0:
+                table = np.zeros((V, H), np.float32)
+                for j in range(R):
+                    table[j::R] = info[j][3]
+                for j in range(R):
+                    rkj, hj, tj, _ = info[j]
+                    sc = hj.astype(np.float64) @ table.T.astype(np.float64)
+                    ref = (sc > sc[np.arange(len(tj)), tj][:, None]).sum(1)
+                    assert (rkj == ref).mean() > 0.97 and np.abs(rkj - ref).max() <= 2, (case, j, np.abs(rkj - ref).max())
+                print("rank counts ok:", case["cell"], "tied" if tied else "untied")
         got = {"loss": losses, "W": eng.get_param("W"), "U": eng.get_param("U"), "b": eng.get_param("b"),
                "E": eng.get_param("E")}
         if not tied:
