@@ -345,9 +345,6 @@ class ShardedEngine(Engine):
         call("seqrec_gather_rows", ptr(Hd), ptr(ar), ptr(dEtgt), n, Hp, ptr(dlt), None, 0, st)
         dPre = self.buf("dPre", n, GHp)
         self._scan_bwd(d, dHd, Hout, gates, aux, dPre)
-        if c.use_bias:
-            cs_ws = self.buf("colsum_ws", 64 * GHp)
-            call("seqrec_colsum", ptr(dPre), n, GHp, GHp, ptr(Gd["b"]), 0, ptr(cs_ws), st)
         Hprev = self.buf("Hprev", n, Hp)
         call("seqrec_gather_rows", ptr(Hout), ptr(d["prev"]), ptr(Hprev), n, Hp, None, None, 0, st)
         if c.cell == "gru":
@@ -356,6 +353,8 @@ class ShardedEngine(Engine):
         else:
             wgrad = [(Hp, GHp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp)]
         wgrad.append((Dp, GHp, n, X, Dp, dPre, GHp, Gd["W"], GHp))
+        if c.use_bias:                       # db = ones^T . dPre in the same grouped launch (M = 1)
+            wgrad.append((1, GHp, n, self._ones(n), 1, dPre, GHp, Gd["b"], GHp))
         tiles = sum(((m + 63) // 64) * ((nn_ + 63) // 64) for (m, nn_, *_r) in wgrad)
         sk = int(max(1, min(32, -(-SPLITK_TARGET_WGS // max(tiles, 1)), n // 128)))
         wsp = self.buf("gemm_ws", sum(sk * m * nn_ for (m, nn_, *_r) in wgrad)) if sk > 1 else None

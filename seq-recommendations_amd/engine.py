@@ -230,6 +230,13 @@ class Engine:
             self.ws[name] = t
         return t[:n].view(*shape) if shape else t[:1]
 
+    def _ones(self, n):
+        t = self.ws.get("_ones")
+        if t is None or t.numel() < n:
+            t = torch.ones(max(n, 4096), dtype=torch.float32, device=self.dev)
+            self.ws["_ones"] = t
+        return t[:n]
+
     def gemm(self, a_kc, b_kc, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, accumulate=0, splitk=1, tag=None,
              ws_name="gemm_ws"):
         wsp = None
@@ -674,7 +681,8 @@ class Engine:
             call("seqrec_mul", ptr(dHd), ptr(drops["out"]), ptr(dHd), n * Hp, st)
         dPre = self.buf("dPre", n, GHp)
         self._scan_bwd(d, dHout, r["Hout"], r["gates"], r["aux"], dPre, drops.get("rec"))
-        if c.use_bias and tr["b"]:
+        bias_in_group = c.use_bias and tr["b"] and "rec" not in drops
+        if c.use_bias and tr["b"] and not bias_in_group:
             call("seqrec_colsum", ptr(dPre), n, GHp, GHp, ptr(Gd["b"]), 0, ptr(cs_ws), st)
         if tr["U"]:
             Hprev = self.buf("Hprev", n, Hp)
@@ -714,6 +722,12 @@ class Engine:
                     call("seqrec_mul", ptr(dX), ptr(drops["in"]), ptr(dX), n * self.Dp, st)
                 base_i = (n + c.K) if c.tied else 0
                 sparse_jobs.append(self._job("E", d["ids"], dX, self.Dp, None, n, self.Dp, base_i))
+        if bias_in_group:
+            if 0 < len(wgrad) < 4:
+                # db = ones^T . dPre rides in the same launch as the other token reductions (M = 1)
+                wgrad.append((1, GHp, n, self._ones(n), 1, dPre, GHp, Gd["b"], GHp))
+            else:
+                call("seqrec_colsum", ptr(dPre), n, GHp, GHp, ptr(Gd["b"]), 0, ptr(cs_ws), st)
         if wgrad:
             # the weight gradients A^T . dPre all reduce over the tokens: one grouped split-K launch
             tiles = sum(((m + 63) // 64) * ((nn_ + 63) // 64) for (m, nn_, *_rest) in wgrad)
