@@ -26,8 +26,11 @@ __device__ __forceinline__ rsrc_t mk_rsrc(const void* p) {
 __device__ __forceinline__ float bload(rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+#ifndef SEQREC_STORE_AUX
+#define SEQREC_STORE_AUX 0       // cache policy of the step kernels' output stores (tuning builds: 2 nt, 16 sc1, 17 sc0 sc1)
+#endif
 __device__ __forceinline__ void bstore(rsrc_t r, int voff, int soff, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, SEQREC_STORE_AUX);
 }
 
 struct StepArgs {
@@ -83,10 +86,14 @@ __device__ __forceinline__ bool tile_of(const StepArgs& a, int& r0, int& cb) {
 // output element (row = tid>>4, col = tid&15), whose epilogue inputs were requested at kernel entry.
 // Per launch the dependent chain is: loads (one L2 round trip) -> 16..32 MFMAs -> LDS reduce -> store.
 //
-// packed[((cb*4 + w)*(K/64) + i)*64 + lane] (float4): element e <-> kb = w*(K/16) + 4*i + e,
-//   value = B[4*kb + (lane>>4)][16*cb + (lane&15)]
+// packed[((cb*4 + w)*(K/64) + i)*64 + lane] (float4): element e <-> MFMA m = 4*i + e of wave w,
+//   value = B[k(w, m, lane>>4)][16*cb + (lane&15)]
+//   LDS-staged A (K > 512):        k = 4*(w*(K/16) + m) + q
+//   register A  (K <= 512, reg=1): k = w*(K/4) + q*(K/16) + m      -- lane (row, q) of wave w then owns K/16
+//                                   CONSECUTIVE k of its A row and loads them straight from global memory
 // mode 0: B[k][n] = U[k*ldu + coff + n]           (forward:  K = H)
 // mode 1: B[k][n] = U[n*ldu + coff + k]           (backward: transposed; K = H or 2H)
+constexpr bool reg_operand(int K) { return K <= 512; }
 struct PackStepJob { int coff, K, N, mode; long off; };
 struct PackStepArgs { const float* U; float* out; int ldu; PackStepJob job[4]; };
 __global__ void pack_step_kernel(PackStepArgs pa) {
@@ -103,8 +110,8 @@ __global__ void pack_step_kernel(PackStepArgs pa) {
         const int i = (int)(q % G4); q /= G4;
         const int w = (int)(q & 3); q >>= 2;
         const int cb = (int)q;
-        const int kb = w * (K / 16) + 4 * i + e;
-        const int k = 4 * kb + (l >> 4);
+        const int m = 4 * i + e;
+        const int k = reg_operand(K) ? w * (K / 4) + (l >> 4) * (K / 16) + m : 4 * (w * (K / 16) + m) + (l >> 4);
         const int n = 16 * cb + (l & 15);
         out[o] = mode == 0 ? U[(long)k * ldu + coff + n] : U[(long)n * ldu + coff + k];
     }
@@ -131,6 +138,56 @@ __device__ __forceinline__ float tile_16x16(const float* __restrict__ ab, float*
     __syncthreads();
     return (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
 }
+// ---- register-operand form (K <= 512): no LDS staging and no barrier in front of the MFMAs.
+// lane (row = lane & 15, q = lane >> 4) of wave w owns k in [w*K/4 + q*K/16, +K/16) of its A row.
+template <int K> __device__ __forceinline__ int a_koff(int lane, int w) { return w * (K / 4) + (lane >> 4) * (K / 16); }
+// (plain 16-byte global loads from a CLAMPED row pointer: rows beyond the block's last session read a
+//  valid row -- they only feed output rows that are never stored.  hipcc lowers the b128 raw-buffer
+//  builtin to a single dword load on this toolchain, so the branch-free buffer form is not available.)
+template <int N>      // N (multiple of 4) consecutive floats
+__device__ __forceinline__ void gload_vec(float (&a)[N], const float* __restrict__ p) {
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+        const float4 v = reinterpret_cast<const float4*>(p)[i];
+        a[4 * i + 0] = v.x; a[4 * i + 1] = v.y; a[4 * i + 2] = v.z; a[4 * i + 3] = v.w;
+    }
+}
+template <int N>
+__device__ __forceinline__ void gstore_vec(const float (&a)[N], float* __restrict__ p) {
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) reinterpret_cast<float4*>(p)[i] = make_float4(a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]);
+}
+template <int K>
+__device__ __forceinline__ float tile_16x16_reg(const float (&a)[K / 16], const float4 (&b)[K / 64], float* __restrict__ red,
+                                                int tid) {
+    const int lane = tid & 63, w = tid >> 6;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);      // every load of the kernel is in flight before the first MFMA waits
+#pragma unroll
+    for (int i = 0; i < K / 64; ++i) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * i + 0], b[i].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * i + 1], b[i].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * i + 2], b[i].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * i + 3], b[i].w, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[w * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc0[r] + acc1[r];
+    __syncthreads();
+    return (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+}
+// recurrent-dropout multipliers of gate g for the lane's A elements (sorted session row srow)
+template <int N>
+__device__ __forceinline__ void mask_vec(float (&a)[N], const float* __restrict__ rmask, int B, int H, int g, int srow, int koff,
+                                         bool ok) {
+    if (!ok) return;
+    const float4* m = reinterpret_cast<const float4*>(rmask + ((long)g * B + srow) * H + koff);
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+        const float4 v = m[i];
+        a[4 * i + 0] *= v.x; a[4 * i + 1] *= v.y; a[4 * i + 2] *= v.z; a[4 * i + 3] *= v.w;
+    }
+}
+
 __device__ __forceinline__ float4 mask4(const float* __restrict__ rmask, int B, int H, int g, int srow, int c4) {
     return reinterpret_cast<const float4*>(rmask + ((long)g * B + srow) * H)[c4];
 }
@@ -159,8 +216,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd(StepArgs a_in) {
     if (!tile_of(a, r0, cb)) return;
     // PHASE 0: [z|r] = hs(xw + h_prev.U_zr), r*h_prev        grid (rows/16, 2H/16)
     // PHASE 1: h~ = act(xw_h + (r*h_prev).U_h), h = z h_prev + (1-z) h~   grid (rows/16, H/16)
-    constexpr int H = 64 * J, LDA = H + 2, GH = 3 * H;
-    __shared__ float ab[16 * LDA];
+    constexpr int H = 64 * J, GH = 3 * H;
     __shared__ float red[4 * 256];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nact = min(16, a.bt - r0);
@@ -186,25 +242,12 @@ __global__ __launch_bounds__(256) void gru_step_fwd(StepArgs a_in) {
         const float4* pk = reinterpret_cast<const float4*>(a.pk) + (size_t)(cb * 4 + w) * (H / 64) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < H / 64; ++i) b[i] = pk[i * 64];
-        // A rows: PHASE 0 -> h_prev = Hout[prev step], PHASE 1 -> r*h_prev = aux[this step]
-        const float* src = PHASE == 0 ? a.Hout + (long)(a.pprev0 + r0) * H : a.aux + (long)(a.p0 + r0) * H;
-#pragma unroll
-        for (int it = 0; it < (16 * (H / 4)) / 256; ++it) {
-            const int idx = tid + 256 * it;
-            const int rr = idx / (H / 4), c4 = idx % (H / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rr < nact) {
-                v = reinterpret_cast<const float4*>(src + (long)rr * H)[c4];
-                if (a.rmask) {
-                    const float4 m = mask4(a.rmask, a.B, H, mg, r0 + rr, c4);
-                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
-                }
-            }
-            float* d = ab + rr * LDA + 4 * c4;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        }
-        __syncthreads();
-        acc = tile_16x16<H>(ab, red, b, tid);
+        // A rows straight into MFMA operand registers: PHASE 0 -> h_prev = Hout[prev step], PHASE 1 -> r*h_prev = aux[this step]
+        const int arow = min(lane & 15, nact - 1), koff = a_koff<H>(lane, w);
+        float av[H / 16];
+        gload_vec(av, (PHASE == 0 ? a.Hout + (long)(a.pprev0 + r0 + arow) * H : a.aux + (long)(a.p0 + r0 + arow) * H) + koff);
+        if (a.rmask) mask_vec(av, a.rmask, a.B, H, mg, r0 + arow, koff, true);
+        acc = tile_16x16_reg<H>(av, b, red, tid);
     }
     if (PHASE == 0) {
         const float g = hard_sigmoid(acc + xw);
@@ -229,7 +272,8 @@ __global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a_in) {
     // PHASE 1 (grid rows/16 x H/16, skipped at t = 0): dh_prev = tmpc + [dpre_z|dpre_r] . U_zr^T -> dHc[prev token]
     constexpr int H = 64 * J, GH = 3 * H;
     constexpr int K = PHASE == 0 ? H : 2 * H, LDA = K + 2;
-    __shared__ float ab[16 * LDA];
+    constexpr bool REG = reg_operand(K);
+    __shared__ float ab[REG ? 4 : 16 * LDA];
     __shared__ float red[4 * 256];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nact = min(16, a.bt - r0);
@@ -255,35 +299,59 @@ __global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a_in) {
 #pragma unroll
     for (int i = 0; i < K / 64; ++i) b[i] = pk[i * 64];
     const long pt = (long)a.p0 + r0;
+    float acc;
+    if constexpr (REG) {
+        // A operand in registers: PHASE 0 recomputes d = dh (1-z) act'(h~) for the lane's own k range
+        // (the workgroups of a row block do so redundantly; column block 0 also stores it), PHASE 1 reads dpre
+        const bool aok = (lane & 15) < nact;
+        const int arow = min(lane & 15, nact - 1), koff = a_koff<K>(lane, w);
+        const long q = pt + arow;
+        float av[K / 16];
+        if (PHASE == 0) {
+            float dh[K / 16], cc[K / 16], zz[K / 16], hh[K / 16];
+            gload_vec(dh, a.dHout + q * H + koff);
+            gload_vec(cc, a.dHc + q * H + koff);
+            gload_vec(zz, a.gates + q * GH + koff);
+            gload_vec(hh, a.gates + q * GH + 2 * H + koff);
+            const float carry = (r0 + arow < a.bnext) ? 1.f : 0.f;     // dHc rows of sessions that ended here are stale
 #pragma unroll
-    for (int it = 0; it < (16 * (K / 4)) / 256; ++it) {
-        const int idx = tid + 256 * it;
-        const int rr = idx / (K / 4), c4 = idx % (K / 4);
-        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rr < nact) {
-            const long q = pt + rr;
-            if (PHASE == 0) {
-                float4 dh = reinterpret_cast<const float4*>(a.dHout + q * H)[c4];
-                if (r0 + rr < a.bnext) {
-                    const float4 c = reinterpret_cast<const float4*>(a.dHc + q * H)[c4];
-                    dh.x += c.x; dh.y += c.y; dh.z += c.z; dh.w += c.w;
-                }
-                const float4 z = reinterpret_cast<const float4*>(a.gates + q * GH)[c4];
-                const float4 hh = reinterpret_cast<const float4*>(a.gates + q * GH + 2 * H)[c4];
-                d.x = dh.x * (1.f - z.x) * act_grad<ACT>(hh.x);
-                d.y = dh.y * (1.f - z.y) * act_grad<ACT>(hh.y);
-                d.z = dh.z * (1.f - z.z) * act_grad<ACT>(hh.z);
-                d.w = dh.w * (1.f - z.w) * act_grad<ACT>(hh.w);
-                if (cb == 0) reinterpret_cast<float4*>(a.dPre + q * GH + 2 * H)[c4] = d;
-            } else {
-                d = reinterpret_cast<const float4*>(a.dPre + q * GH)[c4];
-            }
+            for (int j = 0; j < K / 16; ++j) av[j] = (dh[j] + (carry != 0.f ? cc[j] : 0.f)) * (1.f - zz[j]) * act_grad<ACT>(hh[j]);
+            if (cb == 0 && aok) gstore_vec(av, a.dPre + q * GH + 2 * H + koff);
+        } else {
+            gload_vec(av, a.dPre + q * GH + koff);
         }
-        float* o = ab + rr * LDA + 4 * c4;
-        o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = d.w;
+        acc = tile_16x16_reg<K>(av, b, red, tid);
+    } else {
+#pragma unroll
+        for (int it = 0; it < (16 * (K / 4)) / 256; ++it) {
+            const int idx = tid + 256 * it;
+            const int rr = idx / (K / 4), c4 = idx % (K / 4);
+            float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rr < nact) {
+                const long q = pt + rr;
+                if (PHASE == 0) {
+                    float4 dh = reinterpret_cast<const float4*>(a.dHout + q * H)[c4];
+                    if (r0 + rr < a.bnext) {
+                        const float4 c = reinterpret_cast<const float4*>(a.dHc + q * H)[c4];
+                        dh.x += c.x; dh.y += c.y; dh.z += c.z; dh.w += c.w;
+                    }
+                    const float4 z = reinterpret_cast<const float4*>(a.gates + q * GH)[c4];
+                    const float4 hh = reinterpret_cast<const float4*>(a.gates + q * GH + 2 * H)[c4];
+                    d.x = dh.x * (1.f - z.x) * act_grad<ACT>(hh.x);
+                    d.y = dh.y * (1.f - z.y) * act_grad<ACT>(hh.y);
+                    d.z = dh.z * (1.f - z.z) * act_grad<ACT>(hh.z);
+                    d.w = dh.w * (1.f - z.w) * act_grad<ACT>(hh.w);
+                    if (cb == 0) reinterpret_cast<float4*>(a.dPre + q * GH + 2 * H)[c4] = d;
+                } else {
+                    d = reinterpret_cast<const float4*>(a.dPre + q * GH)[c4];
+                }
+            }
+            float* o = ab + rr * LDA + 4 * c4;
+            o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = d.w;
+        }
+        __syncthreads();
+        acc = tile_16x16<K>(ab, red, b, tid);
     }
-    __syncthreads();
-    float acc = tile_16x16<K>(ab, red, b, tid);
     const int srow = min(r0 + row, a.B - 1);
     if (PHASE == 0) {
         if (a.rmask) acc *= a.rmask[((long)2 * a.B + srow) * H + col];          // d(r*h*m2) -> d(r*h)
@@ -387,15 +455,14 @@ __global__ __launch_bounds__(256) void srnn_step_fwd(StepArgs a_in) {
     const StepArgs a = resolve(a_in);
     int r0, cb;
     if (!tile_of(a, r0, cb)) return;
-    constexpr int H = 64 * J, LDA = H + 2;
-    __shared__ float ab[16 * LDA];
+    constexpr int H = 64 * J;
     __shared__ float red[4 * 256];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nact = min(16, a.bt - r0);
     const int row = tid >> 4, col = 16 * cb + (tid & 15);
     const bool ok = row < nact;
     const rsrc_t rXW = mk_rsrc(a.XW), rH = mk_rsrc(a.Hout);
-    const int soH = (a.p0 + r0) * H * 4;
+    const int soH = (a.p0 + r0) * H * 4, soP = (a.pprev0 + r0) * H * 4;
     const int vh = ok ? (row * H + col) * 4 : INVALID_OFF;
     const float xw = bload(rXW, vh, soH);
     float acc = 0.f;
@@ -404,24 +471,11 @@ __global__ __launch_bounds__(256) void srnn_step_fwd(StepArgs a_in) {
         const float4* pk = reinterpret_cast<const float4*>(a.pk) + (size_t)(cb * 4 + w) * (H / 64) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < H / 64; ++i) b[i] = pk[i * 64];
-        const float* src = a.Hout + (long)(a.pprev0 + r0) * H;
-#pragma unroll
-        for (int it = 0; it < (16 * (H / 4)) / 256; ++it) {
-            const int idx = tid + 256 * it;
-            const int rr = idx / (H / 4), c4 = idx % (H / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rr < nact) {
-                v = reinterpret_cast<const float4*>(src + (long)rr * H)[c4];
-                if (a.rmask) {
-                    const float4 m = mask4(a.rmask, a.B, H, 0, r0 + rr, c4);
-                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
-                }
-            }
-            float* d = ab + rr * LDA + 4 * c4;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        }
-        __syncthreads();
-        acc = tile_16x16<H>(ab, red, b, tid);
+        const int arow = min(lane & 15, nact - 1), koff = a_koff<H>(lane, w);
+        float av[H / 16];
+        gload_vec(av, a.Hout + (long)(a.pprev0 + r0 + arow) * H + koff);
+        if (a.rmask) mask_vec(av, a.rmask, a.B, H, 0, r0 + arow, koff, true);
+        acc = tile_16x16_reg<H>(av, b, red, tid);
     }
     float y = act_fwd<ACT>(acc + xw);
     if (col >= a.H_real) y = 0.f;
@@ -467,7 +521,8 @@ __global__ __launch_bounds__(256) void gemm_bwd_step(StepArgs a_in, int H, int l
     int r0, cb;
     if (!tile_of(a, r0, cb)) return;
     constexpr int LDA = K + 2;
-    __shared__ float ab[16 * LDA];
+    constexpr bool REG = reg_operand(K);
+    __shared__ float ab[REG ? 4 : 16 * LDA];
     __shared__ float red[4 * 256];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nact = min(16, a.bt - r0);
@@ -478,17 +533,25 @@ __global__ __launch_bounds__(256) void gemm_bwd_step(StepArgs a_in, int H, int l
 #pragma unroll
     for (int i = 0; i < K / 64; ++i) b[i] = pk[i * 64];
     const long pt = (long)a.p0 + r0;
+    float acc;
+    if constexpr (REG) {
+        const int arow = min(lane & 15, nact - 1), koff = a_koff<K>(lane, w);
+        float av[K / 16];
+        gload_vec(av, a.dPre + (pt + arow) * ldp + koff);
+        acc = tile_16x16_reg<K>(av, b, red, tid);
+    } else {
 #pragma unroll
-    for (int it = 0; it < (16 * (K / 4)) / 256; ++it) {
-        const int idx = tid + 256 * it;
-        const int rr = idx / (K / 4), c4 = idx % (K / 4);
-        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rr < nact) d = reinterpret_cast<const float4*>(a.dPre + (pt + rr) * ldp)[c4];
-        float* o = ab + rr * LDA + 4 * c4;
-        o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = d.w;
+        for (int it = 0; it < (16 * (K / 4)) / 256; ++it) {
+            const int idx = tid + 256 * it;
+            const int rr = idx / (K / 4), c4 = idx % (K / 4);
+            float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rr < nact) d = reinterpret_cast<const float4*>(a.dPre + (pt + rr) * ldp)[c4];
+            float* o = ab + rr * LDA + 4 * c4;
+            o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = d.w;
+        }
+        __syncthreads();
+        acc = tile_16x16<K>(ab, red, b, tid);
     }
-    __syncthreads();
-    float acc = tile_16x16<K>(ab, red, b, tid);
     if (a.rmask) {
         const int srow = min(r0 + row, a.B - 1);
         if (K == H) {
@@ -686,6 +749,40 @@ extern "C" int seqrec_graph_cache_clear(void) {
     return 0;
 }
 
+namespace {
+// Launch-graph grids.  A captured graph must not depend on the batch, but sizing every launch for B
+// rows (1 536 workgroups at B = 512, almost all of which exit at once) costs more than the replay
+// saves.  With the XCD placement the grid only depends on j_t = ceil(row blocks / 8), which decays
+// with t; it is covered by a geometric ENVELOPE  env_t = max(1, jmax >> (t / S))  with the smallest
+// halving stride S from a fixed menu that dominates the batch's j_t, so batches of equal T share a
+// graph (MSNBC-shaped batches: S = 5; every session full length: S = inf).
+struct Envelope { int jmax, S; };
+Envelope pick_envelope(const int32_t* soh, int T, int B) {
+    int jmax = 1;
+    const int jb = ((B + 15) / 16 + 7) / 8;
+    while (jmax < jb) jmax <<= 1;
+    static const int menu[] = {3, 5, 8, 12, 1 << 30};
+    for (int S : menu) {
+        bool ok = true;
+        for (int t = 0; t < T && ok; ++t) {
+            const int bt = soh[t + 1] - soh[t];
+            const int j = ((bt + 15) / 16 + 7) / 8;
+            const int sh = t / S;
+            const int env = sh >= 30 ? 1 : (jmax >> sh > 1 ? jmax >> sh : 1);
+            ok = j <= env;
+        }
+        if (ok) return Envelope{jmax, S};
+    }
+    return Envelope{jmax, 1 << 30};
+}
+inline int env_rows(const Envelope& e, int t, int B) {
+    const int sh = t / e.S;
+    const int j = sh >= 30 ? 1 : (e.jmax >> sh > 1 ? e.jmax >> sh : 1);
+    const int rows = j * 8 * 16;
+    return rows < B ? rows : B;
+}
+}  // namespace
+
 extern "C" int seqrec_rnn_fwd_stepwise(int cell, int act, int H, int H_real, int T, int B,
                                        const int32_t* step_off, const int32_t* step_off_host, const float* XW,
                                        float* Hout, float* gates, float* aux, const float* upack,
@@ -699,13 +796,14 @@ extern "C" int seqrec_rnn_fwd_stepwise(int cell, int act, int H, int H_real, int
     const long HH = (long)H * H;
     const bool graph = use_graph != 0;
     const int32_t* soh = graph ? nullptr : step_off_host;       // a graph must not bake host-side sizes in
+    const Envelope env = (graph && step_off_host) ? pick_envelope(step_off_host, T, B) : Envelope{1 << 20, 1 << 30};
     auto enqueue = [&](hipStream_t st) -> int {
         StepArgs a = {};
         a.H = H; a.H_real = H_real; a.XW = XW; a.Hout = Hout; a.gates = gates; a.aux = aux;
         a.rmask = rmask; a.B = B; a.step_off = step_off; a.T = T;
         for (int t = 0; t < T; ++t) {
             a.t = t;
-            const int bt = soh ? soh[t + 1] - soh[t] : B;       // exact rows when known on the host, else the maximum
+            const int bt = soh ? soh[t + 1] - soh[t] : env_rows(env, t, B);   // exact rows (eager) or the envelope (graph)
             if (bt <= 0) break;
             if (soh) {
                 a.step_off = nullptr;
@@ -728,7 +826,8 @@ extern "C" int seqrec_rnn_fwd_stepwise(int cell, int act, int H, int H_real, int
         return 0;
     };
     const GraphKey key = {0ull, (unsigned long long)cell, (unsigned long long)act, (unsigned long long)H,
-                          (unsigned long long)H_real, (unsigned long long)T, (unsigned long long)B, pk_(step_off), pk_(XW),
+                          (unsigned long long)H_real, (unsigned long long)T, (unsigned long long)B,
+                          (unsigned long long)env.jmax, (unsigned long long)env.S, pk_(step_off), pk_(XW),
                           pk_(Hout), pk_(gates), pk_(aux), pk_(upack), pk_(rmask)};
     return run_maybe_graph(graph, key, st, enqueue);
 }
@@ -748,6 +847,7 @@ extern "C" int seqrec_rnn_bwd_stepwise(int cell, int act, int H, int H_real, int
     const long HH = (long)H * H;
     const bool graph = use_graph != 0;
     const int32_t* soh = graph ? nullptr : step_off_host;
+    const Envelope env = (graph && step_off_host) ? pick_envelope(step_off_host, T, B) : Envelope{1 << 20, 1 << 30};
     auto enqueue = [&](hipStream_t st) -> int {
         StepArgs a = {};
         a.H = H; a.H_real = H_real; a.Hout = const_cast<float*>(Hout); a.gates = const_cast<float*>(gates);
@@ -756,7 +856,7 @@ extern "C" int seqrec_rnn_bwd_stepwise(int cell, int act, int H, int H_real, int
         a.rmask = rmask; a.B = B; a.step_off = step_off; a.T = T;
         for (int t = T - 1; t >= 0; --t) {
             a.t = t;
-            const int bt = soh ? soh[t + 1] - soh[t] : B;
+            const int bt = soh ? soh[t + 1] - soh[t] : env_rows(env, t, B);
             if (bt <= 0) continue;
             if (soh) {
                 a.step_off = nullptr;
@@ -786,7 +886,8 @@ extern "C" int seqrec_rnn_bwd_stepwise(int cell, int act, int H, int H_real, int
         return 0;
     };
     const GraphKey key = {1ull, (unsigned long long)cell, (unsigned long long)act, (unsigned long long)H,
-                          (unsigned long long)H_real, (unsigned long long)T, (unsigned long long)B, pk_(step_off),
+                          (unsigned long long)H_real, (unsigned long long)T, (unsigned long long)B,
+                          (unsigned long long)env.jmax, (unsigned long long)env.S, pk_(step_off),
                           (unsigned long long)n_tok, pk_(dHout), pk_(Hout), pk_(gates), pk_(aux), pk_(dPre), pk_(upack),
                           pk_(workspace), pk_(rmask)};
     return run_maybe_graph(graph, key, st, enqueue);

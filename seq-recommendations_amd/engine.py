@@ -504,9 +504,12 @@ class Engine:
         Hp = self.Hp
         if self.stepwise:
             so = d["rb"].step_off
-            wsp = self.buf("scan_ws", 2 * d["n"] * Hp)
+            cap = d["n"]
+            if self.use_graph:           # a captured graph bakes the workspace split in: keep it batch-independent
+                cap = self._tok_cap = max(getattr(self, "_tok_cap", 0), (d["n"] + 4095) // 4096 * 4096)
+            wsp = self.buf("scan_ws", 2 * cap * Hp)
             sod = self._sod_cur          # the table the forward scan of this step installed
-            call("seqrec_rnn_bwd_stepwise", CELL[c.cell], ACT[c.act], Hp, c.H, d["T"], d["B"], ptr(sod), so.ctypes.data, d["n"],
+            call("seqrec_rnn_bwd_stepwise", CELL[c.cell], ACT[c.act], Hp, c.H, d["T"], d["B"], ptr(sod), so.ctypes.data, cap,
                  ptr(dHout), ptr(Hout), ptr(gates), ptr(aux), ptr(dPre), ptr(self.upack), ptr(wsp), ptr(rmask),
                  int(self.use_graph), st)
         else:
