@@ -724,14 +724,14 @@ template <typename F> int run_maybe_graph(bool use_graph, const GraphKey& key, h
         if (e != hipSuccess) return (int)e;
         const int rc = enqueue(g_capture_stream);
         e = hipStreamEndCapture(g_capture_stream, &graph);
-        if (rc) { if (e == hipSuccess) hipGraphDestroy(graph); return rc; }
+        if (rc) { if (e == hipSuccess) (void)hipGraphDestroy(graph); return rc; }
         if (e != hipSuccess) return (int)e;
         hipGraphExec_t exec;
         e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        hipGraphDestroy(graph);
+        (void)hipGraphDestroy(graph);
         if (e != hipSuccess) return (int)e;
         if (g_graphs.size() >= 256) {                      // bounded: drop everything, rebuild on demand
-            for (auto& kv : g_graphs) hipGraphExecDestroy(kv.second);
+            for (auto& kv : g_graphs) (void)hipGraphExecDestroy(kv.second);
             g_graphs.clear();
         }
         it = g_graphs.emplace(key, exec).first;
@@ -744,7 +744,7 @@ unsigned long long pk_(const void* p) { return (unsigned long long)reinterpret_c
 
 extern "C" int seqrec_graph_cache_clear(void) {
     std::lock_guard<std::mutex> lk(g_graph_mu);
-    for (auto& kv : g_graphs) hipGraphExecDestroy(kv.second);
+    for (auto& kv : g_graphs) (void)hipGraphExecDestroy(kv.second);
     g_graphs.clear();
     return 0;
 }

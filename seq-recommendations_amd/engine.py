@@ -207,11 +207,6 @@ class Engine:
         self.use_graph = self.stepwise and os.environ.get("SEQREC_SCAN_GRAPH", "0") != "0"   # hipGraph replay of the scan launches (measured: no gain, GPU-bound)
         self._so_fixed = None
         self._so_token = object()
-        self.use_side = os.environ.get("SEQREC_SIDE_STREAM", "0") != "0"   # measured: overlap slows the scan more than it hides
-        self.side = torch.cuda.Stream(device=self.dev, priority=0)
-        self.main_hi = torch.cuda.Stream(device=self.dev, priority=-1) if os.environ.get("SEQREC_MAIN_HI", "0") != "0" else None     # independent work beside the scan (dEneg GEMM)
-        self.ev_fork = torch.cuda.Event()
-        self.ev_join = torch.cuda.Event()
         self.sampler = None       # (thresh uint32-as-int32 tensor, alias int32 tensor, logq float tensor)
         self.step_count = 0
 
@@ -600,16 +595,6 @@ class Engine:
 
     # ------------------------------------------------------------------ training step
     def train_step(self, d, lr=0.01, eps=1e-8, clipnorm=1.0, step=None, negatives=None, apply_update=True):
-        if self.main_hi is None:
-            return self._train_step(d, lr, eps, clipnorm, step, negatives, apply_update)
-        cur = torch.cuda.current_stream(self.dev)
-        self.main_hi.wait_stream(cur)
-        with torch.cuda.stream(self.main_hi):
-            out = self._train_step(d, lr, eps, clipnorm, step, negatives, apply_update)
-        cur.wait_stream(self.main_hi)
-        return out
-
-    def _train_step(self, d, lr=0.01, eps=1e-8, clipnorm=1.0, step=None, negatives=None, apply_update=True):
         """One full step on an uploaded batch: forward, masked-mean CE, BPTT, global-norm clip,
         Adagrad.  Returns the batch loss as a 1-element device tensor (no host sync)."""
         c, P = self.cfg, self.P
@@ -628,7 +613,6 @@ class Engine:
         tr = self.trainable
         sparse_jobs = []     # scatter lists of this step (see _job)
         wgrad = []           # deferred weight-gradient GEMMs (M, N, K, A, lda, B, ldb, C, ldc), launched grouped
-        forked = False
         dHd = self.buf("dHd", n, Hp)
         cs_ws = self.buf("colsum_ws", 64 * max(GHp, self.Vp, c.K if c.output == "sampled" else 1))
         if c.output == "full":
@@ -659,19 +643,8 @@ class Engine:
             self.gemm(1, 0, n, Hp, K, dln, K, Eneg, Hp, dHd, Hp, splitk=self._splitk(n, Hp, K), tag="dH")
             call("seqrec_gather_rows", ptr(Et), ptr(d["tgt"]), ptr(dHd), n, Hp, ptr(dlt), None, 1, st)
             if tr[tname]:
-                # the output-table gradient does not feed the BPTT chain: run it beside the scan
                 dEneg = self.buf("dEneg", K, Hp)
-                if self.use_side:
-                    main = torch.cuda.current_stream(self.dev)
-                    self.ev_fork.record(main)
-                    self.side.wait_event(self.ev_fork)
-                    with torch.cuda.stream(self.side):
-                        self.gemm(0, 0, K, Hp, n, dln, K, Hd, Hp, dEneg, Hp, splitk=self._splitk(K, Hp, n), tag="dEneg",
-                                  ws_name="gemm_ws_side")
-                        self.ev_join.record(self.side)
-                    forked = True
-                else:
-                    self.gemm(0, 0, K, Hp, n, dln, K, Hd, Hp, dEneg, Hp, splitk=self._splitk(K, Hp, n), tag="dEneg")
+                self.gemm(0, 0, K, Hp, n, dln, K, Hd, Hp, dEneg, Hp, splitk=self._splitk(K, Hp, n), tag="dEneg")
                 sparse_jobs.append(self._job(tname, d["tgt"], Hd, Hp, dlt, n, Hp, 0))
                 sparse_jobs.append(self._job(tname, neg, dEneg, Hp, None, K, Hp, n))
             if c.out_bias and tr["bout"]:
@@ -738,8 +711,6 @@ class Engine:
             wsz = sum(sk * m * nn_ for (m, nn_, *_rest) in wgrad)
             wsp = self.buf("gemm_ws", wsz) if sk > 1 else None
             call("seqrec_gemm_f32_grouped", len(wgrad), 0, 0, _lib.gemm_descs(wgrad), sk, ptr(wsp), st, tag="dW+dU")
-        if forked:
-            torch.cuda.current_stream(self.dev).wait_event(self.ev_join)
         # ---- row-sparse contributions: one launch for (up to 4) scatter lists
         groups = [sparse_jobs[i:i + 4] for i in range(0, len(sparse_jobs), 4)]
         packed = [_lib.rows_jobs(g) for g in groups]

@@ -1,4 +1,4 @@
-"""N > 1 routing logic (row-sharded tables over all-to-all) on CPU with gloo, world size 2 and 3."""
+"""N > 1 routing logic (row-sharded tables over all-to-all) on CPU with gloo, world size 2, 3 and 8."""
 import os
 import subprocess
 import sys
@@ -8,7 +8,7 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_row_exchange_gloo(world):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     port = 29600 + world

@@ -209,17 +209,19 @@ def test_sharded_engine_single_rank_equals_oracle():
             dist.destroy_process_group()
 
 
-def test_sharded_engine_two_ranks_one_gpu_vs_global_oracle():
-    """Two processes share cuda:0 (collectives staged through gloo) and train the row-sharded model
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_engine_ranks_share_one_gpu_vs_global_oracle(world):
+    """2 / 4 processes share cuda:0 (collectives staged through gloo) and train the row-sharded model
     for two steps; rank 0 checks global loss, replicated weights and every table shard against the
-    oracle run on the global model with the same stratified negatives (tests/dist_gpu_worker.py)."""
+    oracle run on the global model with the same stratified negatives, plus the sharded eval loss
+    and Recall@K rank counting (tests/dist_gpu_worker.py)."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29641", os.path.join(here, "dist_gpu_worker.py")]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(29640 + world), os.path.join(here, "dist_gpu_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
-    assert r.stdout.count("case ok") == 3 and r.stdout.count("rank") >= 2
+    assert r.stdout.count("case ok") == 3 and r.stdout.count("rank counts ok") == 2 and r.stdout.count(" ok\n") >= world
