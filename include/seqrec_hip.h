@@ -140,10 +140,13 @@ int seqrec_full_softmax_ce(float* logits, int64_t ld, const int32_t* tgt, int64_
 /*      sampled softmax over {target} U K shared negatives (extension).
  *      ln [n,K] = Hd . Eout[neg]^T is overwritten by dln.  The target logit is computed here from
  *      hd[n,H] and Eout[tgt] (row gather); bout (nullable, [V]) is added and logq (nullable, [V])
- *      subtracted for every candidate; accidental hits (neg == tgt) are removed.  dlt [n] out. */
+ *      subtracted for every candidate; accidental hits (neg == tgt) are removed.  dlt [n] out.
+ *      cand_logq (nullable, [K]) = logq[neg[k]] gathered ONCE per step by the caller: the negatives are
+ *      shared by all rows, so the kernel then reads one coalesced vector instead of doing K dependent
+ *      item-table lookups per row (the target term still uses logq[tgt]). */
 int seqrec_sampled_softmax_ce(float* ln, int64_t ld, const float* hd, int H, const float* Eout,
-                              const float* bout, const float* logq, const int32_t* tgt,
-                              const int32_t* neg, int64_t n, int K, float inv_denom,
+                              const float* bout, const float* logq, const float* cand_logq,
+                              const int32_t* tgt, const int32_t* neg, int64_t n, int K, float inv_denom,
                               float* loss_rows, float* dlt, void* stream);
 /*      same, for row-sharded tables (multi-GPU): Etgt [n,H] holds the target rows already fetched
  *      from their owners (row i for token i), lq_tgt [n] / lq_neg [K] the candidates' log-Q values

@@ -48,7 +48,7 @@ _SIGS = {
     "seqrec_rnn_bwd_stepwise": [I, I, I, I, I, I, P, P, L, P, P, P, P, P, P, P, P, I, P],
     "seqrec_graph_cache_clear": [],
     "seqrec_full_softmax_ce": [P, L, P, L, I, F, P, P, P],
-    "seqrec_sampled_softmax_ce": [P, L, P, I, P, P, P, P, P, L, I, F, P, P, P],
+    "seqrec_sampled_softmax_ce": [P, L, P, I, P, P, P, P, P, P, L, I, F, P, P, P],
     "seqrec_sampled_softmax_ce_rows": [P, L, P, I, P, P, P, P, P, L, I, F, P, P, P],
     "seqrec_reduce_sum": [P, L, P, I, P],
     "seqrec_colsum": [P, L, I, L, P, I, P, P],

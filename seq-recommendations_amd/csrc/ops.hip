@@ -114,7 +114,8 @@ __global__ void sampled_softmax_ce_kernel(float* __restrict__ ln, long ld, const
             if (lq_n) l -= lq_n[k];
         } else {
             if (bout) l += bout[v];
-            if (logq) l -= logq[v];
+            if (lq_n) l -= lq_n[k];
+            else if (logq) l -= logq[v];
         }
         if (v == t) l = -INFINITY;
         x[k] = l;
@@ -461,7 +462,8 @@ __global__ void sampled_softmax_ce_reg_kernel(float* __restrict__ ln, long ld, c
                     if (lq_n) l -= lq_n[k];
                 } else {
                     if (bout) l += bout[id];
-                    if (logq) l -= logq[id];
+                    if (lq_n) l -= lq_n[k];              // per-candidate log-Q gathered once per step by the caller
+                    else if (logq) l -= logq[id];
                 }
                 if (id == t) l = -INFINITY;
             }
@@ -530,13 +532,13 @@ int launch_sampled(float* ln, long ld, const float* hd, int H, const float* Eout
 }  // namespace
 
 extern "C" int seqrec_sampled_softmax_ce(float* ln, int64_t ld, const float* hd, int H, const float* Eout,
-                                         const float* bout, const float* logq, const int32_t* tgt,
-                                         const int32_t* neg, int64_t n, int K, float inv_denom,
+                                         const float* bout, const float* logq, const float* cand_logq,
+                                         const int32_t* tgt, const int32_t* neg, int64_t n, int K, float inv_denom,
                                          float* loss_rows, float* dlt, void* stream) {
     if (n < 0 || K < 0 || H <= 0 || ld < K) return SEQREC_E_ARG;
     if (n == 0) return 0;
     if (!ln || !hd || !Eout || !tgt || (K > 0 && !neg) || !loss_rows || !dlt) return SEQREC_E_ARG;
-    return launch_sampled<false>(ln, (long)ld, hd, H, Eout, bout, logq, nullptr, tgt, neg, (long)n, K, inv_denom, loss_rows,
+    return launch_sampled<false>(ln, (long)ld, hd, H, Eout, bout, logq, cand_logq, tgt, neg, (long)n, K, inv_denom, loss_rows,
                                  dlt, as_stream(stream));
 }
 

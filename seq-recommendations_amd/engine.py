@@ -586,8 +586,12 @@ class Engine:
             ln = self.buf("ln", n, K)
             self.gemm(1, 1, n, K, Hp, Hd, Hp, Eneg, Hp, ln, K, tag="logits")
             dlt = self.buf("dlt", n)
+            lq_neg = None
+            if c.logq:                       # the candidates' log-Q once per step, not once per row
+                lq_neg = self.buf("lq_neg", K)
+                call("seqrec_gather_rows", ptr(lq), ptr(neg), ptr(lq_neg), K, 1, None, None, 0, st)
             call("seqrec_sampled_softmax_ce", ptr(ln), K, ptr(Hd), Hp, ptr(Et), ptr(P.get("bout")),
-                 ptr(lq if c.logq else None), ptr(tgt), ptr(neg), n, K, inv, ptr(loss_rows), ptr(dlt), st)
+                 ptr(lq if c.logq else None), ptr(lq_neg), ptr(tgt), ptr(neg), n, K, inv, ptr(loss_rows), ptr(dlt), st)
             r.update(neg=neg, Eneg=Eneg, dln=ln, dlt=dlt)
         if tgt is not None:
             call("seqrec_reduce_sum", ptr(loss_rows), n, ptr(self.loss_sum), 0, st)

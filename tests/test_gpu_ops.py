@@ -247,12 +247,15 @@ def test_sampled_softmax_ce_vs_oracle(n, K, H, V, bias, lq):
     lnraw = h @ E[neg].T
     lnd = dev(lnraw.astype(np.float32))
     lr = torch.empty(n, device="cuda"); dltd = torch.empty(n, device="cuda")
-    call("seqrec_sampled_softmax_ce", ptr(lnd), K, ptr(dev(h)), H, ptr(dev(E)), ptr(dev(bout)) if bias else None,
-         ptr(dev(logq)) if lq else None, ptr(dev(tgt)), ptr(dev(neg)), n, K, 1.0 / n, ptr(lr), ptr(dltd), st())
-    assert abs(lr.cpu().numpy().astype(np.float64).sum() - ce) <= 3e-5 * max(1.0, abs(ce))
-    np.testing.assert_allclose(dltd.cpu().numpy(), dlt, atol=2e-6)
-    np.testing.assert_allclose(lnd.cpu().numpy(), dln, atol=2e-6)
-    assert np.all(lnd.cpu().numpy()[0, :3] == 0)
+    for pre_gathered in (False, True):       # per-candidate log-Q vector gathered by the caller: identical results
+        lnd = dev(lnraw.astype(np.float32))
+        cand = dev(logq[neg]) if (lq and pre_gathered) else None
+        call("seqrec_sampled_softmax_ce", ptr(lnd), K, ptr(dev(h)), H, ptr(dev(E)), ptr(dev(bout)) if bias else None,
+             ptr(dev(logq)) if lq else None, ptr(cand), ptr(dev(tgt)), ptr(dev(neg)), n, K, 1.0 / n, ptr(lr), ptr(dltd), st())
+        assert abs(lr.cpu().numpy().astype(np.float64).sum() - ce) <= 3e-5 * max(1.0, abs(ce))
+        np.testing.assert_allclose(dltd.cpu().numpy(), dlt, atol=2e-6)
+        np.testing.assert_allclose(lnd.cpu().numpy(), dln, atol=2e-6)
+        assert np.all(lnd.cpu().numpy()[0, :3] == 0)
 
 
 def test_colsum_reduce_mul_fill():
