@@ -65,6 +65,9 @@ __device__ __forceinline__ StepArgs resolve(StepArgs a) {
 // fetched by up to 8 L2s from the Infinity Cache), and every XCD keeps the packed U resident.
 // Grid = 8 * cbn * ceil(rb / 8); workgroups of XCDs without a row block exit at once.
 __device__ __forceinline__ bool tile_of(const StepArgs& a, int& r0, int& cb) {
+#ifdef SEQREC_SCAN_EMPTY        // timing-only build (tools/bench_scan.py): every workgroup exits at once, which
+    return false;               // leaves the launch chain itself -- same launches, same grids -- to be timed
+#endif
     const int L = blockIdx.x;
     int rbk;
     if (a.xcd) {

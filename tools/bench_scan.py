@@ -1,5 +1,11 @@
 #!/usr/bin/env python3
-"""Time the scan kernels alone on c3-shaped batches (developer tool, GPU box only)."""
+"""Time the scan kernels alone on c3-shaped batches (developer tool, GPU box only).
+
+Launch-chain floor: build a second library with empty step kernels and point SEQREC_LIB at it --
+    cd seq-recommendations_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics \
+        -I../../include -DSEQREC_SCAN_EMPTY gemm.hip ops.hip rnn.hip rnn_step.hip -o ../../tools/bin/libseqrec_scan_empty.so
+    SEQREC_LIB=$PWD/tools/bin/libseqrec_scan_empty.so python tools/bench_scan.py gru 256
+(the step-wise columns then show the cost of the dependent launches alone, eager and as a replayed graph)."""
 import importlib, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
