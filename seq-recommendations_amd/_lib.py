@@ -164,9 +164,16 @@ def ptr(t):
     """Device pointer of a torch tensor (or None)."""
     if t is None:
         return None
-    return C.c_void_p(t.data_ptr())
+    return t.data_ptr()             # a plain int: ctypes converts it for the c_void_p parameters
+
+
+_FN = {}
 
 
 def call(name, *args):
-    fn = getattr(load(), name)
-    check(fn(*args), name)
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(load(), name)
+    rc = fn(*args)
+    if rc != 0:
+        check(rc, name)
