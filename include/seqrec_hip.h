@@ -217,6 +217,19 @@ int seqrec_sqnorm_multi(int count, const float* const* g, const int64_t* n, floa
 int seqrec_adagrad_dense_multi(int count, float* const* p, float* const* a, const float* const* g,
                                const int64_t* n, float lr, float eps, const float* scale, void* stream);
 
+/* ---- fused optimizer step (clipnorm + Adagrad, experiments_methods.py:41) over up to 8 dense tensors and up
+ *      to 4 scatter lists: ONE launch for the squared gradient norm of everything, ONE for the Keras clip
+ *      scale + dense Adagrad + row-sparse Adagrad (same arithmetic as seqrec_sqnorm_multi /
+ *      seqrec_rows_sqnorm_multi / seqrec_clip_scale / seqrec_adagrad_dense_multi / seqrec_rows_adagrad_multi).
+ *      opt_sqnorm ADDS into *sq_accum (zero it first); opt_apply writes the scale to *scale_out and, if
+ *      zero_next != NULL, stores 0 to *zero_next -- callers alternate two norm slots so that no step needs
+ *      a separate clearing launch. */
+int seqrec_opt_sqnorm(int n_dense, const float* const* grads, const int64_t* numel,
+                      const seqrec_rows_job* jobs_host, int n_jobs, float* sq_accum, void* stream);
+int seqrec_opt_apply(int n_dense, float* const* params, float* const* accums, const float* const* grads,
+                     const int64_t* numel, const seqrec_rows_job* jobs_host, int n_jobs, const float* sq,
+                     float clipnorm, float lr, float eps, float* scale_out, float* zero_next, void* stream);
+
 /* ---- counter RNG (specification: oracle/rng.py).  Alias-method draw of K negatives for
  *      training step `step`; inverted-dropout multipliers out[r*ld + j] (j < width) drawn with
  *      counter rowkey[r]*width + j (rowkey nullable -> r): 0 or 1/(1-rate). */

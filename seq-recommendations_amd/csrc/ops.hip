@@ -4,6 +4,7 @@
 // one wave per table row so that a 256-float row is exactly one 1-KiB coalesced wave access.
 #include "common.h"
 #include <limits.h>
+#include <algorithm>
 
 namespace {
 
@@ -349,6 +350,82 @@ __global__ void rows_adagrad_multi_kernel(RowsMulti m, float lr, float eps, cons
     const int r = J.rows[i];
     if (r < 0 || J.slot[r] != J.base + (int)i) return;
     const float sc = scale[0];
+    const long o = (long)r * J.width;
+    for (int c = lane; c < J.width; c += 64) {
+        const float g = J.gtab[o + c] * sc;
+        const float a = J.accum[o + c] + g * g;
+        J.accum[o + c] = a;
+        J.table[o + c] -= lr * g / (sqrtf(a) + eps);
+        J.gtab[o + c] = 0.f;
+    }
+    if (lane == 0) J.slot[r] = INT_MAX;
+}
+
+// fused optimizer launches: the norm of EVERYTHING (dense tensors + owned rows) in one launch, then clip
+// scale + dense Adagrad + row-sparse Adagrad in one launch (the step otherwise spends six ~5 us
+// launches here).  blockIdx.y < nd: dense tensor, else scatter list blockIdx.y - nd.
+struct OptPlan { DenseMulti d; RowsMulti r; int nd, nr; };
+__global__ void opt_sqnorm_kernel(OptPlan pl, float* __restrict__ sq) {
+    __shared__ float part[4];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float s = 0.f;
+    if ((int)blockIdx.y < pl.nd) {
+        const float* g = pl.d.g[blockIdx.y];
+        const long n = pl.d.n[blockIdx.y];
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += g[i] * g[i];
+    } else {
+        constexpr int RPW = 4;
+        const seqrec_rows_job& J = pl.r.j[blockIdx.y - pl.nd];
+        const long i0 = ((long)blockIdx.x * (blockDim.x >> 6) + wv) * RPW;
+        int r[RPW];
+        bool own[RPW];
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) r[k] = (i0 + k < J.n) ? J.rows[i0 + k] : -1;
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) own[k] = r[k] >= 0 && J.slot[r[k]] == J.base + (int)(i0 + k);
+        for (int c = lane; c < J.width; c += 64) {
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) {
+                const float g = own[k] ? J.gtab[(long)r[k] * J.width + c] : 0.f;
+                s += g * g;
+            }
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) part[wv] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = part[0] + part[1] + part[2] + part[3];
+        if (t != 0.f) atomicAdd(sq, t);
+    }
+}
+__global__ void opt_apply_kernel(OptPlan pl, const float* __restrict__ sq, float clipnorm, float lr, float eps,
+                                 float* __restrict__ scale_out, float* __restrict__ zero_next) {
+    const float nrm = sqrtf(sq[0]);
+    const float sc = (clipnorm > 0.f && nrm >= clipnorm) ? clipnorm / nrm : 1.f;   // Keras clip_norm (== clip_scale_kernel)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        scale_out[0] = sc;
+        if (zero_next) zero_next[0] = 0.f;            // the OTHER norm slot: nobody reads or adds to it during this step
+    }
+    if ((int)blockIdx.y < pl.nd) {
+        float* p = pl.d.p[blockIdx.y];
+        float* a = pl.d.a[blockIdx.y];
+        const float* g = pl.d.g[blockIdx.y];
+        const long n = pl.d.n[blockIdx.y];
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+            const float gv = g[i] * sc;
+            const float av = a[i] + gv * gv;
+            a[i] = av;
+            p[i] -= lr * gv / (sqrtf(av) + eps);
+        }
+        return;
+    }
+    const seqrec_rows_job& J = pl.r.j[blockIdx.y - pl.nd];
+    const int lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= J.n) return;
+    const int r = J.rows[i];
+    if (r < 0 || J.slot[r] != J.base + (int)i) return;
     const long o = (long)r * J.width;
     for (int c = lane; c < J.width; c += 64) {
         const float g = J.gtab[o + c] * sc;
@@ -857,6 +934,57 @@ extern "C" int seqrec_rows_adagrad_multi(const seqrec_rows_job* jobs, int count,
     if (!scale) return SEQREC_E_ARG;
     for (int i = 0; i < count; ++i) if (jobs[i].n > 0 && (!jobs[i].table || !jobs[i].accum)) return SEQREC_E_ARG;
     hipLaunchKernelGGL(rows_adagrad_multi_kernel, dim3((unsigned)((maxn + 3) / 4), count), dim3(256), 0, as_stream(stream), m, lr, eps, scale);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+
+namespace {
+int fill_opt_plan(int n_dense, float* const* params, float* const* accums, const float* const* grads, const int64_t* numel,
+                  const seqrec_rows_job* jobs, int n_jobs, bool need_state, OptPlan& pl, long& maxn) {
+    if (n_dense < 0 || n_dense > 8 || n_jobs < 0 || n_jobs > 4 || n_dense + n_jobs == 0) return SEQREC_E_ARG;
+    if (n_dense && (!grads || !numel || (need_state && (!params || !accums)))) return SEQREC_E_ARG;
+    pl = OptPlan{};
+    pl.nd = n_dense; pl.nr = n_jobs;
+    for (int i = 0; i < n_dense; ++i) {
+        if (numel[i] < 0 || (numel[i] > 0 && (!grads[i] || (need_state && (!params[i] || !accums[i]))))) return SEQREC_E_ARG;
+        pl.d.g[i] = grads[i]; pl.d.n[i] = (long)numel[i];
+        pl.d.p[i] = need_state ? params[i] : nullptr; pl.d.a[i] = need_state ? accums[i] : nullptr;
+    }
+    maxn = 0;
+    if (n_jobs) {
+        if (!jobs) return SEQREC_E_ARG;
+        RowsMulti m = {};
+        const int rc = fill_rows_multi(jobs, n_jobs, m, maxn);
+        if (rc) return rc;
+        pl.r = m;
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" int seqrec_opt_sqnorm(int n_dense, const float* const* grads, const int64_t* numel,
+                                 const seqrec_rows_job* jobs_host, int n_jobs, float* sq_accum, void* stream) {
+    OptPlan pl;
+    long maxn;
+    const int rc = fill_opt_plan(n_dense, nullptr, nullptr, grads, numel, jobs_host, n_jobs, false, pl, maxn);
+    if (rc) return rc;
+    if (!sq_accum) return SEQREC_E_ARG;
+    const unsigned gx = (unsigned)std::max<long>(32, (maxn + 15) / 16);
+    hipLaunchKernelGGL(opt_sqnorm_kernel, dim3(gx, n_dense + n_jobs), dim3(256), 0, as_stream(stream), pl, sq_accum);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int seqrec_opt_apply(int n_dense, float* const* params, float* const* accums, const float* const* grads,
+                                const int64_t* numel, const seqrec_rows_job* jobs_host, int n_jobs, const float* sq,
+                                float clipnorm, float lr, float eps, float* scale_out, float* zero_next, void* stream) {
+    OptPlan pl;
+    long maxn;
+    const int rc = fill_opt_plan(n_dense, params, accums, grads, numel, jobs_host, n_jobs, true, pl, maxn);
+    if (rc) return rc;
+    if (!sq || !scale_out) return SEQREC_E_ARG;
+    const unsigned gx = (unsigned)std::max<long>(n_dense ? 256 : 1, (maxn + 3) / 4);
+    hipLaunchKernelGGL(opt_apply_kernel, dim3(gx, n_dense + n_jobs), dim3(256), 0, as_stream(stream), pl, sq, clipnorm, lr, eps,
+                       scale_out, zero_next);
     SEQREC_LAUNCH_CHECK();
     return 0;
 }

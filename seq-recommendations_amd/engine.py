@@ -197,7 +197,11 @@ class Engine:
         self.ws = {}
         self._views = {}
         self._cur_st = None
-        self.sq = z(1)
+        self.sq1 = z(1)                 # squared gradient norm (multi-launch path)
+        self.sq2 = z(2)                 # two alternating slots of the fused optimizer launches
+        self._sq_slots = (self.sq2[0:1], self.sq2[1:2])
+        self._sq_par = 0
+        self.sq = self.sq1
         self.scale = torch.ones(1, **f32)
         self.loss_sum = z(1)
         self.upack = torch.empty(int(_lib.load().seqrec_rnn_upack_floats(CELL[c.cell], self.Hp)), **f32)
@@ -741,20 +745,36 @@ class Engine:
         if not apply_update:
             return sparse_jobs
         # ---- global-norm clip over every trainable tensor (Keras clipnorm), then Adagrad
-        self.sq.zero_()
         dk = [k for k in Gd if tr[k]]
-        if dk:
-            gp = _lib.ptr_array([Gd[k] for k in dk])
-            nn = _lib.i64_array([Gd[k].numel() for k in dk])
-            call("seqrec_sqnorm_multi", len(dk), gp, nn, ptr(self.sq), st)
-        for arr, cnt in packed:
-            call("seqrec_rows_sqnorm_multi", arr, cnt, ptr(self.sq), st)
-        call("seqrec_clip_scale", ptr(self.sq), float(clipnorm if clipnorm else 0.0), ptr(self.scale), st)
-        if dk:
-            call("seqrec_adagrad_dense_multi", len(dk), _lib.ptr_array([P[k] for k in dk]),
-                 _lib.ptr_array([self.A[k] for k in dk]), gp, nn, lr, eps, ptr(self.scale), st)
-        for arr, cnt in packed:
-            call("seqrec_rows_adagrad_multi", arr, cnt, lr, eps, ptr(self.scale), st)
+        clip = float(clipnorm if clipnorm else 0.0)
+        if len(packed) <= 1 and len(dk) <= 8 and (dk or packed):
+            # two launches: norm of everything, then scale + dense + row-sparse update; the two norm slots
+            # alternate so that the slot of the NEXT step is cleared by this step's update launch
+            gp = _lib.ptr_array([Gd[k] for k in dk]) if dk else None
+            nn = _lib.i64_array([Gd[k].numel() for k in dk]) if dk else None
+            arr, cnt = packed[0] if packed else (None, 0)
+            cur, nxt = self._sq_slots[self._sq_par], self._sq_slots[1 - self._sq_par]
+            call("seqrec_opt_sqnorm", len(dk), gp, nn, arr, cnt, ptr(cur), st)
+            call("seqrec_opt_apply", len(dk), _lib.ptr_array([P[k] for k in dk]) if dk else None,
+                 _lib.ptr_array([self.A[k] for k in dk]) if dk else None, gp, nn, arr, cnt, ptr(cur), clip, lr, eps,
+                 ptr(self.scale), ptr(nxt), st)
+            self._sq_par ^= 1
+            self.sq = cur
+        else:
+            self.sq = self.sq1
+            self.sq.zero_()
+            if dk:
+                gp = _lib.ptr_array([Gd[k] for k in dk])
+                nn = _lib.i64_array([Gd[k].numel() for k in dk])
+                call("seqrec_sqnorm_multi", len(dk), gp, nn, ptr(self.sq), st)
+            for arr, cnt in packed:
+                call("seqrec_rows_sqnorm_multi", arr, cnt, ptr(self.sq), st)
+            call("seqrec_clip_scale", ptr(self.sq), clip, ptr(self.scale), st)
+            if dk:
+                call("seqrec_adagrad_dense_multi", len(dk), _lib.ptr_array([P[k] for k in dk]),
+                     _lib.ptr_array([self.A[k] for k in dk]), gp, nn, lr, eps, ptr(self.scale), st)
+            for arr, cnt in packed:
+                call("seqrec_rows_adagrad_multi", arr, cnt, lr, eps, ptr(self.scale), st)
         if tr["U"]:
             self.upack_dirty = True
         if c.x_to_y and c.diag_b and tr["Wxy"]:

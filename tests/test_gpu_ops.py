@@ -372,6 +372,57 @@ def test_index_affine_and_filler_rows():
         assert torch.all(gt == 0) and torch.all(slot == 2 ** 31 - 1)
 
 
+def test_fused_optimizer_launches_equal_the_separate_kernels():
+    """seqrec_opt_sqnorm / seqrec_opt_apply (two launches for the whole clipnorm + Adagrad step) against
+    the five separate kernels on the same data: dense tensors of odd sizes + two scatter lists with
+    duplicates, filler rows and a shared table."""
+    rng = np.random.default_rng(77)
+    V, W = 4000, 256
+    sizes = [196608, 7, 768, 50001]
+    n1, n2 = 900, 333
+    rows1 = rng.integers(0, 60, size=n1).astype(np.int32); rows1[::11] = -1
+    rows2 = rng.integers(0, V, size=n2).astype(np.int32)
+    v1 = rng.normal(size=(n1, W)).astype(np.float32) * 0.01
+    v2 = rng.normal(size=(n2, W)).astype(np.float32) * 0.01
+    P0 = rng.normal(size=(V, W)).astype(np.float32); A0 = np.abs(rng.normal(size=(V, W))).astype(np.float32)
+    dp = [rng.normal(size=s).astype(np.float32) for s in sizes]
+    da = [np.abs(rng.normal(size=s)).astype(np.float32) for s in sizes]
+    dg = [(rng.normal(size=s) * 0.003).astype(np.float32) for s in sizes]
+    res = []
+    for fused in (False, True):
+        Pd, Ad = dev(P0.copy()), dev(A0.copy())
+        gt = torch.zeros((V, W), device="cuda")
+        slot = torch.full((V,), 2 ** 31 - 1, dtype=torch.int32, device="cuda")
+        r1, r2, d1, d2 = dev(rows1), dev(rows2), dev(v1), dev(v2)
+        jobs = [dict(table=Pd, accum=Ad, gtab=gt, slot=slot, rows=r1, vals=d1, ldv=W, row_scale=None, n=n1, width=W, base=0),
+                dict(table=Pd, accum=Ad, gtab=gt, slot=slot, rows=r2, vals=d2, ldv=W, row_scale=None, n=n2, width=W, base=n1)]
+        arr, cnt = L.rows_jobs(jobs)
+        call("seqrec_rows_scatter_add_multi", arr, cnt, st())
+        ps, as_, gs = [dev(x.copy()) for x in dp], [dev(x.copy()) for x in da], [dev(x) for x in dg]
+        pp, ap, gp, nn = L.ptr_array(ps), L.ptr_array(as_), L.ptr_array(gs), L.i64_array(sizes)
+        sq = torch.zeros(2, device="cuda"); sq[1] = 123.0
+        scale = torch.zeros(1, device="cuda")
+        if fused:
+            call("seqrec_opt_sqnorm", len(sizes), gp, nn, arr, cnt, ptr(sq[0:1]), st())
+            call("seqrec_opt_apply", len(sizes), pp, ap, gp, nn, arr, cnt, ptr(sq[0:1]), 0.05, 0.01, 1e-8, ptr(scale), ptr(sq[1:2]), st())
+            assert sq[1].item() == 0.0                       # the other norm slot was cleared for the next step
+        else:
+            call("seqrec_sqnorm_multi", len(sizes), gp, nn, ptr(sq[0:1]), st())
+            call("seqrec_rows_sqnorm_multi", arr, cnt, ptr(sq[0:1]), st())
+            call("seqrec_clip_scale", ptr(sq[0:1]), 0.05, ptr(scale), st())
+            call("seqrec_adagrad_dense_multi", len(sizes), pp, ap, gp, nn, 0.01, 1e-8, ptr(scale), st())
+            call("seqrec_rows_adagrad_multi", arr, cnt, 0.01, 1e-8, ptr(scale), st())
+        assert torch.all(gt == 0) and torch.all(slot == 2 ** 31 - 1)
+        res.append((sq[0].item(), scale.item(), Pd.cpu().numpy(), Ad.cpu().numpy(), [x.cpu().numpy() for x in ps],
+                    [x.cpu().numpy() for x in as_]))
+    a, b = res
+    assert abs(a[0] - b[0]) <= 1e-5 * a[0] and abs(a[1] - b[1]) <= 1e-6 * a[1] and a[1] < 1.0      # clip engaged
+    np.testing.assert_allclose(b[2], a[2], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(b[3], a[3], rtol=1e-5, atol=1e-7)
+    for x, y in zip(a[4] + a[5], b[4] + b[5]):
+        np.testing.assert_allclose(y, x, rtol=1e-5, atol=1e-7)
+
+
 def test_dense_adagrad_and_norm():
     rng = np.random.default_rng(4)
     n = 200003
