@@ -361,9 +361,10 @@ class ShardedEngine(Engine):
         call("seqrec_gemm_f32_grouped", len(wgrad), 0, 0, _lib.gemm_descs(wgrad), sk, ptr(wsp), st, tag="dW+dU")
         self.gemm(1, 1, n, Dp, GHp, dPre, GHp, P["W"], GHp, dX, Dp, splitk=self._splitk(n, Dp, GHp), tag="dX")
 
-    def _dense_update(self, lr, eps, clipnorm):
+    def _dense_update(self, lr, eps, clipnorm, rows_job=None):
         """After the owned row norms were added into self.sq: ONE all-reduce of [dense grads | sq],
-        dense norms on top (identical on every rank), Keras clip scale, dense Adagrad."""
+        dense norms on top (identical on every rank), then ONE launch for the Keras clip scale, the dense
+        Adagrad and (rows_job = (jobs array, count)) the row-sparse Adagrad of the owned rows."""
         st = self._stream()
         P, Gd = self.P, self.Gd
         self.dist.all_reduce(self.gflat, group=self.group)
@@ -371,9 +372,9 @@ class ShardedEngine(Engine):
         gp = _lib.ptr_array([Gd[k] for k in dk])
         nn = _lib.i64_array([Gd[k].numel() for k in dk])
         call("seqrec_sqnorm_multi", len(dk), gp, nn, ptr(self.sq), st)
-        call("seqrec_clip_scale", ptr(self.sq), float(clipnorm if clipnorm else 0.0), ptr(self.scale), st)
-        call("seqrec_adagrad_dense_multi", len(dk), _lib.ptr_array([P[k] for k in dk]),
-             _lib.ptr_array([self.A[k] for k in dk]), gp, nn, lr, eps, ptr(self.scale), st)
+        arr, cnt = rows_job if rows_job is not None else (None, 0)
+        call("seqrec_opt_apply", len(dk), _lib.ptr_array([P[k] for k in dk]), _lib.ptr_array([self.A[k] for k in dk]), gp, nn,
+             arr, cnt, ptr(self.sq), float(clipnorm if clipnorm else 0.0), lr, eps, ptr(self.scale), None, st)
         self.upack_dirty = True
 
     def _rows_in(self, d, step):
@@ -477,8 +478,7 @@ class ShardedEngine(Engine):
             return None
         call("seqrec_fill_f32", ptr(self.sq), 0.0, 1, st)
         call("seqrec_rows_sqnorm_multi", job, cnt, ptr(self.sq), st)
-        self._dense_update(lr, eps, clipnorm)                                   # collective 3
-        call("seqrec_rows_adagrad_multi", job, cnt, lr, eps, ptr(self.scale), st)
+        self._dense_update(lr, eps, clipnorm, (job, cnt))                       # collective 3
         return self.loss_sum * (self.R / d["n_total"])      # this rank's share, scaled so the mean over ranks is the global loss
 
     def _step_split(self, d, lr, eps, clipnorm, step, apply_update):
