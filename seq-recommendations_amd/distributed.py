@@ -30,12 +30,11 @@ upload time.  With D != H the tables keep separate widths and the step uses one 
 ``RowExchange`` is device-agnostic torch code (unit-tested with gloo on CPU, world size 2 and 3);
 ``ShardedEngine`` wires it to the HIP kernels.
 """
-import numpy as np
 import torch
 
 from . import _lib
 from ._lib import ptr
-from .engine import Engine, call, CELL, ACT, INT32_MAX, SPLITK_TARGET_WGS
+from .engine import Engine, call, INT32_MAX, SPLITK_TARGET_WGS
 
 
 class RowPlan:

@@ -19,8 +19,7 @@ HBM layout
   * activations are token-major [N_tok, width] in the time-major packed order of
     ``batching.RaggedBatch``.
 """
-import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 
 import numpy as np
 import torch

@@ -1,6 +1,5 @@
 """Op-level parity of the HIP kernels (through the C ABI) against numpy / the oracle.
 All tests need a real MI355X."""
-import ctypes
 import importlib
 
 import numpy as np
