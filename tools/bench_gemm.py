@@ -10,8 +10,8 @@ st = torch.cuda.current_stream().cuda_stream
 shapes = [(4096, 4096, 4096, 1, 0, 1), (8192, 8192, 1024, 1, 0, 1), (2546, 2000, 256, 1, 1, 1), (2546, 256, 2000, 1, 0, 4),
           (2000, 256, 2546, 0, 0, 4), (2546, 768, 256, 1, 0, 1), (256, 768, 2546, 0, 0, 11), (25088, 2000, 256, 1, 1, 1)]
 if os.environ.get("SWEEP_SPLITK"):
-    shapes = [(2546, 256, 2000, 1, 0, sk) for sk in (1, 2, 3, 4, 5, 6, 8)] + [(2000, 256, 2546, 0, 0, sk) for sk in (1, 2, 3, 4, 5, 6, 8, 10)] + \
-             [(2546, 256, 768, 1, 1, sk) for sk in (1, 2, 3, 4, 6)] + [(2546, 768, 256, 1, 0, sk) for sk in (1, 2)] + [(2546, 2000, 256, 1, 1, sk) for sk in (1, 2)]
+    shapes = [(2546, 256, 2000, 1, 0, sk) for sk in (6, 8, 12, 15)] + [(2000, 256, 2546, 0, 0, sk) for sk in (8, 10, 12, 16, 19)] + \
+             [(2546, 256, 768, 1, 1, sk) for sk in (3, 6)] + [(256, 768, 2546, 0, 0, sk) for sk in (11, 16, 19)]
 for (M, N, K, akc, bkc, sk) in shapes:
     A = torch.randn((M, K) if akc else (K, M), device="cuda")
     B = torch.randn((N, K) if bkc else (K, N), device="cuda")
