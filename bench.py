@@ -155,8 +155,16 @@ def main():
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if os.environ.get("SEQREC_BENCH_BACKEND", "nccl") == "gloo-staged":
+            # rehearsal of the N > 1 code path on a ONE-GPU box: every rank computes on cuda:0 and the
+            # collectives are staged through the host (distributed.HostStagedDist); numbers are meaningless
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist = importlib.import_module("seq-recommendations_amd.distributed").HostStagedDist(dist)
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     pkg = importlib.import_module("seq-recommendations_amd")
     pkg.require_hip()
     E = importlib.import_module("seq-recommendations_amd.engine")

@@ -37,6 +37,51 @@ from ._lib import ptr
 from .engine import Engine, call, INT32_MAX, SPLITK_TARGET_WGS
 
 
+class HostStagedDist:
+    """torch.distributed look-alike that stages device tensors through the host and a gloo group.
+    Debug / test transport only: RCCL refuses two ranks on one device, so the multi-rank logic of
+    ShardedEngine and bench.py is exercised on a ONE-GPU box with several processes sharing cuda:0
+    (tests/dist_gpu_worker.py, SEQREC_BENCH_BACKEND=gloo-staged).  Never used by the product path."""
+
+    def __init__(self, dist):
+        self.d = dist
+        self.ReduceOp = dist.ReduceOp
+
+    def get_world_size(self, group=None):
+        return self.d.get_world_size()
+
+    def get_rank(self, group=None):
+        return self.d.get_rank()
+
+    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None, group=None):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        self.d.all_to_all_single(o, inp.detach().cpu().contiguous(), output_split_sizes=output_split_sizes,
+                                 input_split_sizes=input_split_sizes)
+        out.copy_(o)
+
+    def all_reduce(self, t, op=None, group=None):
+        c = t.detach().cpu()
+        self.d.all_reduce(c, op=self.d.ReduceOp.SUM if op is None else op)
+        t.copy_(c)
+
+    def all_gather(self, outs, t, group=None):
+        cs = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+        self.d.all_gather(cs, t.detach().cpu())
+        for o, c in zip(outs, cs):
+            o.copy_(c)
+
+    def broadcast(self, t, src=0, group=None):
+        c = t.detach().cpu()
+        self.d.broadcast(c, src=src)
+        t.copy_(c)
+
+    def barrier(self, group=None):
+        self.d.barrier()
+
+    def destroy_process_group(self):
+        self.d.destroy_process_group()
+
+
 class RowPlan:
     """Routing of one list of global row ids (fixed per batch): who owns what, in which order."""
     __slots__ = ("n", "send_counts", "recv_counts", "perm", "inv_perm", "recv_local", "m")

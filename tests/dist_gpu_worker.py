@@ -17,41 +17,6 @@ from oracle import nn as onn, rng as orng          # noqa: E402
 from helpers import make_sessions, pad_batch       # noqa: E402
 
 
-class CpuStagedDist:
-    """torch.distributed look-alike that stages device tensors through the CPU (gloo)."""
-
-    def __init__(self):
-        self.d = dist
-
-    def get_world_size(self, group=None):
-        return dist.get_world_size()
-
-    def get_rank(self, group=None):
-        return dist.get_rank()
-
-    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None, group=None):
-        o = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_to_all_single(o, inp.detach().cpu().contiguous(), output_split_sizes=output_split_sizes,
-                               input_split_sizes=input_split_sizes)
-        out.copy_(o)
-
-    ReduceOp = dist.ReduceOp
-
-    def all_reduce(self, t, op=dist.ReduceOp.SUM, group=None):
-        c = t.detach().cpu()
-        dist.all_reduce(c, op=op)
-        t.copy_(c)
-
-    def all_gather(self, outs, t, group=None):
-        cs = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
-        dist.all_gather(cs, t.detach().cpu())
-        for o, c in zip(outs, cs):
-            o.copy_(c)
-
-    def barrier(self):
-        dist.barrier()
-
-
 def main():
     dist.init_process_group("gloo")
     rank, R = dist.get_rank(), dist.get_world_size()
@@ -73,7 +38,7 @@ def main():
         probs = Sm.log_uniform_probs(V)
         cfg = E.NetConfig(cell=cell, act="relu", H=H, V_in=V, V_out=V, input="embed", D=Dm, output="sampled", K=K, tied=tied,
                           logq=True, seed=9)
-        eng = D.ShardedEngine(cfg, "cuda:0", CpuStagedDist())
+        eng = D.ShardedEngine(cfg, "cuda:0", D.HostStagedDist(dist))
         for k in ("W", "U", "b"):
             eng.set_param(k, p[k])
         eng.set_param("E", p["E"][rank::R])

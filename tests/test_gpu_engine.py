@@ -225,3 +225,28 @@ def test_sharded_engine_ranks_share_one_gpu_vs_global_oracle(world):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
     assert r.stdout.count("case ok") == 3 and r.stdout.count("rank counts ok") == 2
+
+
+def test_bench_multi_rank_code_path_rehearsal():
+    """bench.py's N > 1 path (rank-sliced batches, broadcast of the replicated weights, barrier + MAX
+    timing, sharded Recall@20, ONE JSON line from rank 0) rehearsed with two processes on this one GPU
+    over the host-staged gloo transport (RCCL itself needs one device per rank)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4", SEQREC_BENCH_BACKEND="gloo-staged")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29655", os.path.join(root, "bench.py"), "--gpus", "2", "--config", "c2", "--steps", "6", "--warmup", "2",
+           "--distinct-batches", "4", "--profile-steps", "2", "--recall-steps", "4", "--recall-sessions", "256", "--sharded-recall",
+           "--cpu-seconds", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["parallelism"] == "dp2+row-sharded-tables" and out["config"]["global_batch"] == 1024
+    assert out["recall_at_20"] is not None and 0.0 <= out["recall_at_20"] <= 1.0
+    assert out["roofline"] is not None and np.isfinite(out["final_loss"])
