@@ -17,7 +17,7 @@ gen = Sy.SyntheticSessions(V, seed=1234)
 p = Sm.log_uniform_probs(V, gen.proposal_rank()); th, al = Sm.build_alias_table(p); eng.set_sampler(th, al, np.log(p).astype(np.float32))
 flat, starts = gen.generate(512 * 32)
 bs = [eng.upload(Bt.pack_flat(flat, starts, np.arange(i * 512, (i + 1) * 512))) for i in range(32)]
-for i in range(20): eng.train_step(bs[i % 32], step=i)
+for i in range(200): eng.train_step(bs[i % 32], step=i)      # past the fresh-process transient
 torch.cuda.synchronize()
 N = 200
 t0 = time.perf_counter()
