@@ -222,6 +222,9 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int tile
 
 template <int BM, int BN, int BKT, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+#ifdef SEQREC_PROBE_XCD_SKIP       // timing probe only (tools/overlap_probe.py): workgroups dealt to the first N XCDs do nothing
+    if ((int)(blockIdx.x & 7) < SEQREC_PROBE_XCD_SKIP) return;
+#endif
     gemm_tile_body<BM, BN, BKT, A_KC, B_KC>(g, blockIdx.x, blockIdx.z, gridDim.z);
 }
 
