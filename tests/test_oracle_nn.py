@@ -215,6 +215,51 @@ def test_backward_matches_torch_autograd_twin(cell, act):
         np.testing.assert_allclose(dense_grad(g[k], p[k].shape), tg[k], atol=1e-11)
 
 
+def test_simplernn_tanh_matches_torch_nn_rnn():
+    """An INDEPENDENT implementation for the one cell both libraries define identically: the oracle's
+    SimpleRNN with tanh on pre-padded batches against torch.nn.RNN on packed (ragged) sequences --
+    Masking + pre-padding == every session run from a zero state over its real steps (SURVEY 3.2
+    items 1-2).  Loss (masked token mean of softmax CE) and all weight gradients, fp64."""
+    rng = np.random.default_rng(15)
+    V, H = 9, 6
+    cfg = cfg_of("simplernn", act="tanh")
+    p = init_params(rng, cfg, V, H)
+    sessions = make_sessions(rng, 7, V, 2, 9)
+    batch = pad_batch(sessions)
+    net = onn.OracleNet(cfg, p)
+    loss = net.forward(batch)["loss"]
+    g = net.backward()
+    rnn = torch.nn.RNN(V, H, nonlinearity="tanh", batch_first=True).double()
+    with torch.no_grad():
+        rnn.weight_ih_l0.copy_(torch.tensor(p["Wk"].T))
+        rnn.weight_hh_l0.copy_(torch.tensor(p["U"].T))
+        rnn.bias_ih_l0.copy_(torch.tensor(p["b"]))
+        rnn.bias_hh_l0.zero_()
+    Wout = torch.tensor(p["Wout"], dtype=torch.float64, requires_grad=True)
+    lens = [len(s) - 1 for s in sessions]
+    T = max(lens)
+    x = torch.zeros(len(sessions), T, V, dtype=torch.float64)
+    tgt = torch.zeros(len(sessions), T, dtype=torch.long)
+    for b, sq in enumerate(sessions):                       # POST-padded for pack_padded_sequence
+        for t in range(lens[b]):
+            x[b, t, sq[t]] = 1.0
+            tgt[b, t] = sq[t + 1]
+    packed = torch.nn.utils.rnn.pack_padded_sequence(x, torch.tensor(lens), batch_first=True, enforce_sorted=False)
+    out, _ = rnn(packed)
+    hs, _ = torch.nn.utils.rnn.pad_packed_sequence(out, batch_first=True, total_length=T)
+    logp = torch.log_softmax(hs @ Wout, dim=2)
+    m = torch.zeros(len(sessions), T, dtype=torch.float64)
+    for b in range(len(sessions)):
+        m[b, : lens[b]] = 1.0
+    tl = -(logp.gather(2, tgt[:, :, None])[:, :, 0] * m).sum() / m.sum()
+    tl.backward()
+    assert abs(loss - tl.item()) < 1e-12
+    np.testing.assert_allclose(dense_grad(g["Wk"], p["Wk"].shape), rnn.weight_ih_l0.grad.numpy().T, atol=1e-11)
+    np.testing.assert_allclose(g["U"], rnn.weight_hh_l0.grad.numpy().T, atol=1e-11)
+    np.testing.assert_allclose(g["b"], rnn.bias_ih_l0.grad.numpy(), atol=1e-11)
+    np.testing.assert_allclose(g["Wout"], Wout.grad.numpy(), atol=1e-11)
+
+
 # (6) clipnorm + Adagrad
 def test_clip_and_adagrad_first_step():
     assert onn.clip_scale(0.25, 1.0) == 1.0
