@@ -235,6 +235,11 @@ int seqrec_opt_apply(int n_dense, float* const* params, float* const* accums, co
  *      counter rowkey[r]*width + j (rowkey nullable -> r): 0 or 1/(1-rate). */
 int seqrec_sample_negatives(uint64_t seed, uint64_t step, int K, const uint32_t* thresh,
                             const int32_t* alias, int V, int32_t* out, void* stream);
+/*      the same draws, fused with the gathers every step does right after them: rows_out[k,:] =
+ *      table[neg_out[k],:] and (logq_out != NULL) logq_out[k] = logq[neg_out[k]] -- one launch */
+int seqrec_sample_gather(uint64_t seed, uint64_t step, int K, const uint32_t* thresh, const int32_t* alias,
+                         int V, const float* table, int width, const float* logq, int32_t* neg_out,
+                         float* rows_out, float* logq_out, void* stream);
 int seqrec_dropout_mask(uint64_t seed, uint64_t stream_id, const int64_t* rowkey, int64_t n_rows,
                         int width, int64_t ld, double rate, float* out, void* stream);
 

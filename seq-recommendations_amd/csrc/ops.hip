@@ -448,6 +448,32 @@ __global__ void sample_negatives_kernel(uint64_t key, uint64_t step, int K, cons
     const int j = (int)((hi * (uint64_t)V) >> 32);
     out[k] = lo < thresh[j] ? j : alias[j];
 }
+// draw + row gather (+ log-Q gather) of the K shared negatives in one launch: wave k draws negative k
+// (every lane computes the same draw) and copies its table row
+__global__ void sample_gather_kernel(uint64_t key, uint64_t step, int K, const uint32_t* __restrict__ thresh,
+                                     const int* __restrict__ alias, int V, const float* __restrict__ table, int width,
+                                     const float* __restrict__ logq, int* __restrict__ neg, float* __restrict__ rows,
+                                     float* __restrict__ lq) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (k >= K) return;
+    const uint64_t r = rand64(key, step * (uint64_t)K + (uint64_t)k);
+    const uint64_t hi = r >> 32;
+    const uint32_t lo = (uint32_t)(r & 0xFFFFFFFFu);
+    const int j = (int)((hi * (uint64_t)V) >> 32);
+    const int id = lo < thresh[j] ? j : alias[j];
+    const float* src = table + (long)id * width;
+    float* dst = rows + (long)k * width;
+    if ((width & 3) == 0) {
+        for (int c = lane; c < width / 4; c += 64) reinterpret_cast<float4*>(dst)[c] = reinterpret_cast<const float4*>(src)[c];
+    } else {
+        for (int c = lane; c < width; c += 64) dst[c] = src[c];
+    }
+    if (lane == 0) {
+        neg[k] = id;
+        if (lq) lq[k] = logq[id];
+    }
+}
 __global__ void dropout_mask_kernel(uint64_t key, const long* __restrict__ rowkey, long n_rows, int width, long ld,
                                     uint32_t thr, float inv_keep, float* __restrict__ out) {
     const long total = n_rows * width;
@@ -853,6 +879,18 @@ extern "C" int seqrec_sample_negatives(uint64_t seed, uint64_t step, int K, cons
     if (!thresh || !alias || !out) return SEQREC_E_ARG;
     hipLaunchKernelGGL(sample_negatives_kernel, dim3((K + 255) / 256), dim3(256), 0, as_stream(stream), key64(seed, 1), step, K,
                        thresh, alias, V, out);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int seqrec_sample_gather(uint64_t seed, uint64_t step, int K, const uint32_t* thresh, const int32_t* alias,
+                                    int V, const float* table, int width, const float* logq, int32_t* neg_out,
+                                    float* rows_out, float* logq_out, void* stream) {
+    if (K < 0 || V <= 0 || width <= 0) return SEQREC_E_ARG;
+    if (K == 0) return 0;
+    if (!thresh || !alias || !table || !neg_out || !rows_out || (logq_out && !logq)) return SEQREC_E_ARG;
+    if ((width & 3) == 0 && ((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(rows_out)) & 15)) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(sample_gather_kernel, dim3((K + 3) / 4), dim3(256), 0, as_stream(stream), key64(seed, 1), step, K, thresh,
+                       alias, V, table, width, logq, neg_out, rows_out, logq_out);
     SEQREC_LAUNCH_CHECK();
     return 0;
 }

@@ -595,20 +595,20 @@ class Engine:
             K = c.K
             Et = P["E"] if c.tied else P["Eout"]
             th, al, lq = self.sampler
+            Eneg = self.buf("Eneg", K, Hp)
+            lq_neg = self.buf("lq_neg", K) if c.logq else None      # the candidates' log-Q once per step, not once per row
             if negatives is None:
-                neg = self.buf("neg", K, dtype=torch.int32)
-                call("seqrec_sample_negatives", int(c.seed), int(step), K, ptr(th), ptr(al), c.V_out, ptr(neg), st)
+                neg = self.buf("neg", K, dtype=torch.int32)         # draw + row gather + log-Q gather: one launch
+                call("seqrec_sample_gather", int(c.seed), int(step), K, ptr(th), ptr(al), c.V_out, ptr(Et), Hp,
+                     ptr(lq if c.logq else None), ptr(neg), ptr(Eneg), ptr(lq_neg), st)
             else:
                 neg = negatives
-            Eneg = self.buf("Eneg", K, Hp)
-            call("seqrec_gather_rows", ptr(Et), ptr(neg), ptr(Eneg), K, Hp, None, None, 0, st)
+                call("seqrec_gather_rows", ptr(Et), ptr(neg), ptr(Eneg), K, Hp, None, None, 0, st)
+                if c.logq:
+                    call("seqrec_gather_rows", ptr(lq), ptr(neg), ptr(lq_neg), K, 1, None, None, 0, st)
             ln = self.buf("ln", n, K)
             self.gemm(1, 1, n, K, Hp, Hd, Hp, Eneg, Hp, ln, K, tag="logits")
             dlt = self.buf("dlt", n)
-            lq_neg = None
-            if c.logq:                       # the candidates' log-Q once per step, not once per row
-                lq_neg = self.buf("lq_neg", K)
-                call("seqrec_gather_rows", ptr(lq), ptr(neg), ptr(lq_neg), K, 1, None, None, 0, st)
             call("seqrec_sampled_softmax_ce", ptr(ln), K, ptr(Hd), Hp, ptr(Et), ptr(P.get("bout")),
                  ptr(lq if c.logq else None), ptr(lq_neg), ptr(tgt), ptr(neg), n, K, inv, ptr(loss_rows), ptr(dlt), st)
             r.update(neg=neg, Eneg=Eneg, dln=ln, dlt=dlt)

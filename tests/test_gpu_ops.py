@@ -449,6 +449,17 @@ def test_counter_rng_bit_exact_vs_oracle():
         np.testing.assert_array_equal(out.cpu().numpy(), orng.sample_negatives(seed, step, K, th, al))
     # the draws follow the proposal (head items dominate)
     assert (out.cpu().numpy() < 1000).mean() > 0.4
+    # fused draw + row gather + log-Q gather: same ids, bit-identical rows
+    rng = np.random.default_rng(8)
+    for W in (256, 6):
+        tab = rng.normal(size=(V, W)).astype(np.float32)
+        lq = np.log(probs).astype(np.float32)
+        neg2 = torch.empty(K, dtype=torch.int32, device="cuda"); rows = torch.empty((K, W), device="cuda"); lqo = torch.empty(K, device="cuda")
+        call("seqrec_sample_gather", 7, 3, K, ptr(thd), ptr(ald), V, ptr(dev(tab)), W, ptr(dev(lq)), ptr(neg2), ptr(rows), ptr(lqo), st())
+        ids = orng.sample_negatives(7, 3, K, th, al)
+        np.testing.assert_array_equal(neg2.cpu().numpy(), ids)
+        np.testing.assert_array_equal(rows.cpu().numpy(), tab[ids])
+        np.testing.assert_array_equal(lqo.cpu().numpy(), lq[ids])
     rk = np.arange(50, dtype=np.int64) * 977 + 13
     m = torch.zeros((50, 12), device="cuda")
     call("seqrec_dropout_mask", 11, 35, ptr(dev(rk)), 50, 10, 12, 0.3, ptr(m), st())
