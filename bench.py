@@ -135,6 +135,23 @@ def pmc_traffic(kernel, t_mean, a):
     return {"bytes_per_call": round(tot), "source": "profiles/r01_v3_c3_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
 
 
+def pmc_mfma_util(kernel, a):
+    """Counter-based matrix-pipe utilisation of the dominant kernel's launches from the committed rocprofv3 PMC
+    pass (profiles/r01_v6_c3[_saturated]_pmc_mfma.json, tools/pmc_mfma.py); c3 only."""
+    path = os.path.join(ROOT, "profiles", "r01_v6_c3%s_pmc_mfma.json" % ("_saturated" if a.saturated else ""))
+    if a.config != "c3" or not os.path.exists(path):
+        return None
+    frag = {"seqrec_rnn_fwd_stepwise": "gru_step_fwd<4, 0, ", "seqrec_rnn_bwd_stepwise": "gru_step_bwd<4, 0, "}.get(kernel)
+    if not frag:
+        return None
+    pm = json.load(open(path))
+    out = {k[k.index("gru_step"):k.index(">") + 1]: v["mfma_util"] for k, v in pm.items() if frag in k}
+    if not out:
+        return None
+    out["source"] = os.path.relpath(path, ROOT) + " (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE)"
+    return out
+
+
 def main():
     a = parse()
     # stdout carries exactly ONE line (the JSON): everything libraries print while we run (RCCL's
@@ -279,7 +296,8 @@ def main():
                 e = kern[dom]
                 t_mean = float(np.mean([b["T"] for b in batches]))
                 roof = {"kernel": dom, "bound": e["bound"], "achieved": e["achieved"], "peak": e["peak"], "unit": e["unit"],
-                        "frac": e["frac"], "traffic": pmc_traffic(dom, t_mean, a), "avg_us": e["avg_us"],
+                        "frac": e["frac"], "traffic": pmc_traffic(dom, t_mean, a), "pmc_mfma_util": pmc_mfma_util(dom, a),
+                        "avg_us": e["avg_us"],
                         "share_of_step": e["share"]}
         except Exception as e:                                   # noqa: BLE001
             if dist is not None:
