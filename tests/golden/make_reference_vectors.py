@@ -102,6 +102,36 @@ def main():
         "random_seed": 99, "length": 12, "sequences": mc2_seqs,
     }
 
+    # --- randomized count-model / metric cases (incl. the MSNBC vocabulary size, 17) ------------------
+    rnd = []
+    for seed, n, nseq in ((11, 7, 9), (12, 17, 14), (13, 12, 6)):
+        r = np.random.RandomState(seed)
+        seqs = [[int(v) for v in r.randint(0, n, size=int(r.randint(2, 15)))] for _ in range(nseq)]
+        c = {"seqs": seqs, "n": n, "variants": []}
+        for k, freq, end_state in ((0.5, False, False), (2.0, False, True), (0.0 if n < 10 else 1e-3, True, False), (1.0, True, True)):
+            A, g = ru.transition_matrix(seqs, n, k=k, freq=freq, end_state=end_state)
+            c["variants"].append({"k": k, "freq": freq, "end_state": end_state, "alpha": np.asarray(A).tolist(),
+                                  "gamma": np.asarray(g).tolist()})
+        c["multinomial_k0.5"] = ru.multinomial_probabilities(seqs, n, k=0.5).tolist()
+        A, g = ru.transition_matrix(seqs, n, k=0.5, freq=False, end_state=False)
+        preds = [[float(g[s[0]])] + [float(A[i, j]) for i, j in zip(s[:-1], s[1:])] for s in seqs]
+        c["markov_preds"] = preds
+        c["compute_likelihood"] = [float(ru.compute_likelihood(preds, count_first_prob=False)),
+                                   float(ru.compute_likelihood(preds, count_first_prob=True))]
+        c["cut"] = {}
+        for tp in (0.7, 0.5):
+            tr, va = ru.compute_likelihood_cut(preds, tp)
+            c["cut"][str(tp)] = [float(tr), float(va)]
+        T = max(len(p) for p in preds)
+        padded = [[0.25] * (T - len(p)) + p for p in preds]
+        lens = [len(p) for p in preds]
+        tr2, va2 = ru.compute_likelihood_cut(padded, 0.7, orig_lengths=lens)
+        c["cut_orig_lengths"] = {"padded": padded, "lengths": lens, "out": [float(tr2), float(va2)]}
+        c["unique_elements"] = int(ru.compute_unique_elements(seqs))
+        c["seq_max_length"] = int(ru.compute_seq_max_length(seqs))
+        rnd.append(c)
+    out["cases"]["random_count_models"] = rnd
+
     with open(OUT, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", OUT)

@@ -44,3 +44,26 @@ def test_nll_metrics_match_reference():
     tr, va = om.compute_likelihood_cut(o["padded"], 0.7, orig_lengths=o["lengths"])
     assert [tr, va] == o["out"]
     assert om.neg_log_likelihood(np.array([0.5, 0.25, 0.125])) == c["neg_log_likelihood"]
+
+
+def test_random_count_models_and_metrics_match_reference():
+    """Randomized cases (incl. the MSNBC vocabulary size 17) produced by the reference's own utils.py:
+    every (k, freq, end_state) variant of transition_matrix, multinomial_probabilities, the Markov
+    prediction rule, compute_likelihood (both flags) and compute_likelihood_cut (two cut points and the
+    orig_lengths branch) -- bit for bit."""
+    for c in G["random_count_models"]:
+        seqs, n = c["seqs"], c["n"]
+        for v in c["variants"]:
+            A, g = om.transition_matrix(seqs, n, k=v["k"], freq=v["freq"], end_state=v["end_state"])
+            np.testing.assert_array_equal(A, np.array(v["alpha"]))
+            np.testing.assert_array_equal(g, np.array(v["gamma"]))
+        np.testing.assert_array_equal(om.multinomial_probabilities(seqs, n, 0.5), np.array(c["multinomial_k0.5"]))
+        A, g = om.transition_matrix(seqs, n, k=0.5, freq=False, end_state=False)
+        preds = om.markov_predict(A, g, seqs)
+        for a, b in zip(preds, c["markov_preds"]):
+            np.testing.assert_array_equal(a, b)
+        assert [om.compute_likelihood(preds, count_first_prob=False), om.compute_likelihood(preds, count_first_prob=True)] == c["compute_likelihood"]
+        for tp, ref in c["cut"].items():
+            assert list(om.compute_likelihood_cut(preds, float(tp))) == ref
+        o = c["cut_orig_lengths"]
+        assert list(om.compute_likelihood_cut(o["padded"], 0.7, orig_lengths=o["lengths"])) == o["out"]

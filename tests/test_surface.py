@@ -44,6 +44,29 @@ def test_product_metrics_match_reference_golden():
     assert r2.val_loss == c["compute_likelihood"]
 
 
+def test_product_metrics_match_reference_random_cases():
+    """The product's utils / count models against the randomized reference vectors (same checks as the
+    oracle's, tests/test_oracle_golden.py)."""
+    for c in G["random_count_models"]:
+        seqs, n = c["seqs"], c["n"]
+        for v in c["variants"]:
+            A, g = utils.transition_matrix(seqs, n, k=v["k"], freq=v["freq"], end_state=v["end_state"])
+            np.testing.assert_array_equal(A, np.array(v["alpha"]))
+            np.testing.assert_array_equal(g, np.array(v["gamma"]))
+        np.testing.assert_array_equal(utils.multinomial_probabilities(seqs, n, 0.5), np.array(c["multinomial_k0.5"]))
+        mk = model.MarkovModel(n, k=0.5)
+        mk.fit_model(seqs)
+        preds = mk.predict(seqs)
+        for a, b in zip(preds, c["markov_preds"]):
+            np.testing.assert_array_equal(a, b)
+        assert [utils.compute_likelihood(preds, count_first_prob=False), utils.compute_likelihood(preds, count_first_prob=True)] == c["compute_likelihood"]
+        for tp, ref in c["cut"].items():
+            assert list(utils.compute_likelihood_cut(preds, float(tp))) == ref
+        o = c["cut_orig_lengths"]
+        assert list(utils.compute_likelihood_cut(o["padded"], 0.7, orig_lengths=o["lengths"])) == o["out"]
+        assert utils.compute_unique_elements(seqs) == c["unique_elements"] and utils.compute_seq_max_length(seqs) == c["seq_max_length"]
+
+
 def test_preprocessor_pairing_and_pre_padding():
     seqs = [[3, 1, 0, 2], [2, 2], [1], [0, 1, 2, 3, 0, 1]]
     vocab = {i: i for i in range(4)}
