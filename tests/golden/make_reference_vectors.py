@@ -102,6 +102,25 @@ def main():
         "random_seed": 99, "length": 12, "sequences": mc2_seqs,
     }
 
+    # --- a seeded MCSampler DATASET at the MSNBC vocabulary size (SURVEY 8c KAT 9): inputs of the 3-epoch
+    #     loss-trajectory parity test (tests/test_gpu_model.py)
+    r17 = np.random.RandomState(17)
+    n17 = 17
+    a17 = r17.rand(n17, n17 + 1) ** 3                      # peaked rows: a learnable chain
+    a17[:, n17] = 0.12 * a17[:, :n17].sum(axis=1)          # end-token mass -> mean length ~8
+    a17 /= a17.sum(axis=1, keepdims=True)
+    g17 = r17.rand(n17)
+    g17 /= g17.sum()
+    random.seed(2017)
+    mc17 = rs.MCSampler(a17.copy(), g17.copy(), beta=0.8, use_end_token=True)
+    data = []
+    while len(data) < 650:
+        sq = [int(v) for v in mc17.gen_sequence()]
+        if 2 <= len(sq) <= 40:
+            data.append(sq)
+    out["cases"]["mcsampler_v17_dataset"] = {"alpha": a17.tolist(), "gamma": g17.tolist(), "beta": 0.8, "random_seed": 2017,
+                                             "train": data[:500], "val": data[500:]}
+
     # --- randomized count-model / metric cases (incl. the MSNBC vocabulary size, 17) ------------------
     rnd = []
     for seed, n, nseq in ((11, 7, 9), (12, 17, 14), (13, 12, 6)):
