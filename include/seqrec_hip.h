@@ -279,6 +279,16 @@ int seqrec_rank_count_thr(const float* hd, int H, const float* Eout, const float
                           const int32_t* tgt_local, const float* thr, int64_t n, int V, int32_t* rank,
                           void* stream);
 
+/* ---- top-K prediction at catalogue scale (extension; the reference's predict returns a dense (N,T,V)
+ *      tensor, model.py:186-190, which does not exist at |items| = 1M).  state_val / state_idx [n,64]
+ *      hold a running top-64 per row (initialise to -inf / -1); topk_merge folds in one chunk
+ *      scores[n, width] (+ bias[col0 + c]) of item columns col0 .. col0+width; topk_finish writes the k <= 64
+ *      best, sorted, to out_val / out_idx [n,k]. */
+int seqrec_topk_merge(const float* scores, int64_t ld, int64_t n, int width, int col0, const float* bias,
+                      float* state_val, int32_t* state_idx, void* stream);
+int seqrec_topk_finish(const float* state_val, const int32_t* state_idx, int64_t n, int k, float* out_val,
+                       int32_t* out_idx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

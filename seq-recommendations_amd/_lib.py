@@ -55,6 +55,8 @@ _SIGS = {
     "seqrec_mul": [P, P, P, L, P],
     "seqrec_fill_f32": [P, F, L, P],
     "seqrec_fill_i32": [P, I, L, P],
+    "seqrec_topk_merge": [P, L, L, I, I, P, P, P, P],
+    "seqrec_topk_finish": [P, P, L, I, P, P, P],
     "seqrec_opt_sqnorm": [I, P, P, P, I, P, P],
     "seqrec_opt_apply": [I, P, P, P, P, P, I, P, F, F, F, P, P, P],
     "seqrec_prior_grad": [P, P, L, C.c_float, P, P, P],

@@ -696,6 +696,84 @@ extern "C" int seqrec_fill_f32(float* x, float v, int64_t n, void* stream) {
     return 0;
 }
 // ---------------------------------------------------------------------------------------------
+// top-K prediction at catalogue scale ("top-K form at large V"): a running top-64 per row,
+// one candidate per lane, merged with one chunk of scores at a time -- no n x V matrix is ever kept
+// ---------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// state_val/state_idx [n,64]: the 64 best (score, item) pairs seen so far, unordered (init -inf / -1)
+__global__ void topk_merge_kernel(const float* __restrict__ scores, long ld, long n, int width, int col0,
+                                  const float* __restrict__ bias, float* __restrict__ state_val, int* __restrict__ state_idx) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float sv = state_val[row * 64 + lane];
+    int si = state_idx[row * 64 + lane];
+    float m = wave_min(sv);
+    const float* x = scores + row * ld;
+    for (int c0 = 0; c0 < width; c0 += 64) {
+        const int c = c0 + lane;
+        float v = c < width ? x[c] + (bias ? bias[col0 + c] : 0.f) : -INFINITY;
+        bool pending = v > m;
+        while (__any(pending)) {
+            const float vmax = wave_max(pending ? v : -INFINITY);
+            const int src = __ffsll((unsigned long long)__ballot(pending && v == vmax)) - 1;     // best pending candidate
+            const int dst = __ffsll((unsigned long long)__ballot(sv == m)) - 1;                  // slot holding the minimum
+            if (lane == dst) { sv = vmax; si = col0 + c0 + src; }
+            if (lane == src) pending = false;
+            m = wave_min(sv);
+            pending = pending && v > m;
+        }
+    }
+    state_val[row * 64 + lane] = sv;
+    state_idx[row * 64 + lane] = si;
+}
+// sorted output: out[row, r] = r-th best of the 64 (ties broken towards the lower item id)
+__global__ void topk_finish_kernel(const float* __restrict__ state_val, const int* __restrict__ state_idx, long n, int k,
+                                   float* __restrict__ out_val, int* __restrict__ out_idx) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float v = state_val[row * 64 + lane];
+    const int id = state_idx[row * 64 + lane];
+    int rank = 0;
+    for (int j = 0; j < 64; ++j) {
+        const float vj = __shfl(v, j, 64);
+        const int ij = __shfl(id, j, 64);
+        rank += (vj > v || (vj == v && (unsigned)ij < (unsigned)id)) ? 1 : 0;
+    }
+    if (rank < k) {
+        out_val[row * k + rank] = v;
+        out_idx[row * k + rank] = id;
+    }
+}
+}  // namespace
+extern "C" int seqrec_topk_merge(const float* scores, int64_t ld, int64_t n, int width, int col0, const float* bias,
+                                 float* state_val, int32_t* state_idx, void* stream) {
+    if (n < 0 || width < 0 || ld < width || col0 < 0) return SEQREC_E_ARG;
+    if (n == 0 || width == 0) return 0;
+    if (!scores || !state_val || !state_idx) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), scores, (long)ld, (long)n,
+                       width, col0, bias, state_val, state_idx);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int seqrec_topk_finish(const float* state_val, const int32_t* state_idx, int64_t n, int k, float* out_val,
+                                  int32_t* out_idx, void* stream) {
+    if (n < 0 || k < 1 || k > 64) return SEQREC_E_ARG;
+    if (n == 0) return 0;
+    if (!state_val || !state_idx || !out_val || !out_idx) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(topk_finish_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), state_val, state_idx,
+                       (long)n, k, out_val, out_idx);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Gaussian-prior / L2 kernel regularizer (model.py:71-91): R = strength * sum (w - mean)^2
 // ---------------------------------------------------------------------------------------------
 namespace {

@@ -825,6 +825,39 @@ class Engine:
         r = self.forward(d, train=False, stop_at_hidden=True)
         return r["Hd"]
 
+    def topk_rows(self, d, k=20, rows=None, chunk=65536):
+        """Top-k next items per token for sampled / tied output tables (the large-vocabulary form of
+        ``predict``): -> (item ids int32 [m,k], scores float32 [m,k]), best first.  ``rows`` (int tensor /
+        array of packed token indices, e.g. each session's last step) restricts the tokens that are
+        scored.  Scores one chunk of items at a time (GEMM + running top-64 merge): no m x V matrix."""
+        c, P = self.cfg, self.P
+        if c.output != "sampled":
+            raise ValueError("topk_rows is the catalogue-scale form; full-softmax models have predict_rows")
+        if not 1 <= k <= 64:
+            raise ValueError("1 <= k <= 64")
+        Hd = self.hidden_rows(d)
+        st = self._stream()
+        if rows is not None:
+            idx = torch.as_tensor(np.asarray(rows) if not torch.is_tensor(rows) else rows, dtype=torch.int32).to(self.dev)
+            Hs = torch.empty((idx.numel(), self.Hp), dtype=torch.float32, device=self.dev)
+            call("seqrec_gather_rows", ptr(Hd), ptr(idx), ptr(Hs), idx.numel(), self.Hp, None, None, 0, st)
+            Hd = Hs
+        m = Hd.shape[0]
+        Et = P["E"] if c.tied else P["Eout"]
+        sv = torch.full((max(m, 1), 64), float("-inf"), dtype=torch.float32, device=self.dev)
+        si = torch.full((max(m, 1), 64), -1, dtype=torch.int32, device=self.dev)
+        V = c.V_out
+        chunk = int(min(chunk, V))
+        sc = self.buf("topk_scores", m, chunk)
+        for c0 in range(0, V, chunk):
+            w = min(chunk, V - c0)
+            self.gemm(1, 1, m, w, self.Hp, Hd, self.Hp, Et[c0:c0 + w], self.Hp, sc, chunk, tag="topk")
+            call("seqrec_topk_merge", ptr(sc), chunk, m, w, c0, ptr(P.get("bout")), ptr(sv), ptr(si), st)
+        out_v = torch.empty((m, k), dtype=torch.float32, device=self.dev)
+        out_i = torch.empty((m, k), dtype=torch.int32, device=self.dev)
+        call("seqrec_topk_finish", ptr(sv), ptr(si), m, k, ptr(out_v), ptr(out_i), st)
+        return out_i, out_v
+
     def rank_counts(self, d):
         """rank[i] = number of items scoring strictly above the target of token i (sampled/tied
         output tables; score = h . Eout[v] + bout[v]).  Recall@K = mean(rank < K)."""

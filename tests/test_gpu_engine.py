@@ -175,6 +175,41 @@ def test_device_batcher_equals_host_packing():
             assert l1 == l2
 
 
+def test_topk_rows_matches_numpy_argsort():
+    """Catalogue-scale prediction: running top-64 merge over item chunks against a full numpy argsort,
+    with and without an output bias, on all tokens and on each session's last step only."""
+    import importlib
+    import torch
+    E = importlib.import_module("seq-recommendations_amd.engine")
+    Bt = importlib.import_module("seq-recommendations_amd.batching")
+    rng = np.random.default_rng(23)
+    for V, bias, tied in ((5003, True, False), (777, False, True)):
+        H = 64
+        cfg = E.NetConfig(cell="gru", act="tanh", H=H, V_in=V, V_out=V, input="embed", D=H, output="sampled", K=16, tied=tied,
+                          out_bias=bias, seed=1)
+        eng = E.Engine(cfg)
+        for k_, t in eng.P.items():
+            t.copy_(torch.from_numpy((rng.normal(size=tuple(t.shape)) * 0.2).astype(np.float32)))
+        eng.upack_dirty = True
+        rb = Bt.pack_sessions(make_sessions(rng, 60, V, 2, 9))
+        d = eng.upload(rb)
+        hd = eng.hidden_rows(d).cpu().numpy().astype(np.float64)
+        Et = eng.P["E" if tied else "Eout"].cpu().numpy().astype(np.float64)
+        sc = hd @ Et.T + (eng.P["bout"].cpu().numpy().astype(np.float64) if bias else 0.0)
+        for k in (1, 20, 64):
+            idx, val = eng.topk_rows(d, k=k, chunk=1024)
+            ref = np.argsort(-sc, axis=1, kind="stable")[:, :k]
+            got = idx.cpu().numpy()
+            refv = np.take_along_axis(sc, ref, axis=1)
+            np.testing.assert_allclose(val.cpu().numpy(), refv, rtol=2e-5, atol=2e-5)
+            assert (got == ref).mean() > 0.995                         # fp32-vs-fp64 near-ties may swap neighbours
+            assert np.all(np.diff(val.cpu().numpy(), axis=1) <= 0)       # best first
+        last = np.array([int(rb.step_off[l - 1] + b) for b, l in enumerate(rb.lengths)], dtype=np.int32)   # each session's final step
+        idx, val = eng.topk_rows(d, k=10, rows=last, chunk=2000)
+        ref = np.argsort(-sc[last], axis=1, kind="stable")[:, :10]
+        assert idx.shape == (len(last), 10) and (idx.cpu().numpy() == ref).mean() > 0.995
+
+
 def test_sharded_engine_single_rank_equals_oracle():
     """ShardedEngine over a 1-rank RCCL group: every exchange degenerates to a local copy, so losses
     and gradients must equal the oracle exactly like the plain engine (the N>1 routing itself is

@@ -122,3 +122,18 @@ def test_rank_counts_match_torch_reference_on_a_token_sample(world):
     ref = (sc > ts[:, None]).sum(1)
     diff = (rk[idx].long() - ref).abs()
     assert int(diff.max().item()) <= 3 and float((diff == 0).float().mean().item()) > 0.9, diff
+
+
+def test_topk_prediction_at_full_catalogue_matches_torch_topk(world):
+    """Top-20 next items for every session's last step over all 1M items (chunked GEMM + running top-64
+    merge) against torch.topk of a plain fp32 matmul."""
+    eng, flat, starts = world
+    rb = Bt.pack_flat(flat, starts, np.arange(3 * B, 4 * B))
+    d = eng.upload(rb)
+    last = np.array([int(rb.step_off[l - 1] + b) for b, l in enumerate(rb.lengths)], dtype=np.int32)
+    idx, val = eng.topk_rows(d, k=20, rows=last)
+    hd = eng.hidden_rows(d)[torch.from_numpy(last).to(eng.dev).long()]
+    ref_v, ref_i = torch.topk(hd @ eng.P["Eout"].T, 20, dim=1)
+    assert idx.shape == (len(last), 20)
+    assert float((idx.long() == ref_i).float().mean().item()) > 0.99            # near-ties may swap neighbours
+    torch.testing.assert_close(val, ref_v, rtol=2e-5, atol=2e-6)
