@@ -133,3 +133,82 @@ def test_msnbc_text_format_and_history_features(tmp_path):
     for k in ("order", "lengths", "step_off", "prev", "tok_b", "tok_s", "tok_row"):
         np.testing.assert_array_equal(getattr(a, k), getattr(b, k))
     assert b.ids is None and (a.B, a.T, a.n_tok, a.n_sessions) == (b.B, b.T, b.n_tok, b.n_sessions)
+
+
+def test_c_abi_rejects_bad_arguments_before_any_launch():
+    """Error behaviour of the boundary: negative status (SEQREC_E_ARG = -1, SEQREC_E_SHAPE = -2) for null
+    pointers / inconsistent sizes, detected on the host -- so this runs without a GPU."""
+    L = importlib.import_module("seq-recommendations_amd._lib")
+    lib = L.load()
+    E_ARG, E_SHAPE = -1, -2
+    one = 0x1000                       # a non-null address that is never dereferenced on the host
+    assert lib.seqrec_gather_rows(None, None, None, 5, 8, None, None, 0, None) == E_ARG
+    assert lib.seqrec_gemm_f32(1, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, 0, 1, None, None) == E_ARG
+    assert lib.seqrec_gemm_f32(1, 0, 4, 4, 4, one, 4, one, 4, one, 4, None, 0, 2, None, None) == E_ARG          # split-K without workspace
+    assert lib.seqrec_gemm_f32_grouped(0, 0, 0, None, 1, None, None) == E_ARG
+    assert lib.seqrec_rnn_fwd(0, 0, 100, 100, 3, 4, None, None, None, None, None, None, None) == E_SHAPE       # H not in {64..512}
+    assert lib.seqrec_rnn_fwd_stepwise(2, 0, 256, 300, 3, 4, one, None, one, one, one, one, one, None, 0, None) == E_SHAPE   # H_real > H
+    assert lib.seqrec_rnn_fwd_stepwise(2, 0, 256, 256, 3, 4, None, None, None, None, None, None, None, None, 0, None) == E_ARG
+    assert lib.seqrec_rnn_pack_u_stepwise(1, 100, one, one, None) == E_SHAPE
+    assert lib.seqrec_full_softmax_ce(one, 4, one, 3, 8, 1.0, one, None, None) == E_ARG                          # ld < V
+    assert lib.seqrec_sampled_softmax_ce(None, 8, one, 64, one, None, None, None, one, one, 3, 8, 1.0, one, one, None) == E_ARG
+    assert lib.seqrec_rows_scatter_add(one, one, one, one, 8, None, -1, 8, 0, None) == E_ARG
+    assert lib.seqrec_rows_adagrad(None, one, one, one, one, 4, 8, 0, 0.01, 1e-8, one, None) == E_ARG
+    assert lib.seqrec_opt_sqnorm(0, None, None, None, 0, one, None) == E_ARG                                      # nothing to do is an error
+    assert lib.seqrec_opt_sqnorm(9, one, one, None, 0, one, None) == E_ARG                                        # > 8 dense tensors
+    assert lib.seqrec_opt_apply(1, None, None, one, one, None, 0, one, 1.0, 0.01, 1e-8, one, None, None) == E_ARG
+    assert lib.seqrec_sample_negatives(1, 0, 4, None, None, 10, one, None) == E_ARG
+    assert lib.seqrec_sample_gather(1, 0, 4, one, one, 10, one, 0, None, one, one, None, None) == E_ARG           # width 0
+    assert lib.seqrec_dropout_mask(1, 2, one, 4, 8, 4, 0.5, one, None) == E_ARG                                   # ld < width
+    assert lib.seqrec_dropout_mask(1, 2, one, 4, 8, 8, 1.0, one, None) == E_ARG                                   # rate == 1
+    assert lib.seqrec_pack_batch(None, one, one, one, 4, 3, one, one, one, None) == E_ARG
+    assert lib.seqrec_history_features(one, one, one, one, 4, 3, 8, 4, 0, one, None) == E_ARG                     # ld < x_dim
+    assert lib.seqrec_topk_finish(one, one, 4, 65, one, one, None) == E_ARG                                       # k > 64
+    assert lib.seqrec_topk_merge(one, 4, 4, 8, 0, None, one, one, None) == E_ARG                                  # ld < width
+    assert lib.seqrec_rank_count(None, 64, one, None, one, 4, 10, one, one, None) == E_ARG
+    assert lib.seqrec_prior_grad(one, None, 4, 0.5, None, None, None) == E_ARG                                    # neither grad nor loss
+    assert lib.seqrec_index_affine_i32(None, None, one, None, 4, 1, 0, None) == E_ARG
+    # empty inputs are NOT errors
+    assert lib.seqrec_gather_rows(None, None, None, 0, 8, None, None, 0, None) == 0
+    assert lib.seqrec_rows_scatter_add(None, None, None, None, 8, None, 0, 8, 0, None) == 0
+    assert lib.seqrec_rnn_fwd_stepwise(2, 0, 256, 256, 0, 0, None, None, None, None, None, None, None, None, 0, None) == 0
+
+
+def test_packing_properties_hypothesis():
+    """Property-based: for ANY ragged set of sessions (empty ones, single-item ones, up to 50 items) the three
+    packers agree and the layout invariants hold -- every transition appears exactly once, time-major in
+    length-sorted order, prev links walk each session backwards."""
+    from hypothesis import given, settings, strategies as hst
+    B = importlib.import_module("seq-recommendations_amd.batching")
+
+    @settings(max_examples=120, deadline=None)
+    @given(hst.lists(hst.lists(hst.integers(0, 40), min_size=0, max_size=50), min_size=0, max_size=40))
+    def check(sessions):
+        rb = B.pack_sessions(sessions)
+        lens = [max(len(s) - 1, 0) for s in sessions]
+        assert rb.n_tok == sum(lens) and rb.T == (max(lens) if lens else 0) and rb.B == sum(1 for l in lens if l > 0)
+        assert rb.n_sessions == len(sessions)
+        assert list(rb.lengths) == sorted((l for l in lens if l > 0), reverse=True)
+        assert rb.step_off[0] == 0 and rb.step_off[-1] == rb.n_tok and np.all(np.diff(rb.step_off) >= 0)
+        assert np.all(np.diff(np.diff(rb.step_off)) <= 0) if rb.T > 1 else True        # B_t is non-increasing
+        seen = set()
+        for p in range(rb.n_tok):
+            b, t = int(rb.tok_b[p]), int(rb.tok_s[p])
+            assert rb.ids[p] == sessions[b][t] and rb.tgt[p] == sessions[b][t + 1]
+            assert p == rb.step_off[t] + rb.tok_row[p]
+            assert rb.prev[p] == (-1 if t == 0 else rb.step_off[t - 1] + rb.tok_row[p])
+            seen.add((b, t))
+        assert len(seen) == rb.n_tok
+        if sessions:
+            starts = np.zeros(len(sessions) + 1, np.int64)
+            np.cumsum([len(s) for s in sessions], out=starts[1:])
+            flat = np.array([v for s in sessions for v in s], dtype=np.int64)
+            rf = B.pack_flat(flat, starts, np.arange(len(sessions)))
+            ri = B.index_flat(starts, np.arange(len(sessions)))
+            for k in ("order", "lengths", "step_off", "prev", "tok_b", "tok_s", "tok_row"):
+                np.testing.assert_array_equal(getattr(rf, k), getattr(rb, k))
+                np.testing.assert_array_equal(getattr(ri, k), getattr(rb, k))
+            np.testing.assert_array_equal(rf.ids, rb.ids)
+            np.testing.assert_array_equal(rf.tgt, rb.tgt)
+
+    check()
