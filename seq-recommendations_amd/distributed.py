@@ -492,6 +492,59 @@ class ShardedEngine(Engine):
         self.dist.all_reduce(counts, group=self.group)
         return counts[self.rank * nmax: self.rank * nmax + n].clone()
 
+    def topk_rows(self, d, k=20, rows=None, chunk=65536):
+        """Top-k next items (GLOBAL ids) for this rank's tokens over the whole row-sharded catalogue:
+        hidden rows of all ranks are all-gathered, every rank keeps a running top-64 over its own shard
+        (seqrec_topk_merge), the per-shard candidates return to the rows' home ranks with one all-to-all
+        and the final top-k of the R x 64 candidates is taken there.  -> (ids int32 [m,k], scores [m,k])."""
+        if not self.unified:
+            raise NotImplementedError("sharded evaluation needs the unified tables (D == H)")
+        if not 1 <= k <= 64:
+            raise ValueError("1 <= k <= 64")
+        c, R, st = self.cfg, self.R, self._stream()
+        n, w = d["n"], self.Hp
+        xen, _ = self._rows_in(d, 0)
+        Hd = self._hidden(d, xen[:n])
+        if rows is not None:
+            idx = torch.as_tensor(np.asarray(rows) if not torch.is_tensor(rows) else rows, dtype=torch.int32).to(self.dev)
+            Hd = self._take(Hd, idx)
+        m = Hd.shape[0]
+        mm = torch.tensor([m], dtype=torch.int64, device=self.dev)
+        self.dist.all_reduce(mm, op=self.dist.ReduceOp.MAX, group=self.group)
+        mmax = int(mm.item())
+        pad = torch.zeros((mmax, w), dtype=torch.float32, device=self.dev)
+        pad[:m] = Hd
+        parts = [torch.empty_like(pad) for _ in range(R)]
+        if R > 1:
+            self.dist.all_gather(parts, pad, group=self.group)
+        else:
+            parts = [pad]
+        Hall = torch.cat(parts)                                          # [R * mmax, w]
+        rows_all = R * mmax
+        Et = self.P["E" if c.tied else "Eout"]
+        Vl = Et.shape[0]
+        sv = torch.full((rows_all, 64), float("-inf"), dtype=torch.float32, device=self.dev)
+        si = torch.full((rows_all, 64), -1, dtype=torch.int32, device=self.dev)
+        ch = int(min(chunk, max(Vl, 1)))
+        sc = self.buf("topk_scores", rows_all, ch)
+        for c0 in range(0, Vl, ch):
+            wd = min(ch, Vl - c0)
+            self.gemm(1, 1, rows_all, wd, w, Hall, w, Et[c0:c0 + wd], w, sc, ch, tag="topk")
+            call("seqrec_topk_merge", ptr(sc), ch, rows_all, wd, c0, None, ptr(sv), ptr(si), st)
+        gi = torch.where(si >= 0, si * R + self.rank, si)                # local row -> global item id
+        cand_v = self.ex.swap_fixed(sv.view(R, mmax, 64))                 # [R, mmax, 64]: candidates of MY rows from every shard
+        cand_i = self.ex.swap_fixed(gi.view(R, mmax, 64))
+        cv = cand_v.permute(1, 0, 2).reshape(mmax, R * 64).contiguous()
+        ci = cand_i.permute(1, 0, 2).reshape(mmax, R * 64).contiguous()
+        fv = torch.full((mmax, 64), float("-inf"), dtype=torch.float32, device=self.dev)
+        fc = torch.full((mmax, 64), -1, dtype=torch.int32, device=self.dev)
+        call("seqrec_topk_merge", ptr(cv), R * 64, mmax, R * 64, 0, None, ptr(fv), ptr(fc), st)
+        out_v = torch.empty((mmax, k), dtype=torch.float32, device=self.dev)
+        out_c = torch.empty((mmax, k), dtype=torch.int32, device=self.dev)
+        call("seqrec_topk_finish", ptr(fv), ptr(fc), mmax, k, ptr(out_v), ptr(out_c), st)
+        out_i = torch.gather(ci, 1, out_c.long().clamp_(min=0))          # candidate column -> global item id
+        return out_i[:m].contiguous(), out_v[:m].contiguous()
+
     def _hidden(self, d, X):
         P = self.P
         n, Hp, GHp, Dp = d["n"], self.Hp, self.GHp, self.Dp

@@ -82,6 +82,19 @@ def main():
                     ref = (sc > sc[np.arange(len(tj)), tj][:, None]).sum(1)
                     assert (rkj == ref).mean() > 0.97 and np.abs(rkj - ref).max() <= 2, (case, j, np.abs(rkj - ref).max())
                 print("rank counts ok:", case["cell"], "tied" if tied else "untied")
+            # sharded top-k prediction: global item ids of the 10 best items of every token
+            ti, tv = eng.topk_rows(d, k=10, chunk=300)
+            tk = [None] * R
+            dist.all_gather_object(tk, (ti.cpu().numpy(), tv.cpu().numpy()))
+            if rank == 0:
+                for j in range(R):
+                    _, hj, _, _ = info[j]
+                    sc = hj.astype(np.float64) @ table.T.astype(np.float64)
+                    ref = np.argsort(-sc, axis=1, kind="stable")[:, :10]
+                    gi_, gv_ = tk[j]
+                    assert gi_.shape == ref.shape and (gi_ == ref).mean() > 0.99, (case, j, (gi_ == ref).mean())
+                    np.testing.assert_allclose(gv_, np.take_along_axis(sc, ref, axis=1), rtol=2e-5, atol=2e-5)
+                print("sharded topk ok:", case["cell"])
         got = {"loss": losses, "W": eng.get_param("W"), "U": eng.get_param("U"), "b": eng.get_param("b"),
                "E": eng.get_param("E")}
         if not tied:

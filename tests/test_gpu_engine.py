@@ -259,7 +259,7 @@ def test_sharded_engine_ranks_share_one_gpu_vs_global_oracle(world):
            "127.0.0.1", "--master-port", str(29640 + world), os.path.join(here, "dist_gpu_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
-    assert r.stdout.count("case ok") == 3 and r.stdout.count("rank counts ok") == 2
+    assert r.stdout.count("case ok") == 3 and r.stdout.count("rank counts ok") == 2 and r.stdout.count("sharded topk ok") == 2
 
 
 def test_bench_multi_rank_code_path_rehearsal():
