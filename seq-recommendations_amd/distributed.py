@@ -30,6 +30,7 @@ upload time.  With D != H the tables keep separate widths and the step uses one 
 ``RowExchange`` is device-agnostic torch code (unit-tested with gloo on CPU, world size 2 and 3);
 ``ShardedEngine`` wires it to the HIP kernels.
 """
+import numpy as np
 import torch
 
 from . import _lib
