@@ -104,14 +104,18 @@ class SampledRNNModel:
         np.cumsum(lens, out=starts[1:])
         return np.fromiter((v for s in sessions for v in s), dtype=np.int32, count=int(starts[-1])), starts
 
-    def _epoch(self, flat, starts, order, batch_size, train):
+    def _park(self, flat, starts):
+        """Sessions parked in HBM once (single-GPU engine): batches are then built on the GPU."""
+        return self.engine.put_dataset(flat, starts) if self.dist is None else None
+
+    def _epoch(self, flat, starts, order, batch_size, train, ds=None):
         import torch
         eng, opt = self.engine, self.optimizer
         tot = torch.zeros(1, device=eng.dev)
         cnt = 0
         for s in range(0, len(order), batch_size):
             sel = order[s:s + batch_size]
-            d = eng.upload(batching.pack_flat(flat, starts, sel))
+            d = eng.upload_device(ds, sel) if ds is not None else eng.upload(batching.pack_flat(flat, starts, sel))
             if d["n"] == 0:
                 continue
             if train:
@@ -140,12 +144,14 @@ class SampledRNNModel:
         N = len(starts) - 1
         index = np.arange(N)
         self.stop_training = False
+        ds_tr = self._park(flat, starts)
+        ds_va = None if val is None else self._park(val[0], val[1])
         for epoch in range(n_epochs):
             if shuffle:
                 np.random.shuffle(index)
-            logs = {"loss": self._epoch(flat, starts, index, batch_size, True)}
+            logs = {"loss": self._epoch(flat, starts, index, batch_size, True, ds_tr)}
             if val is not None:
-                logs["val_loss"] = self._epoch(val[0], val[1], np.arange(len(val[1]) - 1), batch_size, False)
+                logs["val_loss"] = self._epoch(val[0], val[1], np.arange(len(val[1]) - 1), batch_size, False, ds_va)
             for cb in cbs:
                 cb.on_epoch_end(epoch, logs)
             if verbose:
@@ -158,7 +164,7 @@ class SampledRNNModel:
 
     def evaluate(self, x_test, y_test=None, batch_size=512, verbose=0):
         flat, starts = self._flat(x_test)
-        return self.metrics_names, [self._epoch(flat, starts, np.arange(len(starts) - 1), batch_size, False)]
+        return self.metrics_names, [self._epoch(flat, starts, np.arange(len(starts) - 1), batch_size, False, self._park(flat, starts))]
 
     def recall_at_k(self, sessions, k=20, batch_size=512):
         """Share of transitions whose true next item is among the k best-scored items (rank counting over
