@@ -96,7 +96,7 @@ __device__ __forceinline__ bool tile_of(const StepArgs& a, int& r0, int& cb) {
 //                                   CONSECUTIVE k of its A row and loads them straight from global memory
 // mode 0: B[k][n] = U[k*ldu + coff + n]           (forward:  K = H)
 // mode 1: B[k][n] = U[n*ldu + coff + k]           (backward: transposed; K = H or 2H)
-constexpr bool reg_operand(int K) { return K <= 512; }
+constexpr bool reg_operand(int K) { return K <= 2048; }
 struct PackStepJob { int coff, K, N, mode; long off; };
 struct PackStepArgs { const float* U; float* out; int ldu; PackStepJob job[4]; };
 __global__ void pack_step_kernel(PackStepArgs pa) {
