@@ -5,18 +5,27 @@ Workload (BASELINE.json `metric`, configs[2] = "c3"): synthetic MSNBC-shaped ses
 |items| = 1M, seq_len <= 50, batch 512 sessions per GPU, GRU hidden = 256 (Keras-2.0 GRU
 equations, hard_sigmoid gates, relu), embedding width 256, sampled softmax with K = 2000 shared
 log-uniform negatives, masked-token-mean CE, BPTT, global-norm clip 1.0 + Adagrad(lr 0.01,
-eps 1e-8).  A "step" is one full training step on one batch whose index arrays are already
-resident in HBM.  fp32 end to end (exact-fp32 MFMA).
+eps 1e-8).  fp32 end to end (exact-fp32 MFMA).
+
+What a "step" is (the loop of the reference's fit, experiments_methods.py:41-45 -> model.py:179-182):
+the SURVEY 8(d) data set -- 200k training and 20k held-out sessions per GPU -- is parked in HBM once; every
+step takes the NEXT 512 sessions of a per-epoch shuffle, builds its ragged batch on the device
+(Engine.upload_device: length sort on the host, id / target / link gather on the GPU) and runs one full
+training step.  Batch construction is INSIDE the timed region and no batch is revisited within an epoch
+(390 steps).  `--resident` restores the round-1 measurement (<= 64 pre-built batches cycled) for comparison.
 
     python bench.py --gpus N --steps K --warmup W
 
 prints ONE JSON line (rank 0).  Besides the contract fields it carries
   roofline     -- the dominant kernel of the step (by summed device time, HIP events on the launch
-                  stream over a profiled pass of the same batches): algorithmic flops (or bytes)
-                  per launch / mean launch duration against the gfx950 peak that bounds it;
+                  stream over a profiled pass): algorithmic flops (or bytes) per launch / mean launch
+                  duration against the gfx950 peak that bounds it;
   kernels      -- the same for every kernel class of the step;
   cpu_baseline -- the oracle (numpy fp32 restatement of the Keras/Theano path) timed on this box's
-                  host cores on a bounded sample of the SAME workload (rank 0, N = 1 only).
+                  host cores on a bounded sample of the SAME workload (rank 0, N = 1 only);
+  parity       -- GPU vs that CPU path from IDENTICAL host-generated initial weights on the same first
+                  batches and negatives: per-step loss of both, max relative difference (bound 1e-3,
+                  BASELINE.json north_star) and Recall@20 of both on the same held-out token sample.
 """
 import argparse
 import importlib
@@ -33,6 +42,7 @@ if ROOT not in sys.path:
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, Peak FP32 (matrix)
 PEAK_HBM_GBS = 8000.0             # HBM3E spec (6.29 TB/s measured-achievable)
+PARITY_BOUND = 1e-3               # north_star: loss / Recall@K within 1e-3 relative
 
 CONFIGS = {
     # name: V, H, D, K, cell
@@ -46,10 +56,12 @@ CONFIGS = {
     # c5: tied input/output table at 5M items
     "c5": dict(V=5_000_000, H=256, D=256, K=2000, cell="gru", tied=True,
                desc="c5: |items|=5M seq_len<=50 GRU hidden=256 tied input/output table sampled-softmax K=2000 batch 512/GPU"),
+    # tiny shape for the CPU-only test of the cpu_baseline / parity leg (tests/test_bench_cpu.py)
+    "tiny": dict(V=600, H=24, D=16, K=40, cell="gru", desc="tiny: test shape"),
 }
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -57,35 +69,94 @@ def parse():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=512, help="sessions per GPU per step")
     ap.add_argument("--saturated", action="store_true", help="every session has 50 items (roofline runs)")
+    ap.add_argument("--train-sessions", type=int, default=200_000, help="training sessions per GPU (SURVEY 8d)")
+    ap.add_argument("--test-sessions", type=int, default=20_000, help="held-out sessions (Recall@20)")
+    ap.add_argument("--resident", action="store_true",
+                    help="round-1 measurement: cycle <= --distinct-batches pre-built batches instead of fresh ones")
     ap.add_argument("--distinct-batches", type=int, default=64)
+    ap.add_argument("--settle", type=int, default=32, help="untimed steps before --warmup (see DESIGN.md 5)")
     ap.add_argument("--profile-steps", type=int, default=10)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--parity-steps", type=int, default=8, help="steps whose loss is compared GPU vs CPU (>= 5)")
+    ap.add_argument("--parity-sessions", type=int, default=256, help="held-out sessions of the Recall@20 parity sample")
     ap.add_argument("--recall-steps", type=int, default=1500, help="extra training steps before Recall@20 (0 = skip)")
-    ap.add_argument("--recall-sessions", type=int, default=2048)
     ap.add_argument("--force-sharded", action="store_true", help="use the row-sharded engine even on one GPU")
     ap.add_argument("--sharded-recall", action="store_true",
                     help="also compute Recall@20 through the sharded rank counting when N > 1 (default: only for N = 1)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def init_params_device(eng, cfg, seed):
-    """E, Eout ~ U(-0.01, 0.01); W glorot-uniform; U orthogonal per gate; b = 0."""
+# ------------------------------------------------------------------------------------------------
+# initial weights: E, Eout ~ U(-0.01, 0.01); W glorot-uniform; U orthogonal per gate; b = 0
+# ------------------------------------------------------------------------------------------------
+def host_weights(cd, seed):
+    """UNPADDED numpy fp32 initial weights, generated once on the host and loaded into BOTH the GPU
+    engine (Engine.set_param) and the CPU oracle: the parity leg starts both from identical values."""
+    V, H, D = cd["V"], cd["H"], cd["D"]
+    G = 3 if cd["cell"] == "gru" else (4 if cd["cell"] == "lstm" else 1)
+    rs = np.random.default_rng(seed)
+
+    def uni(shape, lim):
+        a = rs.random(shape, dtype=np.float32)
+        a *= np.float32(2 * lim)
+        a -= np.float32(lim)
+        return a
+
+    p = {"E": uni((V, D), 0.01)}
+    if not cd.get("tied", False):
+        p["Eout"] = uni((V, H), 0.01)
+    p["W"] = uni((D, G * H), float(np.sqrt(6.0 / (D + G * H))))
+    p["U"] = np.concatenate([np.linalg.qr(rs.normal(size=(H, H)))[0] for _ in range(G)], axis=1).astype(np.float32)
+    b = np.zeros(G * H, np.float32)
+    if cd["cell"] == "lstm":
+        b[H:2 * H] = 1.0                                   # Keras unit_forget_bias
+    p["b"] = b
+    return p
+
+
+def init_params_device(eng, cd, seed):
+    """Same distributions drawn on the device (multi-GPU runs and the full-size tests, where no CPU leg
+    needs the values).  Padded columns stay exactly zero."""
     import torch
     g = torch.Generator(device=eng.dev)
     g.manual_seed(seed)
     c = eng.cfg
     H, D, G = c.H, c.D, eng.G
     with torch.no_grad():
-        eng.P["E"].uniform_(-0.01, 0.01, generator=g)
+        eng.P["E"].zero_()
+        eng.P["E"][:, : (H if c.tied else D)].uniform_(-0.01, 0.01, generator=g)
         if "Eout" in eng.P:
-            eng.P["Eout"].uniform_(-0.01, 0.01, generator=g)
-        lim = float(np.sqrt(6.0 / (D + G * H)))
-        eng.P["W"].uniform_(-lim, lim, generator=g)
-        rs = np.random.default_rng(seed)
-        U = np.concatenate([np.linalg.qr(rs.normal(size=(H, H)))[0] for _ in range(G)], axis=1)
-        eng.set_param("U", U.astype(np.float32))
-        if "b" in eng.P:
-            eng.P["b"].zero_()
+            eng.P["Eout"].zero_()
+            eng.P["Eout"][:, :H].uniform_(-0.01, 0.01, generator=g)
+    rs = np.random.default_rng(seed)
+    lim = float(np.sqrt(6.0 / (D + G * H)))
+    eng.set_param("W", rs.uniform(-lim, lim, (D, G * H)).astype(np.float32))
+    eng.set_param("U", np.concatenate([np.linalg.qr(rs.normal(size=(H, H)))[0] for _ in range(G)], axis=1).astype(np.float32))
+    if "b" in eng.P:
+        b = np.zeros(G * H, np.float32)
+        if c.cell == "lstm":
+            b[H:2 * H] = 1.0
+        eng.set_param("b", b)
+
+
+# ------------------------------------------------------------------------------------------------
+# the batch stream: Keras fit's order (model.py:179-182 -> Model.fit: reshuffle every epoch, last batch short)
+# ------------------------------------------------------------------------------------------------
+class BatchStream:
+    """sel(i) = the session indices of global step i: epoch e = i // steps_per_epoch uses a permutation
+    of [lo, lo + n_train) seeded by (seed, e).  Deterministic, so the CPU leg replays the same batches."""
+
+    def __init__(self, lo, n_train, batch, seed):
+        self.lo, self.n, self.batch, self.seed = lo, n_train, batch, seed
+        self.per_epoch = -(-n_train // batch)
+        self._e, self._perm = -1, None
+
+    def sel(self, i):
+        e, j = divmod(i, self.per_epoch)
+        if e != self._e:
+            self._perm = self.lo + np.random.default_rng([self.seed, e]).permutation(self.n)
+            self._e = e
+        return self._perm[j * self.batch:(j + 1) * self.batch]
 
 
 def kernel_model(cfgd, n_tok, K, B):
@@ -96,7 +167,7 @@ def kernel_model(cfgd, n_tok, K, B):
     m = {
         "seqrec_rnn_fwd": ("mfma", 2.0 * G * H * H * n_tok),
         "seqrec_rnn_bwd": ("mfma", 2.0 * G * H * H * n_tok),
-        # step-wise scan: one C-ABI call = 2 launches per time step; work and time are per CALL
+        # step-wise scan: one C-ABI call = all its per-step launches; work and time are per CALL
         "seqrec_rnn_fwd_stepwise": ("mfma", 2.0 * G * H * H * n_tok),
         "seqrec_rnn_bwd_stepwise": ("mfma", 2.0 * G * H * H * n_tok),
         "seqrec_gemm_f32[xw]": ("mfma", 2.0 * n_tok * D * G * H),
@@ -112,13 +183,19 @@ def kernel_model(cfgd, n_tok, K, B):
     return m
 
 
+def _latest_profile(pattern):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return files[-1] if files else None
+
+
 def pmc_traffic(kernel, t_mean, a):
     """HBM bytes per call of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_v3_c3_pmc_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of
+    (profiles/r*_c3_pmc_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of
     this same command; FETCH_SIZE doubled per the gfx950 correction for wide coalesced reads).
     Only valid for the workload those passes profiled (c3, MSNBC-shaped); None otherwise."""
-    path = os.path.join(ROOT, "profiles", "r01_v3_c3_pmc_hbm_traffic.json")
-    if a.config != "c3" or a.saturated or not os.path.exists(path):
+    path = _latest_profile("r*_c3_pmc_hbm_traffic.json")
+    if a.config != "c3" or a.saturated or not path:
         return None
     pm = json.load(open(path))
     pick = {"seqrec_rnn_fwd_stepwise": ("gru_step_fwd<4, 0, 0>", "gru_step_fwd<4, 0, 1>"),
@@ -132,14 +209,15 @@ def pmc_traffic(kernel, t_mean, a):
             return None
         launches = t_mean - (1 if (i == 1 and "bwd" in kernel) else 0)     # bwd phase 1 is skipped at t = 0
         tot += launches * (ent["fetch_kib_x2"] + ent["write_kib"]) * 1024.0
-    return {"bytes_per_call": round(tot), "source": "profiles/r01_v3_c3_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+    return {"bytes_per_call": round(tot), "source": os.path.relpath(path, ROOT) +
+            " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
 
 
 def pmc_mfma_util(kernel, a):
     """Counter-based matrix-pipe utilisation of the dominant kernel's launches from the committed rocprofv3 PMC
-    pass (profiles/r01_v6_c3[_saturated]_pmc_mfma.json, tools/pmc_mfma.py); c3 only."""
-    path = os.path.join(ROOT, "profiles", "r01_v6_c3%s_pmc_mfma.json" % ("_saturated" if a.saturated else ""))
-    if a.config != "c3" or not os.path.exists(path):
+    pass (profiles/r*_c3[_saturated]_pmc_mfma.json, tools/pmc_mfma.py); c3 only."""
+    path = _latest_profile("r*_c3%s_pmc_mfma.json" % ("_saturated" if a.saturated else ""))
+    if a.config != "c3" or not path:
         return None
     frag = {"seqrec_rnn_fwd_stepwise": "gru_step_fwd<4, 0, ", "seqrec_rnn_bwd_stepwise": "gru_step_bwd<4, 0, "}.get(kernel)
     if not frag:
@@ -152,8 +230,112 @@ def pmc_mfma_util(kernel, a):
     return out
 
 
-def main():
-    a = parse()
+# ------------------------------------------------------------------------------------------------
+# CPU leg: the oracle on the same workload -- baseline timing AND the parity reference
+# ------------------------------------------------------------------------------------------------
+def padded_batch(flat, starts, sel):
+    """The reference's view of a batch (preprocessor.py:16-20,67-94): x = s[i], y = s[i+1], PRE-padded."""
+    sel = np.asarray(sel, dtype=np.int64)
+    L = (starts[sel + 1] - starts[sel] - 1).astype(np.int64)
+    T = int(max(L.max(), 1))
+    B = len(sel)
+    ids = np.zeros((B, T), np.int64); tgt = np.zeros((B, T), np.int64); mask = np.zeros((B, T), bool)
+    for b, s in enumerate(sel):
+        n = L[b]
+        if n <= 0:
+            continue
+        seq = flat[starts[s]:starts[s + 1]]
+        ids[b, T - n:] = seq[:-1]; tgt[b, T - n:] = seq[1:]; mask[b, T - n:] = True
+    return {"ids": ids, "tgt": tgt, "mask": mask}
+
+
+def cpu_rank_counts(onn, cd, p, batch, chunk=65536):
+    """rank[i] = #items scoring strictly above the target of real token i (oracle hidden states, scores
+    h . Eout[v]); token order = np.nonzero(mask) (row-major), the caller matches it with the GPU's."""
+    mask = batch["mask"]
+    ids = np.where(mask, batch["ids"], 0)
+    xw = p["E"][ids] @ p["W"] + p["b"]
+    xw = xw * mask[:, :, None].astype(xw.dtype)
+    hs, _ = onn.rnn_forward(cd["cell"], "relu", xw, mask, p["U"])
+    bi, ti = np.nonzero(mask)
+    h = hs[bi, ti]
+    Et = p["E"] if cd.get("tied", False) else p["Eout"]
+    tg = batch["tgt"][bi, ti]
+    ts = np.einsum("ij,ij->i", h, Et[tg])
+    rank = np.zeros(len(tg), np.int64)
+    for c0 in range(0, Et.shape[0], chunk):
+        gt = h @ Et[c0:c0 + chunk].T > ts[:, None]
+        own = np.nonzero((tg >= c0) & (tg < c0 + chunk))[0]
+        gt[own, tg[own] - c0] = False                  # the target never outranks itself (seqrec_rank_count: col != tgt)
+        rank += gt.sum(axis=1)
+    return rank, bi, ti
+
+
+def cpu_leg(cd, batch, flat, starts, sels, weights, th, al, logq, seed, seconds, parity_steps, sample_sel,
+            lr=0.01, eps=1e-8, clipnorm=1.0, max_steps=200):
+    """Runs the oracle from `weights` over the batches sels[0], sels[1], ... (wrapping around: an optional
+    leg must never index past what was generated) with the negatives of (seed, step): returns the timing,
+    the first `parity_steps` losses and the rank counts of `sample_sel` after exactly `parity_steps` steps."""
+    from oracle import nn as onn
+    from oracle import rng as orng
+    K = cd["K"]
+    p = {k: v.copy() for k, v in weights.items()}
+    acc = {k: np.zeros_like(v) for k, v in p.items()}
+    net = onn.OracleNet(dict(cell=cd["cell"], act="relu", input="embed", output="sampled", tied=bool(cd.get("tied", False)),
+                             use_bias=True, out_bias=False), p)
+
+    def one(i):
+        neg = orng.sample_negatives(seed, i, K, th, al)
+        out = net.forward(padded_batch(flat, starts, sels[i % len(sels)]), negatives=neg, logq=logq)
+        g = net.backward()
+        onn.adagrad_step(p, acc, g, lr=lr, eps=eps, clipnorm=clipnorm)
+        return float(out["loss"])
+
+    losses, el, n, ranks = [], 0.0, 0, None
+    parity_steps = max(1, parity_steps)
+    while True:
+        t0 = time.perf_counter()
+        l = one(n)
+        dt = time.perf_counter() - t0
+        if n > 0:                                    # step 0 pages the tables in: warm-up, not timed
+            el += dt
+        if n < parity_steps:
+            losses.append(l)
+        n += 1
+        if n == parity_steps and sample_sel is not None and len(sample_sel):
+            ranks = cpu_rank_counts(onn, cd, p, padded_batch(flat, starts, sample_sel))     # untimed
+        if n >= parity_steps and (el >= seconds or n >= max_steps):
+            break
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count()
+    timed = max(n - 1, 1)
+    return {"value": round(timed * batch / max(el, 1e-9), 1), "unit": "sessions/s", "cores": cores, "kind": "port",
+            "ms_per_step": round(el / timed * 1e3, 2), "steps_timed": timed, "losses": losses, "ranks": ranks,
+            "sample": "%d training steps of the same workload (batch %d, the GPU run's own first batches and negatives, "
+                      "identical initial weights; numpy fp32 oracle, BLAS threads = host cores), %.1f s"
+                      % (timed, batch, el)}
+
+
+def sample_order(rb):
+    """Packed-token index of every real (session row, step) in the row-major order cpu_rank_counts uses."""
+    order, ls, so = rb.order.astype(np.int64), rb.lengths.astype(np.int64), rb.step_off.astype(np.int64)
+    inv = np.full(rb.n_sessions, -1, np.int64)
+    inv[order] = np.arange(len(order))                   # original row -> sorted row
+    out = []
+    for b in np.sort(order):                             # sessions with >= 1 transition, original order
+        sb = inv[b]
+        out.append(so[:ls[sb]] + sb)
+    return np.concatenate(out) if out else np.zeros(0, np.int64)
+
+
+def rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-12)
+
+
+def main(argv=None):
+    a = parse(argv)
     # stdout carries exactly ONE line (the JSON): everything libraries print while we run (RCCL's
     # version banner, warnings) is sent to stderr by pointing fd 1 at fd 2 until the final print.
     sys.stdout.flush()
@@ -191,21 +373,30 @@ def main():
 
     cd = CONFIGS[a.config]
     V, H, D, K = cd["V"], cd["H"], cd["D"], cd["K"]
+    SEED = 1234
     dev = "cuda:%d" % local
     ncfg = E.NetConfig(cell=cd["cell"], act="relu", H=H, V_in=V, V_out=V, input="embed", D=D, output="sampled", K=K,
-                       tied=bool(cd.get("tied", False)), use_bias=True, out_bias=False, logq=True, seed=1234)
+                       tied=bool(cd.get("tied", False)), use_bias=True, out_bias=False, logq=True, seed=SEED)
     sharded = dist is not None
+    notes = []          # a failing OPTIONAL leg (single process only) must not take the throughput line with it
+    do_cpu = rank == 0 and world == 1 and not sharded and a.cpu_seconds > 0
     if sharded:
         Dm = importlib.import_module("seq-recommendations_amd.distributed")
         eng = Dm.ShardedEngine(ncfg, dev, dist)
     else:
         eng = E.Engine(ncfg, dev)
-    init_params_device(eng, cd, seed=1234 + rank)
+    weights = None
+    if do_cpu:
+        weights = host_weights(cd, SEED)
+        for k, v in weights.items():
+            eng.set_param(k, v)
+    else:
+        init_params_device(eng, cd, seed=SEED + rank)
     if sharded and world > 1:
         for k in ("W", "U", "b"):                       # replicated cell weights: rank 0's values everywhere
             dist.broadcast(eng.P[k], src=0)
         eng.upack_dirty = True
-    gen = Sy.SyntheticSessions(V, seed=1234)
+    gen = Sy.SyntheticSessions(V, seed=SEED)
     probs = Sm.log_uniform_probs(V, gen.proposal_rank())
     th, al = Sm.build_alias_table(probs)
     logq = np.log(probs).astype(np.float32)
@@ -218,15 +409,34 @@ def main():
     else:
         eng.set_sampler(th, al, logq)
 
-    # ---- batches: generated once, packed on the host, index arrays resident in HBM before timing
-    nb = max(1, min(a.distinct_batches, a.steps + a.warmup))
-    flat, starts = gen.generate(world * nb * a.batch + a.recall_sessions, saturated=a.saturated)
-    batches = []
-    for i in range(nb):
-        sel = np.arange((rank * nb + i) * a.batch, (rank * nb + i + 1) * a.batch)
-        batches.append(eng.upload(Bt.pack_flat(flat, starts, sel)))
-    n_tok_mean = float(np.mean([b["n"] for b in batches]))
-    t_max = int(max(b["T"] for b in batches))
+    # ---- data: world * n_train training sessions (rank r owns slice r) + n_test held-out, parked in HBM
+    n_train, n_test = a.train_sessions, a.test_sessions
+    flat, starts = gen.generate(world * n_train + n_test, saturated=a.saturated)
+    test_lo = world * n_train
+    stream = BatchStream(rank * n_train, n_train, a.batch, SEED)
+    ds = None if sharded else eng.put_dataset(flat, starts)
+    if not sharded:
+        eng.reserve(a.batch * 49)                      # no workspace growth while fresh batches stream through
+    resident = []
+    if a.resident:
+        nb = max(1, min(a.distinct_batches, stream.per_epoch))
+        resident = [eng.upload(Bt.pack_flat(flat, starts, stream.sel(i))) for i in range(nb)]
+
+    tok_seen = []
+
+    def next_batch(i):
+        if resident:
+            d = resident[i % len(resident)]
+        elif sharded:
+            d = eng.upload(Bt.pack_flat(flat, starts, stream.sel(i)))
+        else:
+            d = eng.upload_device(ds, stream.sel(i))
+        return d
+
+    def train(i):
+        d = next_batch(i)
+        tok_seen.append((d["n"], d["T"], d["rb"].n_sessions))
+        return eng.train_step(d, lr=0.01, eps=1e-8, clipnorm=1.0, step=i)
 
     def sync():
         torch.cuda.synchronize()
@@ -234,23 +444,40 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def gpu_ranks(sel):
+        d = eng.upload(Bt.pack_flat(flat, starts, sel))
+        return eng.rank_counts(d), d
+
     step = 0
-    # settle pass (untimed, not part of --warmup): one step on every distinct batch so that the grow-only
-    # workspaces reach their final size, every kernel variant is loaded and the clocks are up before the
-    # warm-up starts -- a 0.7 ms step is otherwise measured through ~60 steps of allocator growth and
-    # lazy code loading (tools/warmup_probe.py: 3.3 / 0.8 / 3.8 ms per step in the first three 20-step blocks)
-    settle = max(128, nb)       # also covers a one-off runtime stall seen around steps 40-60 of a fresh process
-    for i in range(settle):
-        eng.train_step(batches[step % nb], lr=0.01, eps=1e-8, clipnorm=1.0, step=step)
+    # ---- parity leg, GPU side: the first P steps from the host-generated weights, loss fetched per step
+    parity = None
+    P = max(5, a.parity_steps)
+    sample_sel = np.arange(test_lo, test_lo + min(a.parity_sessions, n_test))
+    gpu_par = None
+    if do_cpu:
+        try:
+            gl = []
+            for i in range(P):
+                gl.append(float(train(step).item()))
+                step += 1
+            rk, dsmp = gpu_ranks(sample_sel)
+            gpu_par = {"losses": gl, "ranks": rk.cpu().numpy()[sample_order(dsmp["rb"])]}
+        except Exception as e:                                   # noqa: BLE001
+            notes.append("parity leg (GPU side) failed: %r" % (e,))
+
+    # ---- settle (untimed; DESIGN.md 5 says what it covers), warm-up, timed region
+    for i in range(a.settle):
+        train(step)
         step += 1
     sync()
     for i in range(a.warmup):
-        eng.train_step(batches[step % nb], lr=0.01, eps=1e-8, clipnorm=1.0, step=step)
+        train(step)
         step += 1
     sync()
+    first_timed = len(tok_seen)
     t0 = time.perf_counter()
     for i in range(a.steps):
-        loss = eng.train_step(batches[step % nb], lr=0.01, eps=1e-8, clipnorm=1.0, step=step)
+        loss = train(step)
         step += 1
     sync()
     dt = time.perf_counter() - t0
@@ -258,23 +485,36 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    timed = tok_seen[first_timed:first_timed + a.steps]
+    sess_timed = float(sum(t[2] for t in timed))
+    n_tok_mean = float(np.mean([t[0] for t in timed]))
+    t_mean = float(np.mean([t[1] for t in timed]))
+    t_max = int(max(t[1] for t in timed))
+    if dist is not None and world > 1:
+        tt = torch.tensor([sess_timed, n_tok_mean], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt)
+        sess_total, tok_total = float(tt[0].item()), float(tt[1].item()) * a.steps
+    else:
+        sess_total, tok_total = sess_timed, n_tok_mean * a.steps
     ms_per_step = dt / a.steps * 1e3
-    sessions_per_s = a.steps * a.batch * world / dt
-    tokens_per_s = a.steps * n_tok_mean * world / dt
+    sessions_per_s = sess_total / dt
+    tokens_per_s = tok_total / dt
     last_loss = float(loss.item())
 
-    # ---- per-kernel device time (HIP events on the launch stream), same batches
+    # ---- per-kernel device time (HIP events on the launch stream), fresh batches too
     kern = {}
     roof = None
-    notes = []          # a failing OPTIONAL leg (single process only) must not take the throughput line with it
     if a.profile_steps > 0:
         try:
+            mark = len(tok_seen)
             E.profile_start()
             for i in range(a.profile_steps):
-                eng.train_step(batches[step % nb], lr=0.01, eps=1e-8, clipnorm=1.0, step=step)
+                train(step)
                 step += 1
             prof = E.profile_stop()
-            model = kernel_model(cd, n_tok_mean, K, a.batch)
+            n_prof = float(np.mean([t[0] for t in tok_seen[mark:]]))
+            t_prof = float(np.mean([t[1] for t in tok_seen[mark:]]))
+            model = kernel_model(cd, n_prof, K, a.batch)
             tot = sum(ms for _, ms in prof.values())
             for name, (cnt, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
                 per = ms / cnt
@@ -294,25 +534,24 @@ def main():
             dom = next((k for k in kern if "bound" in kern[k]), None)
             if dom:
                 e = kern[dom]
-                t_mean = float(np.mean([b["T"] for b in batches]))
                 roof = {"kernel": dom, "bound": e["bound"], "achieved": e["achieved"], "peak": e["peak"], "unit": e["unit"],
-                        "frac": e["frac"], "traffic": pmc_traffic(dom, t_mean, a), "pmc_mfma_util": pmc_mfma_util(dom, a),
-                        "avg_us": e["avg_us"],
-                        "share_of_step": e["share"]}
+                        "frac": e["frac"], "traffic": pmc_traffic(dom, t_prof, a), "pmc_mfma_util": pmc_mfma_util(dom, a),
+                        "avg_us": e["avg_us"], "share_of_step": e["share"], "tokens_per_call": round(n_prof, 1)}
         except Exception as e:                                   # noqa: BLE001
             if dist is not None:
                 raise
             E._PROF = None
             notes.append("profile leg failed: %r" % (e,))
 
-    # ---- Recall@20 on held-out sessions after some more training
+    # ---- Recall@20 on the held-out sessions after some more training
     recall = None
+    trained_par = None
     if a.recall_steps > 0 and sharded and (world == 1 or a.sharded_recall):
         for i in range(a.recall_steps):
-            eng.train_step(batches[step % nb], lr=0.01, eps=1e-8, clipnorm=1.0, step=step)
+            train(step)
             step += 1
-        per = a.recall_sessions // world                       # every rank scores the same number of held-out sessions
-        base = world * nb * a.batch + rank * per
+        per = n_test // world                                  # every rank scores the same number of held-out sessions
+        base = test_lo + rank * per
         acc = torch.zeros(2, dtype=torch.float64, device=dev)
         for s in range(0, per, a.batch):
             d = eng.upload(Bt.pack_flat(flat, starts, np.arange(base + s, base + min(per, s + a.batch))))
@@ -324,38 +563,75 @@ def main():
     if a.recall_steps > 0 and not sharded:
         try:
             for i in range(a.recall_steps):
-                eng.train_step(batches[step % nb], lr=0.01, eps=1e-8, clipnorm=1.0, step=step)
+                train(step)
                 step += 1
-            sel = np.arange(world * nb * a.batch, world * nb * a.batch + a.recall_sessions)
             hits = n = 0
-            for s in range(0, len(sel), a.batch):
-                d = eng.upload(Bt.pack_flat(flat, starts, sel[s:s + a.batch]))
-                rk = eng.rank_counts(d)
+            for s in range(0, n_test, a.batch):
+                rk, d = gpu_ranks(np.arange(test_lo + s, test_lo + min(n_test, s + a.batch)))
                 hits += int((rk < 20).sum().item())
                 n += d["n"]
             recall = hits / max(n, 1)
+            if do_cpu:
+                rk, dsmp = gpu_ranks(sample_sel)
+                trained_par = {"ranks": rk.cpu().numpy()[sample_order(dsmp["rb"])], "steps": step}
         except Exception as e:                                   # noqa: BLE001
             notes.append("recall leg failed: %r" % (e,))
 
-    # ---- CPU baseline: the oracle on a bounded sample of the same workload
+    # ---- CPU leg: the oracle from the SAME initial weights on the SAME batches / negatives
     cpu = None
-    if rank == 0 and world == 1 and not sharded and a.cpu_seconds > 0:
+    if do_cpu:
         try:
-            cpu = cpu_baseline(a, cd, gen, flat, starts, th, al, logq)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            sels = [stream.sel(i).copy() for i in range(min(stream.per_epoch, 200))]
+            cpu = cpu_leg(cd, a.batch, flat, starts, sels, weights, th, al, logq, SEED, a.cpu_seconds, P, sample_sel)
+            cl, cr = cpu.pop("losses"), cpu.pop("ranks")
+            if gpu_par is not None:
+                gl = gpu_par["losses"]
+                worst = max(rel(g, c) for g, c in zip(gl, cl))
+                parity = {"steps": P, "loss_gpu": [round(x, 6) for x in gl], "loss_cpu": [round(x, 6) for x in cl],
+                          "max_rel_diff": float("%.3g" % worst), "bound": PARITY_BOUND}
+                ok = worst <= PARITY_BOUND
+                if cr is not None:
+                    gr = gpu_par["ranks"]
+                    rg, rc = float((gr < 20).mean()), float((cr[0] < 20).mean())
+                    parity["recall_at_20_sample"] = {
+                        "after_steps": P, "tokens": int(len(gr)), "gpu": round(rg, 6), "cpu": round(rc, 6),
+                        "rel_diff": float("%.3g" % rel(rg, rc)) if max(rg, rc) > 0 else 0.0,
+                        "identical_ranks_frac": round(float((gr == cr[0]).mean()), 5)}
+                    ok = ok and (rg == rc or rel(rg, rc) <= PARITY_BOUND)
+                if trained_par is not None:
+                    # evaluation parity at the TRAINED weights (non-trivial Recall@20): the GPU's parameters are
+                    # downloaded into the oracle, which scores the same held-out sample on the host cores
+                    from oracle import nn as onn
+                    pw = {k: eng.get_param(k) for k in weights}
+                    cr2 = cpu_rank_counts(onn, cd, pw, padded_batch(flat, starts, sample_sel))
+                    gr2 = trained_par["ranks"]
+                    rg, rc = float((gr2 < 20).mean()), float((cr2[0] < 20).mean())
+                    parity["recall_at_20_sample_trained"] = {
+                        "after_steps": trained_par["steps"], "tokens": int(len(gr2)), "gpu": round(rg, 6), "cpu": round(rc, 6),
+                        "rel_diff": float("%.3g" % rel(rg, rc)) if max(rg, rc) > 0 else 0.0,
+                        "identical_ranks_frac": round(float((gr2 == cr2[0]).mean()), 5),
+                        "note": "GPU-trained weights scored by both paths"}
+                    ok = ok and (rg == rc or rel(rg, rc) <= PARITY_BOUND)
+                parity["ok"] = bool(ok)
         except Exception as e:                                   # noqa: BLE001
             notes.append("cpu_baseline leg failed: %r" % (e,))
 
     if rank == 0:
+        mode = ("resident: %d pre-built batches cycled" % len(resident)) if resident else \
+            "fresh batches: %d-session train set in HBM, batch built on the device inside the timed region, reshuffled per epoch" % n_train
         out = {
             "metric": "sessions/sec", "value": round(sessions_per_s, 1), "unit": "sessions/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cd["desc"] + (" (saturated: 50 items/session)" if a.saturated else " (MSNBC-shaped lengths)"),
                        "global_batch": a.batch * world, "seq_len": 50, "tokens_per_step_per_gpu": round(n_tok_mean, 1),
-                       "t_max": t_max, "settle_steps": settle,
+                       "t_mean": round(t_mean, 1), "t_max": t_max, "settle_steps": a.settle, "batches": mode,
+                       "train_sessions_per_gpu": n_train, "test_sessions": n_test,
                        "parallelism": ("dp%d+row-sharded-tables" % world) if sharded else "single"},
             "tokens_per_s": round(tokens_per_s, 1), "final_loss": round(last_loss, 5), "recall_at_20": recall,
-            "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
+            "recall_after_steps": step if recall is not None else None,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "kernels": kern,
         }
         if notes:
             out["notes"] = notes
@@ -365,61 +641,6 @@ def main():
         os.dup2(2, 1)
     if dist is not None:
         dist.destroy_process_group()
-
-
-def cpu_baseline(a, cd, gen, flat, starts, th, al, logq):
-    """Time the oracle (numpy fp32, all host cores through OpenBLAS) on the same workload."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle import nn as onn
-    from oracle import rng as orng
-    V, H, D, K = cd["V"], cd["H"], cd["D"], cd["K"]
-    G = onn.N_GATES[cd["cell"]]
-    rs = np.random.default_rng(1234)
-    p = {
-        "E": rs.uniform(-0.01, 0.01, (V, D)).astype(np.float32),
-        "Eout": rs.uniform(-0.01, 0.01, (V, H)).astype(np.float32),
-        "W": rs.uniform(-1, 1, (D, G * H)).astype(np.float32) * np.float32(np.sqrt(6.0 / (D + G * H))),
-        "U": np.concatenate([np.linalg.qr(rs.normal(size=(H, H)))[0] for _ in range(G)], axis=1).astype(np.float32),
-        "b": np.zeros(G * H, np.float32),
-    }
-    acc = {k: np.zeros_like(v) for k, v in p.items()}
-    net = onn.OracleNet(dict(cell=cd["cell"], act="relu", input="embed", output="sampled", tied=False,
-                             use_bias=True, out_bias=False), p)
-
-    def padded(i):
-        sel = np.arange(i * a.batch, (i + 1) * a.batch)
-        L = (starts[sel + 1] - starts[sel] - 1).astype(np.int64)
-        T = int(L.max())
-        ids = np.zeros((a.batch, T), np.int64); tgt = np.zeros((a.batch, T), np.int64); mask = np.zeros((a.batch, T), bool)
-        for b, s in enumerate(sel):
-            n = L[b]
-            seq = flat[starts[s]:starts[s + 1]]
-            ids[b, T - n:] = seq[:-1]; tgt[b, T - n:] = seq[1:]; mask[b, T - n:] = True
-        return {"ids": ids, "tgt": tgt, "mask": mask}
-
-    def one(i):
-        neg = orng.sample_negatives(1234, i, K, th, al)
-        net.forward(padded(i), negatives=neg, logq=logq)
-        g = net.backward()
-        onn.adagrad_step(p, acc, g, lr=0.01, eps=1e-8, clipnorm=1.0)
-
-    one(0)                                   # warm-up (page in the tables)
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        one(n + 1)
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= a.cpu_seconds or n >= 200:
-            break
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        cores = os.cpu_count()
-    return {"value": round(n * a.batch / el, 1), "unit": "sessions/s", "cores": cores, "kind": "port",
-            "ms_per_step": round(el / n * 1e3, 2),
-            "sample": "%d training steps of the same %s workload (batch %d, identical session generator, numpy fp32 "
-                      "oracle, OpenBLAS threads = host cores), %.1f s" % (n, a.config, a.batch, el)}
 
 
 if __name__ == "__main__":

@@ -201,6 +201,15 @@ typedef struct seqrec_rows_job {
     int64_t n; int32_t width; int32_t base;
 } seqrec_rows_job;
 int seqrec_rows_scatter_add_multi(const seqrec_rows_job* jobs_host, int count, void* stream);
+/*      deterministic alternative to seqrec_rows_scatter_add_multi for the lists of ONE table (same gtab, slot
+ *      and width; `base` ranges disjoint): contributions are keyed (row, base + i), sorted by row with a stable
+ *      radix sort and summed per row in increasing index order with plain loads/stores -- no float atomics,
+ *      bitwise reproducible (merge.hip).  Leaves gtab / slot exactly as the atomic form does
+ *      (gtab[row] += sum, slot[row] = min(base + i)), so sqnorm / adagrad are shared.  The reference's dense
+ *      Adagrad (experiments_methods.py:41) is deterministic; this is the path that matches that property. */
+int64_t seqrec_rows_merge_workspace_bytes(int64_t n_total, int width);
+int seqrec_rows_merge_sorted(const seqrec_rows_job* jobs_host, int count, void* workspace, int64_t workspace_bytes,
+                             void* stream);
 int seqrec_rows_sqnorm_multi(const seqrec_rows_job* jobs_host, int count, float* sq_accum, void* stream);
 int seqrec_rows_adagrad_multi(const seqrec_rows_job* jobs_host, int count, float lr, float eps,
                               const float* scale, void* stream);
@@ -226,6 +235,12 @@ int seqrec_adagrad_dense_multi(int count, float* const* p, float* const* a, cons
  *      a separate clearing launch. */
 int seqrec_opt_sqnorm(int n_dense, const float* const* grads, const int64_t* numel,
                       const seqrec_rows_job* jobs_host, int n_jobs, float* sq_accum, void* stream);
+/*      deterministic form of the norm (no float atomics): per-block partial sums into `partials`
+ *      (seqrec_opt_sqnorm_ordered_floats() floats), added in index order by one block; *sq_out is overwritten */
+int64_t seqrec_opt_sqnorm_ordered_floats(int n_dense, int n_jobs, int64_t max_job_rows);
+int seqrec_opt_sqnorm_ordered(int n_dense, const float* const* grads, const int64_t* numel,
+                              const seqrec_rows_job* jobs_host, int n_jobs, float* partials,
+                              int64_t partials_floats, float* sq_out, void* stream);
 int seqrec_opt_apply(int n_dense, float* const* params, float* const* accums, const float* const* grads,
                      const int64_t* numel, const seqrec_rows_job* jobs_host, int n_jobs, const float* sq,
                      float clipnorm, float lr, float eps, float* scale_out, float* zero_next, void* stream);

@@ -67,6 +67,10 @@ _SIGS = {
     "seqrec_rows_sqnorm": [P, P, P, L, I, I, P, P],
     "seqrec_rows_adagrad": [P, P, P, P, P, L, I, I, F, F, P, P],
     "seqrec_rows_scatter_add_multi": [P, I, P],
+    "seqrec_rows_merge_workspace_bytes": [L, I],
+    "seqrec_rows_merge_sorted": [P, I, P, L, P],
+    "seqrec_opt_sqnorm_ordered_floats": [I, I, L],
+    "seqrec_opt_sqnorm_ordered": [I, P, P, P, I, P, L, P, P],
     "seqrec_rows_sqnorm_multi": [P, I, P, P],
     "seqrec_rows_adagrad_multi": [P, I, F, F, P, P],
     "seqrec_sqnorm_multi": [I, P, P, P, P],
@@ -85,6 +89,8 @@ _RESTYPES = {
     "seqrec_build_arch": C.c_char_p,
     "seqrec_gemm_workspace_floats": L,
     "seqrec_rnn_upack_floats": L,
+    "seqrec_rows_merge_workspace_bytes": L,
+    "seqrec_opt_sqnorm_ordered_floats": L,
 }
 EXPORTS = sorted(_SIGS)
 

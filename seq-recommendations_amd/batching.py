@@ -36,6 +36,18 @@ class RaggedBatch:
     __slots__ = ("order", "lengths", "step_off", "ids", "tgt", "x", "prev", "tok_b", "tok_s", "tok_row", "xs",
                  "n_sessions", "B", "T", "n_tok")
 
+    def ensure_tokens(self):
+        """Per-token coordinates (prev / tok_b / tok_s / tok_row) of a batch packed by
+        index_flat(..., lean=True), which skips them: only dropout and host-side tests need them."""
+        if self.tok_s is None:
+            so = self.step_off.astype(np.int64)
+            bt = np.diff(so)
+            tok_t = np.repeat(np.arange(self.T, dtype=np.int64), bt)
+            tok_bs = np.arange(self.n_tok, dtype=np.int64) - so[tok_t]
+            _finish(self, self.order.astype(np.int64), self.lengths, so, tok_t, tok_bs, self.B, self.T, self.n_tok,
+                    self.n_sessions)
+        return self
+
 
 def _pack_index(lengths):
     """lengths (any order) -> order, sorted lengths, step_off, (tok_t, tok_bsorted)."""
@@ -103,15 +115,29 @@ def pack_flat(flat, starts, sel):
     return _finish(rb, order, ls, step_off, tok_t, tok_bs, B, T, n_tok, len(sel))
 
 
-def index_flat(starts, sel):
+def index_flat(starts, sel, lean=False):
     """Index-only packing for the device-side batcher (engine.Engine.upload_device): everything the
     host needs (order, lengths, step offsets, token coordinates) from the session LENGTHS alone; the
-    item ids are gathered on the GPU by seqrec_pack_batch, so rb.ids / rb.tgt stay None."""
+    item ids are gathered on the GPU by seqrec_pack_batch, so rb.ids / rb.tgt stay None.
+    lean=True computes only what a training step needs on the host (order, lengths, step offsets:
+    a sort of the batch's lengths); RaggedBatch.ensure_tokens() adds the per-token arrays on demand."""
     sel = np.asarray(sel, dtype=np.int64)
     lengths = np.maximum(starts[sel + 1] - starts[sel] - 1, 0)
-    order, ls, step_off, tok_t, tok_bs, B, T, n_tok = _pack_index(lengths)
     rb = RaggedBatch()
     rb.ids = rb.tgt = rb.x = rb.xs = None
+    if lean:
+        order = np.argsort(-lengths, kind="stable")
+        ls = lengths[order]
+        B = int(np.count_nonzero(ls > 0))
+        T = int(ls[0]) if B else 0
+        step_off = np.zeros(T + 1, dtype=np.int32)
+        # B_t = #{L > t} for the descending ls
+        np.cumsum(np.searchsorted(-ls[:B], -np.arange(T, dtype=np.int64), side="left"), out=step_off[1:])
+        rb.order, rb.lengths, rb.step_off = order[:B].astype(np.int32), ls[:B].astype(np.int32), step_off
+        rb.prev = rb.tok_b = rb.tok_s = rb.tok_row = None
+        rb.B, rb.T, rb.n_tok, rb.n_sessions = B, T, int(step_off[-1]), len(sel)
+        return rb
+    order, ls, step_off, tok_t, tok_bs, B, T, n_tok = _pack_index(lengths)
     return _finish(rb, order, ls, step_off, tok_t, tok_bs, B, T, n_tok, len(sel))
 
 

@@ -399,6 +399,39 @@ __global__ void opt_sqnorm_kernel(OptPlan pl, float* __restrict__ sq) {
         if (t != 0.f) atomicAdd(sq, t);
     }
 }
+// deterministic form of the norm (merge = "sorted"): every block stores its partial sum, a single block adds the
+// partials in index order (reduce_sum_kernel) -- no float atomics, bitwise reproducible
+__global__ void opt_sqnorm_partial_kernel(OptPlan pl, float* __restrict__ partials) {
+    __shared__ float part[4];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float s = 0.f;
+    if ((int)blockIdx.y < pl.nd) {
+        const float* g = pl.d.g[blockIdx.y];
+        const long n = pl.d.n[blockIdx.y];
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += g[i] * g[i];
+    } else {
+        constexpr int RPW = 4;
+        const seqrec_rows_job& J = pl.r.j[blockIdx.y - pl.nd];
+        const long i0 = ((long)blockIdx.x * (blockDim.x >> 6) + wv) * RPW;
+        int r[RPW];
+        bool own[RPW];
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) r[k] = (i0 + k < J.n) ? J.rows[i0 + k] : -1;
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) own[k] = r[k] >= 0 && J.slot[r[k]] == J.base + (int)(i0 + k);
+        for (int c = lane; c < J.width; c += 64) {
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) {
+                const float g = own[k] ? J.gtab[(long)r[k] * J.width + c] : 0.f;
+                s += g * g;
+            }
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) part[wv] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
 __global__ void opt_apply_kernel(OptPlan pl, const float* __restrict__ sq, float clipnorm, float lr, float eps,
                                  float* __restrict__ scale_out, float* __restrict__ zero_next) {
     const float nrm = sqrtf(sq[0]);
@@ -1087,6 +1120,28 @@ extern "C" int seqrec_opt_sqnorm(int n_dense, const float* const* grads, const i
     if (!sq_accum) return SEQREC_E_ARG;
     const unsigned gx = (unsigned)std::max<long>(32, (maxn + 15) / 16);
     hipLaunchKernelGGL(opt_sqnorm_kernel, dim3(gx, n_dense + n_jobs), dim3(256), 0, as_stream(stream), pl, sq_accum);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int64_t seqrec_opt_sqnorm_ordered_floats(int n_dense, int n_jobs, int64_t max_job_rows) {
+    const long gx = std::max<long>(32, (max_job_rows + 15) / 16);
+    return (int64_t)gx * (n_dense + n_jobs);
+}
+extern "C" int seqrec_opt_sqnorm_ordered(int n_dense, const float* const* grads, const int64_t* numel,
+                                         const seqrec_rows_job* jobs_host, int n_jobs, float* partials,
+                                         int64_t partials_floats, float* sq_out, void* stream) {
+    OptPlan pl;
+    long maxn;
+    const int rc = fill_opt_plan(n_dense, nullptr, nullptr, grads, numel, jobs_host, n_jobs, false, pl, maxn);
+    if (rc) return rc;
+    if (!sq_out || !partials) return SEQREC_E_ARG;
+    const unsigned gx = (unsigned)std::max<long>(32, (maxn + 15) / 16);
+    const long np = (long)gx * (n_dense + n_jobs);
+    if (np > partials_floats) return SEQREC_E_ARG;
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(opt_sqnorm_partial_kernel, dim3(gx, n_dense + n_jobs), dim3(256), 0, st, pl, partials);
+    SEQREC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, st, partials, np, sq_out, 0);
     SEQREC_LAUNCH_CHECK();
     return 0;
 }

@@ -105,6 +105,8 @@ class NetConfig:
     x_to_y: bool = False          # logits += xs_t . Wxy   (history features, x_dim wide)
     x_dim: int = 0
     diag_b: bool = True           # OnlyNonZeroDiagonal on Wxy (model.py:48-66): re-applied after every update
+    merge: str = "atomic"         # row-sparse gradient merge: 'atomic' (float atomics, sums reproducible to rounding) |
+                                  # 'sorted' (stable sort by row + ordered segment sum, csrc/merge.hip: bitwise reproducible)
     priors: tuple = ()            # parameters that carry a kernel regularizer (Engine.set_prior); a table listed
                                   # here is updated densely (the penalty's gradient touches every row)
 
@@ -124,6 +126,8 @@ class Engine:
         c = cfg
         if c.cell not in CELL or c.act not in ACT:
             raise ValueError("unsupported cell/activation %r/%r" % (c.cell, c.act))
+        if c.merge not in ("atomic", "sorted"):
+            raise ValueError("merge must be 'atomic' or 'sorted', not %r" % (c.merge,))
         self.Hp = _pad_h(c.H)
         self.G = c.G
         self.GHp = self.G * self.Hp
@@ -194,6 +198,7 @@ class Engine:
         self.slot = {k: torch.full((P[k].shape[0],), INT32_MAX, dtype=torch.int32, device=self.dev)
                      for k in self.table_params}
         self.ws = {}
+        self._merge_ws = {}
         self._views = {}
         self._cur_st = None
         self.sq1 = z(1)                 # squared gradient norm (multi-launch path)
@@ -243,6 +248,41 @@ class Engine:
             self._views.clear()
         self._views[key] = v
         return v
+
+    def reserve(self, n_tok_max):
+        """Size every grow-only workspace of a training step for batches of up to n_tok_max transitions,
+        so that a loop over fresh batches (a new N_tok every step) never re-allocates in steady state."""
+        c = self.cfg
+        n, Hp, GHp = int(n_tok_max), self.Hp, self.GHp
+        need = {"XW": n * GHp, "Hout": n * Hp, "gates": n * GHp, "aux": n * Hp, "loss_rows": n, "dHd": n * Hp,
+                "dPre": n * GHp, "Hprev": n * Hp, "scan_ws": 2 * n * Hp, "thr": n,
+                "colsum_ws": 64 * max(GHp, self.Vp, c.K if c.output == "sampled" else 1)}
+        if c.input == "embed":
+            need.update(X=n * self.Dp, dX=n * self.Dp)
+        if c.output == "sampled":
+            need.update(Eneg=c.K * Hp, lq_neg=c.K, ln=n * c.K, dlt=n, dEneg=c.K * Hp)
+        else:
+            need.update(logits=n * self.Vp, probs=n * c.V_out)
+        ws = 0
+        for m in range(128, n + 64, 64):
+            m = min(m, n)
+            use = [self._splitk(m, Hp, c.K if c.output == "sampled" else c.V_out) * m * Hp]            # dH
+            if c.output == "sampled":
+                use.append(self._splitk(c.K, Hp, m) * c.K * Hp)                                          # dEneg
+            else:
+                use.append(self._splitk(Hp, c.V_out, m) * Hp * c.V_out)                                  # dWout
+            kin = self.Dp if c.input == "embed" else (self.Fp if c.input == "dense" else 0)
+            if kin:
+                use.append(self._splitk(m, kin, GHp) * m * kin)                                          # dX
+            shapes = [(Hp, GHp), (kin, GHp), (1, GHp)]                                                   # grouped dU, dW, db
+            tiles = sum(((a + 63) // 64) * ((b + 63) // 64) for a, b in shapes if a)
+            sk = int(max(1, min(32, -(-SPLITK_TARGET_WGS // max(tiles, 1)), m // 128)))
+            use.append(sk * sum(a * b for a, b in shapes))
+            ws = max(ws, max(use))
+        need["gemm_ws"] = ws
+        for name, sz in need.items():
+            self.buf(name, int(max(sz, 1)))
+        self.buf("neg", c.K if c.output == "sampled" else 1, dtype=torch.int32)
 
     def _ones(self, n):
         t = self.ws.get("_ones")
@@ -413,7 +453,7 @@ class Engine:
         by seqrec_pack_batch / seqrec_history_features from the HBM-resident dataset."""
         from .batching import index_flat
         c = self.cfg
-        rb = index_flat(ds["starts_host"], sel)
+        rb = index_flat(ds["starts_host"], sel, lean=True)
         n, T, B = rb.n_tok, rb.T, rb.B
         sess = np.asarray(sel, dtype=np.int64)[rb.order].astype(np.int32)
         blob = torch.from_numpy(np.concatenate([rb.step_off.astype(np.int32), sess])).to(self.dev, non_blocking=True)
@@ -439,6 +479,8 @@ class Engine:
         n = d["n"]
         st = self._stream()
         out = {}
+        if c.drop_in > 0 or c.drop_out > 0 or c.drop_rec > 0:
+            rb.ensure_tokens()
         if c.drop_in > 0 or c.drop_out > 0:
             key = (rb.tok_b.astype(np.int64) << 16) + rb.tok_s.astype(np.int64)
         if n == 0:
@@ -485,6 +527,29 @@ class Engine:
         """One scatter list of this step for table `name` (see seqrec_rows_job)."""
         return dict(table=self.P[name], accum=self.A[name], gtab=self.Gt[name], slot=self.slot[name], rows=rows, vals=vals,
                     ldv=ldv, row_scale=row_scale, n=n, width=width, base=base, name=name)
+
+    def _merge_sorted(self, jobs):
+        """Deterministic merge (csrc/merge.hip): the scatter lists of each table are sorted by row (stable) and
+        summed per row in increasing contribution order -- what seqrec_rows_scatter_add_multi does with float
+        atomics, bitwise reproducible."""
+        st = self._stream()
+        by_table = {}
+        for j in jobs:
+            by_table.setdefault(j["name"], []).append(j)
+        lib = _lib.load()
+        for name, js in by_table.items():
+            total = sum(int(j["n"]) for j in js)
+            if total == 0:
+                continue
+            key = (total, int(js[0]["width"]))
+            nbytes = self._merge_ws.get(key)
+            if nbytes is None:
+                nbytes = self._merge_ws[key] = int(lib.seqrec_rows_merge_workspace_bytes(total, key[1]))
+                if nbytes <= 0:
+                    raise _lib.SeqrecError("seqrec_rows_merge_workspace_bytes failed")
+            ws = self.buf("merge_ws", (nbytes + 3) // 4)
+            arr, cnt = _lib.rows_jobs(js)
+            call("seqrec_rows_merge_sorted", arr, cnt, ptr(ws), nbytes, st)
 
     def _step_table(self, d):
         """Device step offsets for the step-wise scan.  In graph mode every batch's table is copied
@@ -737,8 +802,11 @@ class Engine:
         # ---- row-sparse contributions: one launch for (up to 4) scatter lists
         groups = [sparse_jobs[i:i + 4] for i in range(0, len(sparse_jobs), 4)]
         packed = [_lib.rows_jobs(g) for g in groups]
-        for arr, cnt in packed:
-            call("seqrec_rows_scatter_add_multi", arr, cnt, st)
+        if c.merge == "sorted":
+            self._merge_sorted(sparse_jobs)
+        else:
+            for arr, cnt in packed:
+                call("seqrec_rows_scatter_add_multi", arr, cnt, st)
         if self.priors:
             self._apply_priors(True)
         if not apply_update:
@@ -753,13 +821,20 @@ class Engine:
             nn = _lib.i64_array([Gd[k].numel() for k in dk]) if dk else None
             arr, cnt = packed[0] if packed else (None, 0)
             cur, nxt = self._sq_slots[self._sq_par], self._sq_slots[1 - self._sq_par]
-            call("seqrec_opt_sqnorm", len(dk), gp, nn, arr, cnt, ptr(cur), st)
+            if c.merge == "sorted":      # the norm without float atomics too: per-block partials added in index order
+                mx = max([j["n"] for j in sparse_jobs] + [0])
+                npart = int(_lib.load().seqrec_opt_sqnorm_ordered_floats(len(dk), cnt, mx))
+                call("seqrec_opt_sqnorm_ordered", len(dk), gp, nn, arr, cnt, ptr(self.buf("sq_partials", npart)), npart, ptr(cur), st)
+            else:
+                call("seqrec_opt_sqnorm", len(dk), gp, nn, arr, cnt, ptr(cur), st)
             call("seqrec_opt_apply", len(dk), _lib.ptr_array([P[k] for k in dk]) if dk else None,
                  _lib.ptr_array([self.A[k] for k in dk]) if dk else None, gp, nn, arr, cnt, ptr(cur), clip, lr, eps,
                  ptr(self.scale), ptr(nxt), st)
             self._sq_par ^= 1
             self.sq = cur
         else:
+            if c.merge == "sorted":
+                raise NotImplementedError("merge='sorted' covers steps with <= 4 scatter lists and <= 8 dense tensors")
             self.sq = self.sq1
             self.sq.zero_()
             if dk:

@@ -13,11 +13,11 @@ def lib():
 
 
 def make_cfg(cell="gru", act="relu", H=64, V=50, inp="onehot", out="full", D=0, K=0, tied=False,
-             use_bias=True, out_bias=False, drop_in=0.0, drop_out=0.0, drop_rec=0.0, logq=False, seed=3, scan="auto"):
+             use_bias=True, out_bias=False, drop_in=0.0, drop_out=0.0, drop_rec=0.0, logq=False, seed=3, scan="auto", merge="atomic"):
     E = importlib.import_module("seq-recommendations_amd.engine")
     ecfg = E.NetConfig(cell=cell, act=act, H=H, V_in=V, V_out=V, input=inp, D=D, output=out, K=K, tied=tied,
                        use_bias=use_bias, out_bias=out_bias, drop_in=drop_in, drop_out=drop_out, drop_rec=drop_rec, logq=logq,
-                       seed=seed, scan=scan)
+                       seed=seed, scan=scan, merge=merge)
     ocfg = dict(cell=cell, act=act, input=inp, output=out, tied=tied, use_bias=use_bias, out_bias=out_bias)
     return ecfg, ocfg
 

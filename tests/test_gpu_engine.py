@@ -21,11 +21,20 @@ CASES = [
     dict(cell="lstm", act="relu", H=128, V=2000, inp="embed", out="sampled", D=64, K=100, drop_out=0.25, drop_in=0.1),
     dict(cell="gru", act="tanh", H=64, V=1500, inp="embed", out="sampled", D=64, K=64, tied=True),
     dict(cell="simplernn", act="tanh", H=64, V=400, inp="embed", out="full", D=32),
+    # c4's model at reduced vocabulary: LSTM 512, embedding 512 (the reference's own cell, model.py:349-352), and c5's:
+    # GRU 256 with the tied input/output table
+    dict(cell="lstm", act="relu", H=512, V=3000, inp="embed", out="sampled", D=512, K=400, logq=True),
+    dict(cell="gru", act="relu", H=256, V=2500, inp="embed", out="sampled", D=256, K=300, tied=True, logq=True),
     # recurrent (z_to_z) dropout: per-gate, per-session masks fixed over time (Keras recurrent_dropout)
     dict(cell="lstm", act="relu", H=64, V=17, inp="onehot", out="full", drop_rec=0.25),
     dict(cell="lstm", act="tanh", H=100, V=33, inp="onehot", out="full", drop_rec=0.2, drop_out=0.3, drop_in=0.1),
     dict(cell="gru", act="relu", H=128, V=2000, inp="embed", out="sampled", D=64, K=100, drop_rec=0.3),
     dict(cell="simplernn", act="relu", H=64, V=17, inp="onehot", out="full", drop_rec=0.4),
+    # deterministic row-gradient merge (sort by row + ordered segment sum) instead of float atomics
+    dict(cell="gru", act="relu", H=128, V=3000, inp="embed", out="sampled", D=128, K=200, logq=True, merge="sorted"),
+    dict(cell="gru", act="tanh", H=64, V=1500, inp="embed", out="sampled", D=64, K=64, tied=True, merge="sorted"),
+    dict(cell="lstm", act="relu", H=64, V=17, inp="onehot", out="full", merge="sorted"),
+    dict(cell="gru", act="relu", H=64, V=900, inp="embed", out="sampled", D=32, K=50, out_bias=True, merge="sorted"),
     # the persistent scan stays selectable
     dict(cell="gru", act="relu", H=256, V=800, inp="embed", out="sampled", D=64, K=64, scan="persistent"),
     dict(cell="lstm", act="relu", H=128, V=17, inp="onehot", out="full", scan="persistent"),
@@ -57,6 +66,34 @@ def test_training_steps_match_oracle(case):
     diffs = pair.max_param_diff()
     med = {k: v for k, v in diffs.items()}
     assert all(np.isfinite(v) for v in med.values())
+
+
+@pytest.mark.parametrize("case", [
+    dict(cell="gru", act="relu", H=128, V=800, inp="embed", out="sampled", D=128, K=100, logq=True),
+    dict(cell="gru", act="relu", H=64, V=300, inp="embed", out="sampled", D=64, K=64, tied=True),
+    dict(cell="lstm", act="relu", H=64, V=17, inp="onehot", out="full")], ids=lambda c: c["cell"] + ("-tied" if c.get("tied") else ""))
+def test_sorted_merge_makes_two_runs_bit_identical(case):
+    """merge='sorted': two engines trained on the same seeded batches (small vocabulary: most rows collect several
+    contributions per step) end with bit-identical parameters and accumulators -- the property of the
+    reference's dense Adagrad (experiments_methods.py:41) that float atomics give up.  (That the sorted path
+    also matches the oracle is covered by the merge='sorted' rows of CASES above.)"""
+    import importlib
+    B = importlib.import_module("seq-recommendations_amd.batching")
+    runs = []
+    for rep in range(2):
+        rng = np.random.default_rng(7)
+        ecfg, ocfg = make_cfg(merge="sorted", **case)
+        pair = Pair(ecfg, ocfg, init_np_params(rng, ocfg, case["V"], case["H"], case.get("D", 0)))
+        losses = []
+        for step in range(5):
+            d = pair.eng.upload(B.pack_sessions(make_sessions(rng, 48, case["V"], 2, 14)))
+            losses.append(float(pair.eng.train_step(d, lr=0.05, step=step).item()))
+        runs.append((losses, {k: v.clone() for k, v in pair.eng.P.items()}, {k: v.clone() for k, v in pair.eng.A.items()}))
+    assert runs[0][0] == runs[1][0]
+    import torch
+    for k in runs[0][1]:
+        assert torch.equal(runs[0][1][k], runs[1][1][k]), k
+        assert torch.equal(runs[0][2][k], runs[1][2][k]), k
 
 
 def test_clip_engages_and_zero_weight_loss_is_lnV():
@@ -244,6 +281,34 @@ def test_sharded_engine_single_rank_equals_oracle():
             dist.destroy_process_group()
 
 
+def test_bench_single_gpu_line_carries_cpu_baseline_and_parity():
+    """bench.py under the DRIVER's flags (--steps 20 --warmup 5) on the small c2 shape: the JSON line must carry a
+    non-null cpu_baseline (value, cores, kind) and a parity object whose GPU-vs-CPU loss trajectory from
+    identical host-generated weights stays within the north_star bound of 1e-3 relative."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--config", "c2",
+           "--train-sessions", "8192", "--test-sessions", "1024", "--settle", "4", "--profile-steps", "2", "--recall-steps", "60",
+           "--cpu-seconds", "3", "--parity-steps", "6", "--parity-sessions", "64"]
+    r = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="8"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert "notes" not in out, out["notes"]
+    cb, par = out["cpu_baseline"], out["parity"]
+    assert cb is not None and cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port"
+    assert par is not None and par["steps"] >= 5 and len(par["loss_gpu"]) == len(par["loss_cpu"]) == par["steps"]
+    assert par["max_rel_diff"] <= 1e-3 and par["ok"] is True, par
+    assert par["recall_at_20_sample"]["identical_ranks_frac"] > 0.97
+    assert par["recall_at_20_sample_trained"]["identical_ranks_frac"] > 0.97
+    assert "fresh batches" in out["config"]["batches"] and out["roofline"] is not None
+    assert 0.0 <= out["recall_at_20"] <= 1.0
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_engine_ranks_share_one_gpu_vs_global_oracle(world):
     """2 / 4 processes share cuda:0 (collectives staged through gloo) and train the row-sharded model
@@ -259,7 +324,7 @@ def test_sharded_engine_ranks_share_one_gpu_vs_global_oracle(world):
            "127.0.0.1", "--master-port", str(29640 + world), os.path.join(here, "dist_gpu_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
-    assert r.stdout.count("case ok") == 3 and r.stdout.count("rank counts ok") == 2 and r.stdout.count("sharded topk ok") == 2
+    assert r.stdout.count("case ok") == 4 and r.stdout.count("rank counts ok") == 3 and r.stdout.count("sharded topk ok") == 3
 
 
 def test_bench_multi_rank_code_path_rehearsal():
@@ -274,8 +339,8 @@ def test_bench_multi_rank_code_path_rehearsal():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4", SEQREC_BENCH_BACKEND="gloo-staged")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29655", os.path.join(root, "bench.py"), "--gpus", "2", "--config", "c2", "--steps", "6", "--warmup", "2",
-           "--distinct-batches", "4", "--profile-steps", "2", "--recall-steps", "4", "--recall-sessions", "256", "--sharded-recall",
-           "--cpu-seconds", "0"]
+           "--train-sessions", "4096", "--test-sessions", "256", "--settle", "2", "--profile-steps", "2", "--recall-steps", "4",
+           "--sharded-recall", "--cpu-seconds", "0"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -1,4 +1,6 @@
-"""Parity at BASELINE.json's FULL c3 size (|items| = 1M, GRU 256, K = 2000, batch 512) through
+"""Parity at BASELINE.json's FULL sizes -- c3 (|items| = 1M, GRU 256, K = 2000), c4's model (|items| = 1M,
+LSTM 512, embedding 512, K = 4000: the reference's own cell, model.py:349-352) and c5 (|items| = 5M, GRU 256,
+TIED input/output table), batch 512 -- through
 size-independent properties -- the oracle cannot run 1M-row tables in test time, so these tests use
 what the domain offers: a closed-form loss for zero weights, decomposition of the masked token mean
 over sub-batches, invariance to session order and to empty sessions, the row-sparse update leaving
@@ -17,15 +19,18 @@ Bt = importlib.import_module("seq-recommendations_amd.batching")
 Sy = importlib.import_module("seq-recommendations_amd.synthetic")
 Sm = importlib.import_module("seq-recommendations_amd.sampling")
 
-V, H, K, B = 1_000_000, 256, 2000, 512
+B = 512
 
 
-@pytest.fixture(scope="module")
-def world():
+@pytest.fixture(scope="module", params=["c3", "c4", "c5"])
+def world(request):
     import bench
-    cfg = E.NetConfig(cell="gru", act="relu", H=H, V_in=V, V_out=V, input="embed", D=H, output="sampled", K=K, logq=True, seed=77)
+    cd = bench.CONFIGS[request.param]
+    V = cd["V"]
+    cfg = E.NetConfig(cell=cd["cell"], act="relu", H=cd["H"], V_in=V, V_out=V, input="embed", D=cd["D"], output="sampled",
+                      K=cd["K"], tied=bool(cd.get("tied", False)), logq=True, seed=77)
     eng = E.Engine(cfg)
-    bench.init_params_device(eng, bench.CONFIGS["c3"], seed=5)
+    bench.init_params_device(eng, cd, seed=5)
     gen = Sy.SyntheticSessions(V, seed=1234)
     probs = Sm.log_uniform_probs(V, gen.proposal_rank())
     th, al = Sm.build_alias_table(probs)
@@ -36,8 +41,13 @@ def world():
     torch.cuda.empty_cache()
 
 
+def _tname(eng):
+    return "E" if eng.cfg.tied else "Eout"
+
+
 def _negatives(eng, step):
     th, al, _ = eng.sampler
+    K, V = eng.cfg.K, eng.cfg.V_out
     neg = torch.empty(K, dtype=torch.int32, device=eng.dev)
     E.call("seqrec_sample_negatives", int(eng.cfg.seed), int(step), K, E.ptr(th), E.ptr(al), V, E.ptr(neg),
            torch.cuda.current_stream().cuda_stream)
@@ -49,8 +59,9 @@ def test_zero_output_table_loss_is_log_of_candidate_count(world):
     of token i is exactly ln(1 + #negatives that are not accidental hits of its target)."""
     eng, flat, starts = world
     import dataclasses
-    saved = eng.P["Eout"].clone()
-    eng.P["Eout"].zero_()
+    K, tn = eng.cfg.K, _tname(eng)               # tied (c5): the one table is zeroed, inputs and outputs alike
+    saved = eng.P[tn].clone()
+    eng.P[tn].zero_()
     eng.cfg = dataclasses.replace(eng.cfg, logq=False)
     try:
         rb = Bt.pack_flat(flat, starts, np.arange(B))
@@ -62,7 +73,7 @@ def test_zero_output_table_loss_is_log_of_candidate_count(world):
         ref = float(np.mean(np.log(1.0 + (K - hits))))
         assert abs(loss - ref) <= 2e-6 * ref, (loss, ref)
     finally:
-        eng.P["Eout"].copy_(saved)
+        eng.P[tn].copy_(saved)
         eng.cfg = dataclasses.replace(eng.cfg, logq=True)
 
 
@@ -85,19 +96,24 @@ def test_token_mean_decomposes_and_is_order_invariant(world):
 
 
 def test_sparse_update_leaves_untouched_rows_bit_identical(world):
-    """One full training step at c3 size: exactly the rows in ids / targets / negatives of the batch
+    """One full training step at full size: exactly the rows in ids / targets / negatives of the batch
     may change (the reference's dense Adagrad leaves a zero-gradient row untouched); all other rows of
-    both 1M-row tables, their accumulators, gradient tables and owner slots keep their checksums."""
+    the item tables (two 1M-row tables; c5: the one tied 5M-row table, hit by the input list AND both
+    output lists), their accumulators, gradient tables and owner slots keep their checksums."""
     eng, flat, starts = world
+    V = eng.cfg.V_out
     rb = Bt.pack_flat(flat, starts, np.arange(B, 2 * B))
     d = eng.upload(rb)
     neg = _negatives(eng, 21)
-    before = {k: eng.P[k].clone() for k in ("E", "Eout")}
-    acc_before = {k: eng.A[k].clone() for k in ("E", "Eout")}
+    names = ("E",) if eng.cfg.tied else ("E", "Eout")
+    before = {k: eng.P[k].clone() for k in names}
+    acc_before = {k: eng.A[k].clone() for k in names}
     loss = eng.train_step(d, lr=0.01, eps=1e-8, clipnorm=1.0, step=21, negatives=neg)
     assert np.isfinite(float(loss.item()))
-    touched = {"E": np.unique(rb.ids), "Eout": np.unique(np.concatenate([rb.tgt, neg.cpu().numpy()]))}
-    for k in ("E", "Eout"):
+    out_rows = np.concatenate([rb.tgt, neg.cpu().numpy()])
+    touched = {"E": np.unique(np.concatenate([rb.ids, out_rows])) if eng.cfg.tied else np.unique(rb.ids),
+               "Eout": np.unique(out_rows)}
+    for k in names:
         keep = torch.ones(V, dtype=torch.bool, device=eng.dev)
         keep[torch.from_numpy(touched[k]).to(eng.dev).long()] = False
         assert torch.equal(eng.P[k][keep], before[k][keep]), k
@@ -117,11 +133,13 @@ def test_rank_counts_match_torch_reference_on_a_token_sample(world):
     rk = eng.rank_counts(d)
     hd = eng.hidden_rows(d)
     idx = torch.from_numpy(np.random.default_rng(1).choice(d["n"], 64, replace=False)).to(eng.dev)
-    sc = hd[idx] @ eng.P["Eout"].T
+    sc = hd[idx] @ eng.P[_tname(eng)].T
     ts = sc[torch.arange(64, device=eng.dev), d["tgt"][idx].long()]
     ref = (sc > ts[:, None]).sum(1)
     diff = (rk[idx].long() - ref).abs()
-    assert int(diff.max().item()) <= 3 and float((diff == 0).float().mean().item()) > 0.9, diff
+    # near-ties at the threshold flip with the summation order of the two matmuls; their number grows with |items|
+    # (5M scores of magnitude 1e-4 around each threshold in c5)
+    assert int(diff.max().item()) <= 3 and float((diff == 0).float().mean().item()) > (0.8 if eng.cfg.V_out > 2_000_000 else 0.9), diff
 
 
 def test_topk_prediction_at_full_catalogue_matches_torch_topk(world):
@@ -133,7 +151,58 @@ def test_topk_prediction_at_full_catalogue_matches_torch_topk(world):
     last = np.array([int(rb.step_off[l - 1] + b) for b, l in enumerate(rb.lengths)], dtype=np.int32)
     idx, val = eng.topk_rows(d, k=20, rows=last)
     hd = eng.hidden_rows(d)[torch.from_numpy(last).to(eng.dev).long()]
-    ref_v, ref_i = torch.topk(hd @ eng.P["Eout"].T, 20, dim=1)
+    parts = [torch.topk(hd[r0:r0 + 128] @ eng.P[_tname(eng)].T, 20, dim=1) for r0 in range(0, hd.shape[0], 128)]   # < 2^31 scores per call
+    ref_v, ref_i = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
     assert idx.shape == (len(last), 20)
     assert float((idx.long() == ref_i).float().mean().item()) > 0.99            # near-ties may swap neighbours
     torch.testing.assert_close(val, ref_v, rtol=2e-5, atol=2e-6)
+
+
+def test_row_gradients_equal_a_torch_index_add_of_the_three_scatter_lists(world):
+    """The row-sparse gradient at full size against plain torch: after a step WITHOUT the update the
+    gradient table(s) must equal index_add_ of (input ids <- dX), (targets <- dlt * h) and (negatives <-
+    dEneg) -- for the tied c5 table all three lists land in ONE table and sessions make most rows both an
+    input and a target.  Also checks the token-mean loss against a torch fp32 log-softmax over the same
+    candidates, and that clearing the table afterwards restores the all-zero invariant."""
+    eng, flat, starts = world
+    c = eng.cfg
+    V, K = c.V_out, c.K
+    rb = Bt.pack_flat(flat, starts, np.arange(3 * B, 4 * B))
+    d = eng.upload(rb)
+    n = d["n"]
+    neg = _negatives(eng, 33)
+    eng.train_step(d, lr=0.01, eps=1e-8, clipnorm=1.0, step=33, negatives=neg, apply_update=False)
+    Hd, dlt = eng.buf("Hout", n, eng.Hp), eng.buf("dlt", n)
+    dX, dEneg = eng.buf("dX", n, eng.Dp), eng.buf("dEneg", K, eng.Hp)
+    ids, tgt, ng = d["ids"].long(), d["tgt"].long(), neg.long()
+    lists = {"E": [(ids, dX)], "Eout": [(tgt, dlt[:, None] * Hd), (ng, dEneg)]}
+    if c.tied:
+        lists = {"E": lists["E"] + lists["Eout"]}
+    try:
+        for name, ls in lists.items():
+            rows = torch.unique(torch.cat([r for r, _ in ls]))
+            ref = torch.zeros((V, eng.Gt[name].shape[1]), dtype=torch.float64, device=eng.dev)
+            for r, v in ls:
+                ref.index_add_(0, r, v.double())
+            got = eng.Gt[name][rows].double()
+            want = ref[rows]
+            err = float((got - want).abs().max() / want.abs().max())
+            assert err < 1e-5, (name, err)
+            mask = torch.ones(V, dtype=torch.bool, device=eng.dev)
+            mask[rows] = False
+            assert not bool((eng.Gt[name][mask] != 0).any().item())
+            del ref
+        # loss: torch log-softmax over [target | negatives minus accidental hits] with the log-Q correction
+        Et = eng.P[_tname(eng)]
+        lq = eng.sampler[2]
+        lt = (Hd * Et[tgt]).sum(1) - lq[tgt]
+        ln = Hd @ Et[ng].T - lq[ng][None, :]
+        ln = torch.where(ng[None, :] == tgt[:, None], torch.full_like(ln, float("-inf")), ln)
+        logp = lt.double() - torch.logsumexp(torch.cat([lt[:, None], ln], 1).double(), 1)
+        ref_loss = float((-torch.log(torch.exp(logp).clamp(1e-7, 1 - 1e-7))).mean().item())      # Theano CE clips p to [1e-7, 1 - 1e-7]
+        got_loss = float((eng.loss_sum / n).item())
+        assert abs(got_loss - ref_loss) <= 2e-6 * abs(ref_loss), (got_loss, ref_loss)
+    finally:
+        for name in lists:
+            eng.Gt[name].zero_()
+            eng.slot[name].fill_(E.INT32_MAX)

@@ -528,3 +528,93 @@ def test_stepwise_scan_vs_oracle_and_persistent(cell, H, B, maxlen, act, graph):
     assert np.abs(H2.cpu().numpy() - got).max() <= 2e-5 * scale
     if graph:
         assert L.load().seqrec_graph_cache_clear() == 0
+
+
+@pytest.mark.parametrize("width,V,sizes", [(256, 5000, (2603, 2000, 2603)), (1, 300, (700, 50)), (100, 64, (900,)),
+                                           (512, 2000, (4000, 4000)), (2048, 40, (300, 17)), (64, 7, (5000, 3, 129))])
+def test_sorted_merge_is_bitwise_reproducible_and_equals_the_atomic_scatter(width, V, sizes):
+    """csrc/merge.hip (deterministic row-gradient merge) against numpy float64 sums and against the
+    float-atomic scatter: same gradient table to rounding, same owner slots exactly, and two invocations on
+    the same inputs agree bit for bit.  Rows are Zipf-skewed so that single rows collect hundreds of
+    contributions (runs longer than one 64-position tile and longer than two: the partial chain), V = 7 puts
+    thousands on one row; -1 rows are fillers; one list carries a per-contribution scale."""
+    rng = np.random.default_rng(width + V)
+    jobs, base = [], 0
+    ref = np.zeros((V, width), np.float64)
+    first = np.full(V, 2 ** 31 - 1, np.int64)
+    for li, n in enumerate(sizes):
+        rows = np.minimum(rng.zipf(1.3, size=n) - 1, V - 1).astype(np.int32)
+        rows[rng.random(n) < 0.02] = -1
+        ld = width + (4 if li == 1 else 0)                        # a strided value matrix
+        vals = rng.normal(size=(n, ld)).astype(np.float32)
+        scale = rng.normal(size=n).astype(np.float32) if li == 0 else None
+        for i in np.nonzero(rows >= 0)[0]:
+            ref[rows[i]] += vals[i, :width].astype(np.float64) * (1.0 if scale is None else float(scale[i]))
+            first[rows[i]] = min(first[rows[i]], base + i)
+        jobs.append(dict(rows=dev(rows), vals=dev(vals), ldv=ld, row_scale=None if scale is None else dev(scale), n=n,
+                         width=width, base=base))
+        base += n
+    total = base
+    nbytes = int(L.load().seqrec_rows_merge_workspace_bytes(total, width))
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    outs = []
+    for rep in range(2):
+        gt = torch.zeros((V, width), device="cuda")
+        sl = torch.full((V,), 2 ** 31 - 1, dtype=torch.int32, device="cuda")
+        js = [dict(j, table=None, accum=None, gtab=gt, slot=sl) for j in jobs[::-1]]      # any order: sorted by base inside
+        arr, cnt = L.rows_jobs(js)
+        ws.fill_(0xA5 if rep else 0)                                                     # stale workspace contents must not matter
+        call("seqrec_rows_merge_sorted", arr, cnt, ptr(ws), nbytes, st())
+        outs.append((gt.cpu().numpy(), sl.cpu().numpy()))
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    np.testing.assert_array_equal(outs[0][1].astype(np.int64), first)
+    scale_ = max(1.0, np.abs(ref).max())
+    assert np.abs(outs[0][0] - ref).max() <= 2e-5 * scale_
+    # the atomic path on the same lists
+    gt = torch.zeros((V, width), device="cuda")
+    sl = torch.full((V,), 2 ** 31 - 1, dtype=torch.int32, device="cuda")
+    arr, cnt = L.rows_jobs([dict(j, table=None, accum=None, gtab=gt, slot=sl) for j in jobs])
+    call("seqrec_rows_scatter_add_multi", arr, cnt, st())
+    np.testing.assert_array_equal(sl.cpu().numpy(), outs[0][1])
+    assert np.abs(gt.cpu().numpy() - ref).max() <= 2e-5 * scale_
+    # bad arguments: overlapping index ranges, mixed tables
+    bad = [dict(j, table=None, accum=None, gtab=gt, slot=sl) for j in jobs]
+    if len(bad) > 1:
+        bad[1] = dict(bad[1], base=bad[0]["base"])
+        arr, cnt = L.rows_jobs(bad)
+        with pytest.raises(L.SeqrecError):
+            call("seqrec_rows_merge_sorted", arr, cnt, ptr(ws), nbytes, st())
+    arr, cnt = L.rows_jobs([dict(jobs[0], table=None, accum=None, gtab=gt, slot=sl)])
+    with pytest.raises(L.SeqrecError):
+        call("seqrec_rows_merge_sorted", arr, cnt, ptr(ws), 16, st())                    # workspace too small
+
+
+def test_ordered_norm_equals_the_atomic_norm_and_is_reproducible():
+    rng = np.random.default_rng(5)
+    V, W = 3000, 256
+    rows = np.minimum(rng.zipf(1.2, size=4000) - 1, V - 1).astype(np.int32)
+    vals = rng.normal(size=(4000, W)).astype(np.float32)
+    gt = torch.zeros((V, W), device="cuda")
+    sl = torch.full((V,), 2 ** 31 - 1, dtype=torch.int32, device="cuda")
+    job = dict(table=None, accum=None, gtab=gt, slot=sl, rows=dev(rows), vals=dev(vals), ldv=W, row_scale=None, n=4000, width=W, base=0)
+    arr, cnt = L.rows_jobs([job])
+    call("seqrec_rows_scatter_add_multi", arr, cnt, st())
+    dense = [dev(rng.normal(size=s).astype(np.float32)) for s in ((256, 768), (768,), (3,))]
+    gp = L.ptr_array(dense)
+    nn = L.i64_array([t.numel() for t in dense])
+    ref = float(sum((t.double() ** 2).sum().item() for t in dense) + (gt.double() ** 2).sum().item())
+    npart = int(L.load().seqrec_opt_sqnorm_ordered_floats(3, 1, 4000))
+    part = torch.empty(npart, device="cuda")
+    got = []
+    for rep in range(2):
+        sq = torch.full((1,), float("nan"), device="cuda")
+        part.fill_(float(rep))
+        call("seqrec_opt_sqnorm_ordered", 3, gp, nn, arr, cnt, ptr(part), npart, ptr(sq), st())
+        got.append(sq.cpu().numpy().copy())
+    np.testing.assert_array_equal(got[0], got[1])
+    assert abs(float(got[0][0]) - ref) <= 1e-5 * ref
+    sq = torch.zeros(1, device="cuda")
+    call("seqrec_opt_sqnorm", 3, gp, nn, arr, cnt, ptr(sq), st())
+    assert abs(float(sq.item()) - ref) <= 1e-5 * ref
