@@ -74,7 +74,7 @@ def parse(argv=None):
     ap.add_argument("--resident", action="store_true",
                     help="round-1 measurement: cycle <= --distinct-batches pre-built batches instead of fresh ones")
     ap.add_argument("--distinct-batches", type=int, default=64)
-    ap.add_argument("--settle", type=int, default=32, help="untimed steps before --warmup (see DESIGN.md 5)")
+    ap.add_argument("--settle", type=int, default=8, help="untimed steps before --warmup (see DESIGN.md 5)")
     ap.add_argument("--profile-steps", type=int, default=10)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--parity-steps", type=int, default=8, help="steps whose loss is compared GPU vs CPU (>= 5)")
@@ -466,6 +466,13 @@ def main(argv=None):
             notes.append("parity leg (GPU side) failed: %r" % (e,))
 
     # ---- settle (untimed; DESIGN.md 5 says what it covers), warm-up, timed region
+    # Python's cyclic GC: the first full (generation-2) collection of a fresh process walks every object torch
+    # and numpy created at import -- 40 ms in ONE training step somewhere in the first ~60 (measured with
+    # gc.callbacks, tools/stall_probe.py; round 1 papered over it with 128 settle steps).  Collect once now
+    # and freeze the survivors out of later collections, as a long-running trainer would after start-up.
+    import gc
+    gc.collect()
+    gc.freeze()
     for i in range(a.settle):
         train(step)
         step += 1

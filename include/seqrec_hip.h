@@ -236,11 +236,12 @@ int seqrec_adagrad_dense_multi(int count, float* const* p, float* const* a, cons
 int seqrec_opt_sqnorm(int n_dense, const float* const* grads, const int64_t* numel,
                       const seqrec_rows_job* jobs_host, int n_jobs, float* sq_accum, void* stream);
 /*      deterministic form of the norm (no float atomics): per-block partial sums into `partials`
- *      (seqrec_opt_sqnorm_ordered_floats() floats), added in index order by one block; *sq_out is overwritten */
+ *      (seqrec_opt_sqnorm_ordered_floats() floats), added in index order by one block; *sq_out is overwritten
+ *      (accumulate == 0) or added to (calls on one stream add in call order) */
 int64_t seqrec_opt_sqnorm_ordered_floats(int n_dense, int n_jobs, int64_t max_job_rows);
 int seqrec_opt_sqnorm_ordered(int n_dense, const float* const* grads, const int64_t* numel,
                               const seqrec_rows_job* jobs_host, int n_jobs, float* partials,
-                              int64_t partials_floats, float* sq_out, void* stream);
+                              int64_t partials_floats, float* sq_out, int accumulate, void* stream);
 int seqrec_opt_apply(int n_dense, float* const* params, float* const* accums, const float* const* grads,
                      const int64_t* numel, const seqrec_rows_job* jobs_host, int n_jobs, const float* sq,
                      float clipnorm, float lr, float eps, float* scale_out, float* zero_next, void* stream);

@@ -70,7 +70,7 @@ _SIGS = {
     "seqrec_rows_merge_workspace_bytes": [L, I],
     "seqrec_rows_merge_sorted": [P, I, P, L, P],
     "seqrec_opt_sqnorm_ordered_floats": [I, I, L],
-    "seqrec_opt_sqnorm_ordered": [I, P, P, P, I, P, L, P, P],
+    "seqrec_opt_sqnorm_ordered": [I, P, P, P, I, P, L, P, I, P],
     "seqrec_rows_sqnorm_multi": [P, I, P, P],
     "seqrec_rows_adagrad_multi": [P, I, F, F, P, P],
     "seqrec_sqnorm_multi": [I, P, P, P, P],

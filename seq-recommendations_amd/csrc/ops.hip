@@ -1129,7 +1129,7 @@ extern "C" int64_t seqrec_opt_sqnorm_ordered_floats(int n_dense, int n_jobs, int
 }
 extern "C" int seqrec_opt_sqnorm_ordered(int n_dense, const float* const* grads, const int64_t* numel,
                                          const seqrec_rows_job* jobs_host, int n_jobs, float* partials,
-                                         int64_t partials_floats, float* sq_out, void* stream) {
+                                         int64_t partials_floats, float* sq_out, int accumulate, void* stream) {
     OptPlan pl;
     long maxn;
     const int rc = fill_opt_plan(n_dense, nullptr, nullptr, grads, numel, jobs_host, n_jobs, false, pl, maxn);
@@ -1141,7 +1141,7 @@ extern "C" int seqrec_opt_sqnorm_ordered(int n_dense, const float* const* grads,
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(opt_sqnorm_partial_kernel, dim3(gx, n_dense + n_jobs), dim3(256), 0, st, pl, partials);
     SEQREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, st, partials, np, sq_out, 0);
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, st, partials, np, sq_out, accumulate);
     SEQREC_LAUNCH_CHECK();
     return 0;
 }

@@ -824,7 +824,7 @@ class Engine:
             if c.merge == "sorted":      # the norm without float atomics too: per-block partials added in index order
                 mx = max([j["n"] for j in sparse_jobs] + [0])
                 npart = int(_lib.load().seqrec_opt_sqnorm_ordered_floats(len(dk), cnt, mx))
-                call("seqrec_opt_sqnorm_ordered", len(dk), gp, nn, arr, cnt, ptr(self.buf("sq_partials", npart)), npart, ptr(cur), st)
+                call("seqrec_opt_sqnorm_ordered", len(dk), gp, nn, arr, cnt, ptr(self.buf("sq_partials", npart)), npart, ptr(cur), 0, st)
             else:
                 call("seqrec_opt_sqnorm", len(dk), gp, nn, arr, cnt, ptr(cur), st)
             call("seqrec_opt_apply", len(dk), _lib.ptr_array([P[k] for k in dk]) if dk else None,
@@ -833,16 +833,27 @@ class Engine:
             self._sq_par ^= 1
             self.sq = cur
         else:
-            if c.merge == "sorted":
-                raise NotImplementedError("merge='sorted' covers steps with <= 4 scatter lists and <= 8 dense tensors")
             self.sq = self.sq1
             self.sq.zero_()
             if dk:
                 gp = _lib.ptr_array([Gd[k] for k in dk])
                 nn = _lib.i64_array([Gd[k].numel() for k in dk])
-                call("seqrec_sqnorm_multi", len(dk), gp, nn, ptr(self.sq), st)
-            for arr, cnt in packed:
-                call("seqrec_rows_sqnorm_multi", arr, cnt, ptr(self.sq), st)
+            if c.merge == "sorted":      # ordered partial sums, added call by call (stream order): no float atomics
+                if len(dk) > 8:
+                    raise NotImplementedError("merge='sorted' covers steps with <= 8 dense tensors")
+                mx = max([j["n"] for j in sparse_jobs] + [0])
+                lib = _lib.load()
+                npart = int(max(lib.seqrec_opt_sqnorm_ordered_floats(len(dk), 0, 0), lib.seqrec_opt_sqnorm_ordered_floats(0, 4, mx)))
+                pbuf = self.buf("sq_partials", npart)
+                if dk:
+                    call("seqrec_opt_sqnorm_ordered", len(dk), gp, nn, None, 0, ptr(pbuf), npart, ptr(self.sq), 1, st)
+                for arr, cnt in packed:
+                    call("seqrec_opt_sqnorm_ordered", 0, None, None, arr, cnt, ptr(pbuf), npart, ptr(self.sq), 1, st)
+            else:
+                if dk:
+                    call("seqrec_sqnorm_multi", len(dk), gp, nn, ptr(self.sq), st)
+                for arr, cnt in packed:
+                    call("seqrec_rows_sqnorm_multi", arr, cnt, ptr(self.sq), st)
             call("seqrec_clip_scale", ptr(self.sq), clip, ptr(self.scale), st)
             if dk:
                 call("seqrec_adagrad_dense_multi", len(dk), _lib.ptr_array([P[k] for k in dk]),

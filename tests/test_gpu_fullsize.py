@@ -151,8 +151,17 @@ def test_topk_prediction_at_full_catalogue_matches_torch_topk(world):
     last = np.array([int(rb.step_off[l - 1] + b) for b, l in enumerate(rb.lengths)], dtype=np.int32)
     idx, val = eng.topk_rows(d, k=20, rows=last)
     hd = eng.hidden_rows(d)[torch.from_numpy(last).to(eng.dev).long()]
-    parts = [torch.topk(hd[r0:r0 + 128] @ eng.P[_tname(eng)].T, 20, dim=1) for r0 in range(0, hd.shape[0], 128)]   # < 2^31 scores per call
-    ref_v, ref_i = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+    # reference by item chunks of 500k (torch's own 512 x 5M product came back with all-zero rows on this stack):
+    # top-20 of every chunk, then top-20 of the candidates
+    Et = eng.P[_tname(eng)]
+    cv, ci = [], []
+    for c0 in range(0, Et.shape[0], 500_000):
+        v, i = torch.topk(hd @ Et[c0:c0 + 500_000].T, 20, dim=1)
+        cv.append(v)
+        ci.append(i + c0)
+    cv, ci = torch.cat(cv, 1), torch.cat(ci, 1)
+    ref_v, pos = torch.topk(cv, 20, dim=1)
+    ref_i = torch.gather(ci, 1, pos)
     assert idx.shape == (len(last), 20)
     assert float((idx.long() == ref_i).float().mean().item()) > 0.99            # near-ties may swap neighbours
     torch.testing.assert_close(val, ref_v, rtol=2e-5, atol=2e-6)

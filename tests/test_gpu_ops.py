@@ -611,7 +611,7 @@ def test_ordered_norm_equals_the_atomic_norm_and_is_reproducible():
     for rep in range(2):
         sq = torch.full((1,), float("nan"), device="cuda")
         part.fill_(float(rep))
-        call("seqrec_opt_sqnorm_ordered", 3, gp, nn, arr, cnt, ptr(part), npart, ptr(sq), st())
+        call("seqrec_opt_sqnorm_ordered", 3, gp, nn, arr, cnt, ptr(part), npart, ptr(sq), 0, st())
         got.append(sq.cpu().numpy().copy())
     np.testing.assert_array_equal(got[0], got[1])
     assert abs(float(got[0][0]) - ref) <= 1e-5 * ref

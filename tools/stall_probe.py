@@ -27,6 +27,16 @@ if not (len(sys.argv) > 2 and sys.argv[2] == "noreserve"):
     eng.reserve(512 * 49)
 stream = bench.BatchStream(0, 40_000, 512, 1)
 torch.cuda.synchronize()
+import gc
+_gc = {"t0": 0.0, "log": []}
+def _cb(phase, info):
+    if phase == "start":
+        _gc["t0"] = time.perf_counter()
+    else:
+        _gc["log"].append((info["generation"], (time.perf_counter() - _gc["t0"]) * 1e3, info["collected"]))
+gc.callbacks.append(_cb)
+if "freeze" in sys.argv[2:]:
+    gc.collect(); gc.freeze()
 step = 0
 print("block  wall_ms/step  host_ms/step  reserved_MB  segments  max_step_host_ms")
 for blk in range(blocks):
@@ -40,4 +50,6 @@ for blk in range(blocks):
     torch.cuda.synchronize()
     ms = torch.cuda.memory_stats()
     print("%5d  %12.3f  %12.3f  %11.1f  %8d  %16.3f" % (blk, (time.perf_counter() - t0) / 10 * 1e3, host / 10 * 1e3,
-          ms["reserved_bytes.all.current"] / 2**20, ms["segment.all.current"], worst * 1e3), flush=True)
+          ms["reserved_bytes.all.current"] / 2**20, ms["segment.all.current"], worst * 1e3),
+          " gc(gen, ms):", [(g, round(t, 2)) for g, t, _ in _gc["log"] if t > 0.5], flush=True)
+    _gc["log"].clear()
