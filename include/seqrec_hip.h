@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SEQREC_ABI_VERSION 1
+#define SEQREC_ABI_VERSION 2
 
 enum { SEQREC_OK = 0, SEQREC_E_ARG = -1, SEQREC_E_SHAPE = -2, SEQREC_E_UNSUPPORTED = -3 };
 
@@ -66,6 +66,22 @@ int seqrec_gemm_f32(int a_kcontig, int b_kcontig, int64_t M, int64_t N, int64_t 
                     float* C, int64_t ldc, const float* bias, int accumulate,
                     int splitk, float* workspace, void* stream);
 int64_t seqrec_gemm_workspace_floats(int64_t M, int64_t N, int splitk);
+/*      the same GEMM with the gathers of the hot path fused in (no materialised copy, no extra launch):
+ *      a_index  : the A operand is read THROUGH an index -- a_kcontig: row m of A is A[a_index[m]*lda + k]
+ *                 (x.W with x = E[ids]: the embedding lookup of model.py:248-255 inside the cell GEMM);
+ *                 !a_kcontig: slice k of A is A[a_index[k]*lda + m] (dU = Hout[prev]^T . dPre).  A negative
+ *                 index is an all-zero row.  M (or K) counts index entries; 64x64 tiles are used.
+ *      add_*    : C[m,:] += add_scale[m] * add_table[add_index[m]*add_ld + :] where the final C is written
+ *                 (dH = dlogits . Eneg + dlt * Eout[tgt]); add_scale NULL = 1, add_index < 0 adds nothing.
+ *      fuse == NULL is seqrec_gemm_f32. */
+typedef struct seqrec_gemm_fuse {
+    const int32_t* a_index;
+    const float* add_table; const int32_t* add_index; const float* add_scale; int64_t add_ld;
+} seqrec_gemm_fuse;
+int seqrec_gemm_f32_fused(int a_kcontig, int b_kcontig, int64_t M, int64_t N, int64_t K,
+                          const float* A, int64_t lda, const float* B, int64_t ldb,
+                          float* C, int64_t ldc, const float* bias, int accumulate,
+                          int splitk, float* workspace, const seqrec_gemm_fuse* fuse_host, void* stream);
 /*      grouped form: up to 4 independent problems that share the layout flags, K and the split count
  *      in ONE launch (the weight-gradient GEMMs dW / dU all reduce over K = N_tok).
  *      workspace (splitk > 1): sum_i splitk * M_i * N_i floats. */
@@ -75,6 +91,7 @@ typedef struct seqrec_gemm_desc {
     const float* B; int64_t ldb;
     float* C; int64_t ldc;
     const float* bias; int32_t accumulate;
+    const int32_t* a_index;           /* nullable: gathered A operand, as in seqrec_gemm_fuse */
 } seqrec_gemm_desc;
 int seqrec_gemm_f32_grouped(int count, int a_kcontig, int b_kcontig, const seqrec_gemm_desc* descs_host,
                             int splitk, float* workspace, void* stream);
@@ -234,14 +251,20 @@ int seqrec_adagrad_dense_multi(int count, float* const* p, float* const* a, cons
  *      zero_next != NULL, stores 0 to *zero_next -- callers alternate two norm slots so that no step needs
  *      a separate clearing launch. */
 int seqrec_opt_sqnorm(int n_dense, const float* const* grads, const int64_t* numel,
-                      const seqrec_rows_job* jobs_host, int n_jobs, float* sq_accum, void* stream);
+                      const seqrec_rows_job* jobs_host, int n_jobs, float* sq_accum,
+                      const float* loss_rows, int64_t n_loss, float* loss_out, void* stream);
+/*      loss_out (nullable, 2 floats): the same launch also reduces the per-token losses of the CE kernels with one
+ *      spare workgroup in a fixed order -- loss_out[0] = sum, loss_out[1] = sum / n_loss (the Keras token mean): no
+ *      separate reduction launch in a training step.  seqrec_loss_reduce is that reduction on its own (evaluation). */
+int seqrec_loss_reduce(const float* loss_rows, int64_t n, float* loss_out, void* stream);
 /*      deterministic form of the norm (no float atomics): per-block partial sums into `partials`
  *      (seqrec_opt_sqnorm_ordered_floats() floats), added in index order by one block; *sq_out is overwritten
  *      (accumulate == 0) or added to (calls on one stream add in call order) */
 int64_t seqrec_opt_sqnorm_ordered_floats(int n_dense, int n_jobs, int64_t max_job_rows);
 int seqrec_opt_sqnorm_ordered(int n_dense, const float* const* grads, const int64_t* numel,
                               const seqrec_rows_job* jobs_host, int n_jobs, float* partials,
-                              int64_t partials_floats, float* sq_out, int accumulate, void* stream);
+                              int64_t partials_floats, float* sq_out, int accumulate,
+                              const float* loss_rows, int64_t n_loss, float* loss_out, void* stream);
 int seqrec_opt_apply(int n_dense, float* const* params, float* const* accums, const float* const* grads,
                      const int64_t* numel, const seqrec_rows_job* jobs_host, int n_jobs, const float* sq,
                      float clipnorm, float lr, float eps, float* scale_out, float* zero_next, void* stream);

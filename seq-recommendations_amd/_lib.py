@@ -37,6 +37,7 @@ _SIGS = {
     "seqrec_build_arch": [],
     "seqrec_gather_rows": [P, P, P, L, I, P, P, I, P],
     "seqrec_gemm_f32": [I, I, L, L, L, P, L, P, L, P, L, P, I, I, P, P],
+    "seqrec_gemm_f32_fused": [I, I, L, L, L, P, L, P, L, P, L, P, I, I, P, P, P],
     "seqrec_gemm_workspace_floats": [L, L, I],
     "seqrec_gemm_f32_grouped": [I, I, I, P, I, P, P],
     "seqrec_rnn_upack_floats": [I, I],
@@ -57,7 +58,8 @@ _SIGS = {
     "seqrec_fill_i32": [P, I, L, P],
     "seqrec_topk_merge": [P, L, L, I, I, P, P, P, P],
     "seqrec_topk_finish": [P, P, L, I, P, P, P],
-    "seqrec_opt_sqnorm": [I, P, P, P, I, P, P],
+    "seqrec_opt_sqnorm": [I, P, P, P, I, P, P, L, P, P],
+    "seqrec_loss_reduce": [P, L, P, P],
     "seqrec_opt_apply": [I, P, P, P, P, P, I, P, F, F, F, P, P, P],
     "seqrec_prior_grad": [P, P, L, C.c_float, P, P, P],
     "seqrec_pack_batch": [P, P, P, P, I, I, P, P, P, P],
@@ -70,7 +72,7 @@ _SIGS = {
     "seqrec_rows_merge_workspace_bytes": [L, I],
     "seqrec_rows_merge_sorted": [P, I, P, L, P],
     "seqrec_opt_sqnorm_ordered_floats": [I, I, L],
-    "seqrec_opt_sqnorm_ordered": [I, P, P, P, I, P, L, P, I, P],
+    "seqrec_opt_sqnorm_ordered": [I, P, P, P, I, P, L, P, I, P, L, P, P],
     "seqrec_rows_sqnorm_multi": [P, I, P, P],
     "seqrec_rows_adagrad_multi": [P, I, F, F, P, P],
     "seqrec_sqnorm_multi": [I, P, P, P, P],
@@ -116,17 +118,34 @@ def rows_jobs(jobs):
 class GemmDesc(C.Structure):
     """seqrec_gemm_desc (include/seqrec_hip.h)."""
     _fields_ = [("M", L), ("N", L), ("K", L), ("A", P), ("lda", L), ("B", P), ("ldb", L), ("C", P), ("ldc", L),
-                ("bias", P), ("accumulate", C.c_int32)]
+                ("bias", P), ("accumulate", C.c_int32), ("a_index", P)]
 
 
 def gemm_descs(items):
-    """items: list of (M, N, K, A, lda, B, ldb, C, ldc) with torch tensors -> ctypes array."""
+    """items: list of (M, N, K, A, lda, B, ldb, C, ldc[, a_index]) with torch tensors -> ctypes array."""
     arr = (GemmDesc * len(items))()
-    for i, (M, N, K, A, lda, B, ldb, Cm, ldc) in enumerate(items):
+    for i, it in enumerate(items):
+        M, N, K, A, lda, B, ldb, Cm, ldc = it[:9]
         arr[i].M, arr[i].N, arr[i].K = int(M), int(N), int(K)
         arr[i].A, arr[i].lda, arr[i].B, arr[i].ldb = A.data_ptr(), int(lda), B.data_ptr(), int(ldb)
         arr[i].C, arr[i].ldc, arr[i].bias, arr[i].accumulate = Cm.data_ptr(), int(ldc), None, 0
+        arr[i].a_index = it[9].data_ptr() if len(it) > 9 and it[9] is not None else None
     return arr
+
+
+class GemmFuse(C.Structure):
+    """seqrec_gemm_fuse (include/seqrec_hip.h)."""
+    _fields_ = [("a_index", P), ("add_table", P), ("add_index", P), ("add_scale", P), ("add_ld", L)]
+
+
+def gemm_fuse(a_index=None, add_table=None, add_index=None, add_scale=None, add_ld=0):
+    f = GemmFuse()
+    f.a_index = None if a_index is None else a_index.data_ptr()
+    f.add_table = None if add_table is None else add_table.data_ptr()
+    f.add_index = None if add_index is None else add_index.data_ptr()
+    f.add_scale = None if add_scale is None else add_scale.data_ptr()
+    f.add_ld = int(add_ld)
+    return f
 
 
 def ptr_array(tensors):

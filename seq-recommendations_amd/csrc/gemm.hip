@@ -24,7 +24,19 @@ struct GemmArgs {
     // epilogue 1 (Recall@K): rank[row] += #{col != tgt[row] : acc + bias[col] > thr[row]}
     int epi;
     const int* tgt; const float* thr; int* rank;
+    // fused gather of the A operand (AIDX kernels): A_KC  -> row m of A is A[a_idx[m] * lda + k]  (x.W with x = E[ids])
+    //                                               !A_KC -> slice k of A is A[a_idx[k] * lda + m] (Hout[prev]^T . dPre)
+    // a negative index is an all-zero row
+    const int* a_idx;
+    // fused row add where the final C is written: C[m, :] += add_scale[m] * add_table[add_idx[m] * add_ld + :]
+    // (dH += dlt * Eout[tgt]); add_idx < 0 adds nothing
+    const float* add_table; const int* add_idx; const float* add_scale; long add_ld;
 };
+__device__ __forceinline__ float row_add(const GemmArgs& g, long row, long col) {
+    if (!g.add_table) return 0.f;
+    const int id = g.add_idx[row];
+    return id < 0 ? 0.f : (g.add_scale ? g.add_scale[row] : 1.f) * g.add_table[(long)id * g.add_ld + col];
+}
 
 constexpr int BK = 16;          // K granule of split-K bookkeeping; kernels use BKT = 16 or 32
 
@@ -93,7 +105,19 @@ __device__ __forceinline__ void store_tile4(float* __restrict__ S, int idx, floa
     }
 }
 
-template <int BM, int BN, int BKT, bool A_KC, bool B_KC>
+// 4 floats of one (possibly gathered) A row / slice starting at p; zeros for a null row
+__device__ __forceinline__ float4 load_row4(const float* __restrict__ p, long c0, long cend, bool vec_ok) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!p) return v;
+    if (vec_ok && c0 + 3 < cend) return *reinterpret_cast<const float4*>(p + c0);
+    if (c0 + 0 < cend) v.x = p[c0 + 0];
+    if (c0 + 1 < cend) v.y = p[c0 + 1];
+    if (c0 + 2 < cend) v.z = p[c0 + 2];
+    if (c0 + 3 < cend) v.w = p[c0 + 3];
+    return v;
+}
+
+template <int BM, int BN, int BKT, bool A_KC, bool B_KC, bool AIDX = false>
 __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int tile, const int zsplit, const int nsplits) {
     constexpr int LDA = BM + 2, LDB = BN + 2;
     constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 MFMA tiles per wave
@@ -122,12 +146,44 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int tile
     auto main_loop = [&](auto fast_tag) {
         constexpr bool FAST = decltype(fast_tag)::value;
         float4 ra[NA], rb[NB];
+        // AIDX: gathered A.  A_KC: the thread's rows are fixed over K -> resolve their base pointers once.
+        // !A_KC: the index runs along K -> the ids of tile kt+1 are fetched while tile kt loads (one tile ahead
+        // of the data they address, so the id -> data chain never sits in front of the MFMAs).
+        const float* arow[NA];
+        int kid[NA];
+        if (AIDX) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int idx = tid + 256 * i;
+                if (A_KC) {
+                    const long gr = m0 + idx / (BKT / 4);
+                    const int id = gr < g.M ? g.a_idx[gr] : -1;
+                    arow[i] = id >= 0 ? g.A + (long)id * g.lda : nullptr;
+                } else {
+                    const long gk = kbeg + idx / (BM / 4);
+                    kid[i] = gk < kend ? g.a_idx[gk] : -1;
+                }
+            }
+        }
         auto gload = [&](int kt) {
             const long k0 = kbeg + (long)kt * BKT;
 #pragma unroll
-            for (int i = 0; i < NA; ++i)
-                ra[i] = FAST ? load_tile4_fast<BM, BKT, A_KC>(g.A, g.lda, m0, k0, tid + 256 * i)
-                             : load_tile4<BM, BKT, A_KC>(g.A, g.lda, m0, k0, g.M, kend, tid + 256 * i, g.a_vec);
+            for (int i = 0; i < NA; ++i) {
+                if (AIDX) {
+                    const int idx = tid + 256 * i;
+                    if (A_KC) {
+                        ra[i] = load_row4(arow[i], k0 + 4 * (idx % (BKT / 4)), kend, g.a_vec);
+                    } else {
+                        const float* p = kid[i] >= 0 ? g.A + (long)kid[i] * g.lda : nullptr;
+                        ra[i] = load_row4(p, m0 + 4 * (idx % (BM / 4)), g.M, g.a_vec);
+                        const long gk = k0 + BKT + idx / (BM / 4);
+                        kid[i] = gk < kend ? g.a_idx[gk] : -1;
+                    }
+                } else {
+                    ra[i] = FAST ? load_tile4_fast<BM, BKT, A_KC>(g.A, g.lda, m0, k0, tid + 256 * i)
+                                 : load_tile4<BM, BKT, A_KC>(g.A, g.lda, m0, k0, g.M, kend, tid + 256 * i, g.a_vec);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < NB; ++i)
                 rb[i] = FAST ? load_tile4_fast<BN, BKT, B_KC>(g.B, g.ldb, n0, k0, tid + 256 * i)
@@ -213,19 +269,22 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int tile
                 if (row < g.M) {
                     float* c = Cb + row * g.ldc + col;
                     float v = acc[i][j][r] + bv;
-                    if (!splits && g.accumulate) v += *c;
+                    if (!splits) {
+                        v += row_add(g, row, col);
+                        if (g.accumulate) v += *c;
+                    }
                     *c = v;
                 }
             }
         }
 }
 
-template <int BM, int BN, int BKT, bool A_KC, bool B_KC>
+template <int BM, int BN, int BKT, bool A_KC, bool B_KC, bool AIDX = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #ifdef SEQREC_PROBE_XCD_SKIP       // timing probe only (tools/overlap_probe.py): workgroups dealt to the first N XCDs do nothing
     if ((int)(blockIdx.x & 7) < SEQREC_PROBE_XCD_SKIP) return;
 #endif
-    gemm_tile_body<BM, BN, BKT, A_KC, B_KC>(g, blockIdx.x, blockIdx.z, gridDim.z);
+    gemm_tile_body<BM, BN, BKT, A_KC, B_KC, AIDX>(g, blockIdx.x, blockIdx.z, gridDim.z);
 }
 
 // grouped launch: blockIdx.y picks one of up to 4 independent problems of the same layout
@@ -234,7 +293,8 @@ template <int BM, int BN, int BKT, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(GemmGroup gg) {
     const int p = blockIdx.y;
     if ((int)blockIdx.x >= gg.ntiles[p]) return;
-    gemm_tile_body<BM, BN, BKT, A_KC, B_KC>(gg.g[p], blockIdx.x, blockIdx.z, gridDim.z);
+    if (gg.g[p].a_idx) gemm_tile_body<BM, BN, BKT, A_KC, B_KC, true>(gg.g[p], blockIdx.x, blockIdx.z, gridDim.z);
+    else gemm_tile_body<BM, BN, BKT, A_KC, B_KC, false>(gg.g[p], blockIdx.x, blockIdx.z, gridDim.z);
 }
 
 struct ReduceGroup { const float* ws[4]; float* C[4]; const float* bias[4]; long M[4], N[4], ldc[4]; int accumulate[4]; };
@@ -254,13 +314,14 @@ __global__ void splitk_reduce_grouped_kernel(ReduceGroup r, int splits) {
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long M, long N,
                                      float* __restrict__ C, long ldc, const float* __restrict__ bias,
-                                     int accumulate) {
+                                     int accumulate, GemmArgs g) {
     const long total = M * N;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int z = 0; z < splits; ++z) s += ws[(long)z * total + i];   // fixed order: deterministic
         const long r = i / N, c = i % N;
         if (bias) s += bias[c];
+        s += row_add(g, r, c);
         float* o = C + r * ldc + c;
         if (accumulate) s += *o;
         *o = s;
@@ -272,6 +333,18 @@ int launch_gemm_bk(int a_kc, int b_kc, GemmArgs& g, int splits, hipStream_t st) 
     const long tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
     g.tiles_n = (int)tiles_n;
     dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)splits), block(256);
+    if (g.a_idx) {                // gathered A operand: 64x64 tiles only (the caller picks them)
+        if constexpr (BM == 64 && BN == 64 && BKT == 16) {
+            if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 16, true, true, true>), grid, block, 0, st, g);
+            else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 16, true, false, true>), grid, block, 0, st, g);
+            else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 16, false, true, true>), grid, block, 0, st, g);
+            else hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 16, false, false, true>), grid, block, 0, st, g);
+            SEQREC_LAUNCH_CHECK();
+            return 0;
+        } else {
+            return SEQREC_E_UNSUPPORTED;
+        }
+    }
     if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BKT, true, true>), grid, block, 0, st, g);
     else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BKT, true, false>), grid, block, 0, st, g);
     else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BKT, false, true>), grid, block, 0, st, g);
@@ -284,7 +357,7 @@ int launch_gemm_bk(int a_kc, int b_kc, GemmArgs& g, int splits, hipStream_t st) 
 template <int BM, int BN>
 int launch_gemm(int a_kc, int b_kc, GemmArgs& g, int splits, hipStream_t st) {
     static const bool bk32 = getenv("SEQREC_GEMM_BK32") && atoi(getenv("SEQREC_GEMM_BK32")) != 0;   // tuning switch
-    if (bk32 && BM * BN < 128 * 128 && g.k_per_split >= 64 && g.k_per_split % 32 == 0)
+    if (bk32 && !g.a_idx && BM * BN < 128 * 128 && g.k_per_split >= 64 && g.k_per_split % 32 == 0)
         return launch_gemm_bk<BM, BN, (BM * BN < 128 * 128 ? 32 : 16)>(a_kc, b_kc, g, splits, st);
     return launch_gemm_bk<BM, BN, 16>(a_kc, b_kc, g, splits, st);
 }
@@ -299,12 +372,25 @@ extern "C" int seqrec_gemm_f32(int a_kcontig, int b_kcontig, int64_t M, int64_t 
                                const float* A, int64_t lda, const float* B, int64_t ldb,
                                float* C, int64_t ldc, const float* bias, int accumulate,
                                int splitk, float* workspace, void* stream) {
+    return seqrec_gemm_f32_fused(a_kcontig, b_kcontig, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, splitk, workspace,
+                                 nullptr, stream);
+}
+
+extern "C" int seqrec_gemm_f32_fused(int a_kcontig, int b_kcontig, int64_t M, int64_t N, int64_t K,
+                                     const float* A, int64_t lda, const float* B, int64_t ldb,
+                                     float* C, int64_t ldc, const float* bias, int accumulate,
+                                     int splitk, float* workspace, const seqrec_gemm_fuse* fuse, void* stream) {
     if (M < 0 || N < 0 || K < 0 || !C) return SEQREC_E_ARG;
     if (M == 0 || N == 0) return 0;
     if ((K > 0 && (!A || !B)) || splitk < 1) return SEQREC_E_ARG;
     if (splitk > 1 && !workspace) return SEQREC_E_ARG;
     hipStream_t st = as_stream(stream);
-    GemmArgs g;
+    GemmArgs g{};
+    if (fuse) {
+        if (fuse->add_table && (!fuse->add_index || fuse->add_ld < N)) return SEQREC_E_ARG;
+        g.a_idx = fuse->a_index;
+        g.add_table = fuse->add_table; g.add_idx = fuse->add_index; g.add_scale = fuse->add_scale; g.add_ld = fuse->add_ld;
+    }
     g.A = A; g.B = B; g.bias = bias;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.accumulate = accumulate;
@@ -324,7 +410,8 @@ extern "C" int seqrec_gemm_f32(int a_kcontig, int b_kcontig, int64_t M, int64_t 
     const long t12864 = ((M + 127) / 128) * ((N + 63) / 64) * splits;
     static const long thr = getenv("SEQREC_GEMM_TILE_THR") ? atol(getenv("SEQREC_GEMM_TILE_THR")) : 1024;   // tuning switch
     int rc;
-    if (t128 >= thr) rc = launch_gemm<128, 128>(a_kcontig, b_kcontig, g, splits, st);
+    if (g.a_idx) rc = launch_gemm<64, 64>(a_kcontig, b_kcontig, g, splits, st);
+    else if (t128 >= thr) rc = launch_gemm<128, 128>(a_kcontig, b_kcontig, g, splits, st);
     else if (t12864 >= thr) rc = launch_gemm<128, 64>(a_kcontig, b_kcontig, g, splits, st);
     else rc = launch_gemm<64, 64>(a_kcontig, b_kcontig, g, splits, st);
     if (rc) return rc;
@@ -332,7 +419,7 @@ extern "C" int seqrec_gemm_f32(int a_kcontig, int b_kcontig, int64_t M, int64_t 
         const long total = M * N;
         int blocks = (int)min((long)2048, (total + 255) / 256);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, splits, (long)M, (long)N,
-                           C, (long)ldc, bias, accumulate);
+                           C, (long)ldc, bias, accumulate, g);
         SEQREC_LAUNCH_CHECK();
     }
     return 0;
@@ -359,7 +446,7 @@ __global__ void target_score_kernel(const float* __restrict__ hd, int H, const f
 namespace {
 int rank_count_launch(const float* hd, int H, const float* Eout, const float* bout, const int32_t* tgt, const float* thr,
                       int64_t n, int V, int32_t* rank, hipStream_t st) {
-    GemmArgs g;
+    GemmArgs g{};
     g.A = hd; g.B = Eout; g.C = nullptr; g.bias = bout;
     g.M = n; g.N = V; g.K = H; g.lda = H; g.ldb = H; g.ldc = 0;
     g.k_per_split = (H + 31) / 32 * 32;
@@ -427,6 +514,8 @@ extern "C" int seqrec_gemm_f32_grouped(int count, int a_kcontig, int b_kcontig, 
         g.M = d[i].M; g.N = d[i].N; g.K = K; g.lda = d[i].lda; g.ldb = d[i].ldb;
         g.accumulate = d[i].accumulate;
         g.epi = 0; g.tgt = nullptr; g.thr = nullptr; g.rank = nullptr;
+        g.a_idx = d[i].a_index;
+        g.add_table = nullptr; g.add_idx = nullptr; g.add_scale = nullptr; g.add_ld = 0;
         g.a_vec = ((reinterpret_cast<uintptr_t>(d[i].A) & 15) == 0) && (d[i].lda % 4 == 0);
         g.b_vec = ((reinterpret_cast<uintptr_t>(d[i].B) & 15) == 0) && (d[i].ldb % 4 == 0);
         g.k_per_split = kps;

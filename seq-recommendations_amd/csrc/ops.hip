@@ -43,15 +43,13 @@ __global__ void gather_rows_kernel(const float* __restrict__ table, const int* _
     }
 }
 
+
 // ---------------------------------------------------------------------------------------------
 // full softmax + Keras/Theano CE, one wave per token row
 // ---------------------------------------------------------------------------------------------
-__global__ void full_softmax_ce_kernel(float* __restrict__ logits, long ld, const int* __restrict__ tgt, long n,
-                                       int V, float inv_denom, float* __restrict__ loss_rows,
-                                       float* __restrict__ probs) {
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= n) return;
+__device__ __forceinline__ void full_softmax_ce_row(float* __restrict__ logits, long ld, const int* __restrict__ tgt, long row,
+                                                    int V, float inv_denom, float* __restrict__ loss_rows,
+                                                    float* __restrict__ probs, int lane) {
     float* x = logits + row * ld;
     float m = -INFINITY;
     for (int j = lane; j < V; j += 64) m = fmaxf(m, x[j]);
@@ -79,6 +77,14 @@ __global__ void full_softmax_ce_kernel(float* __restrict__ logits, long ld, cons
     }
 }
 
+__global__ void full_softmax_ce_kernel(float* __restrict__ logits, long ld, const int* __restrict__ tgt, long n,
+                                       int V, float inv_denom, float* __restrict__ loss_rows,
+                                       float* __restrict__ probs) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row < n) full_softmax_ce_row(logits, ld, tgt, row, V, inv_denom, loss_rows, probs, lane);
+}
+
 // ---------------------------------------------------------------------------------------------
 // sampled softmax + CE over {target} U K negatives, one wave per token row
 // ---------------------------------------------------------------------------------------------
@@ -86,14 +92,12 @@ __global__ void full_softmax_ce_kernel(float* __restrict__ logits, long ld, cons
 // ROWS = true : target row = Eout[i] (rows already fetched from their owners), lq_t[i] / lq_n[k]
 //               are the per-candidate log-Q values (multi-GPU, row-sharded tables)
 template <bool ROWS>
-__global__ void sampled_softmax_ce_kernel(float* __restrict__ ln, long ld, const float* __restrict__ hd, int H,
-                                          const float* __restrict__ Eout, const float* __restrict__ bout,
-                                          const float* __restrict__ logq, const float* __restrict__ lq_n,
-                                          const int* __restrict__ tgt, const int* __restrict__ neg, long n, int K,
-                                          float inv_denom, float* __restrict__ loss_rows, float* __restrict__ dlt) {
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= n) return;
+__device__ __forceinline__ void sampled_softmax_ce_row(float* __restrict__ ln, long ld, const float* __restrict__ hd, int H,
+                                                       const float* __restrict__ Eout, const float* __restrict__ bout,
+                                                       const float* __restrict__ logq, const float* __restrict__ lq_n,
+                                                       const int* __restrict__ tgt, const int* __restrict__ neg, long row, int K,
+                                                       float inv_denom, float* __restrict__ loss_rows, float* __restrict__ dlt,
+                                                       int lane) {
     const int t = tgt[row];
     const float* h = hd + row * H;
     const float* et = Eout + (ROWS ? row : (long)t) * H;
@@ -135,6 +139,16 @@ __global__ void sampled_softmax_ce_kernel(float* __restrict__ ln, long ld, const
         dlt[row] = (pt - 1.f) * active;
     }
     for (int k = lane; k < K; k += 64) x[k] = (expf(x[k] - m) / s) * active;
+}
+template <bool ROWS>
+__global__ void sampled_softmax_ce_kernel(float* __restrict__ ln, long ld, const float* __restrict__ hd, int H,
+                                          const float* __restrict__ Eout, const float* __restrict__ bout,
+                                          const float* __restrict__ logq, const float* __restrict__ lq_n,
+                                          const int* __restrict__ tgt, const int* __restrict__ neg, long n, int K,
+                                          float inv_denom, float* __restrict__ loss_rows, float* __restrict__ dlt) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row < n) sampled_softmax_ce_row<ROWS>(ln, ld, hd, H, Eout, bout, logq, lq_n, tgt, neg, row, K, inv_denom, loss_rows, dlt, lane);
 }
 
 __global__ void reduce_sum_kernel(const float* __restrict__ x, long n, float* __restrict__ out, int accumulate) {
@@ -364,8 +378,27 @@ __global__ void rows_adagrad_multi_kernel(RowsMulti m, float lr, float eps, cons
 // fused optimizer launches: the norm of EVERYTHING (dense tensors + owned rows) in one launch, then clip
 // scale + dense Adagrad + row-sparse Adagrad in one launch (the step otherwise spends six ~5 us
 // launches here).  blockIdx.y < nd: dense tensor, else scatter list blockIdx.y - nd.
-struct OptPlan { DenseMulti d; RowsMulti r; int nd, nr; };
+struct OptPlan { DenseMulti d; RowsMulti r; int nd, nr; const float* loss_rows; long n_loss; float* loss_out; };
+// batch loss in the same launch as the gradient norm (one spare workgroup): loss_out[0] = sum of the per-token CE in a
+// fixed order, loss_out[1] = its token mean -- no separate reduction launch, no host-side division
+__device__ __forceinline__ void block_loss_reduce(const float* __restrict__ x, long n, float* __restrict__ out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (long i = threadIdx.x; i < n; i += 256) s += x[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = red[0]; out[1] = red[0] / (float)n; }
+}
+__global__ void loss_reduce_kernel(const float* __restrict__ x, long n, float* __restrict__ out) { block_loss_reduce(x, n, out); }
 __global__ void opt_sqnorm_kernel(OptPlan pl, float* __restrict__ sq) {
+    if ((int)blockIdx.y == pl.nd + pl.nr) {                 // spare row: the batch loss
+        if (blockIdx.x == 0) block_loss_reduce(pl.loss_rows, pl.n_loss, pl.loss_out);
+        return;
+    }
     __shared__ float part[4];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float s = 0.f;
@@ -402,6 +435,10 @@ __global__ void opt_sqnorm_kernel(OptPlan pl, float* __restrict__ sq) {
 // deterministic form of the norm (merge = "sorted"): every block stores its partial sum, a single block adds the
 // partials in index order (reduce_sum_kernel) -- no float atomics, bitwise reproducible
 __global__ void opt_sqnorm_partial_kernel(OptPlan pl, float* __restrict__ partials) {
+    if ((int)blockIdx.y == pl.nd + pl.nr) {
+        if (blockIdx.x == 0) block_loss_reduce(pl.loss_rows, pl.n_loss, pl.loss_out);
+        return;
+    }
     __shared__ float part[4];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float s = 0.f;
@@ -560,18 +597,15 @@ extern "C" int seqrec_full_softmax_ce(float* logits, int64_t ld, const int32_t* 
 namespace {
 // single-pass variant: the row (K <= 64*KR logits) is held in registers -- one read, one write
 template <bool ROWS, int KR>
-__global__ void sampled_softmax_ce_reg_kernel(float* __restrict__ ln, long ld, const float* __restrict__ hd, int H,
-                                              const float* __restrict__ Eout, const float* __restrict__ bout,
-                                              const float* __restrict__ logq, const float* __restrict__ lq_n,
-                                              const int* __restrict__ tgt, const int* __restrict__ neg, long n, int K,
-                                              float inv_denom, float* __restrict__ loss_rows, float* __restrict__ dlt,
-                                              int vec) {
+__device__ __forceinline__ void sampled_softmax_ce_reg_row(float* __restrict__ ln, long ld, const float* __restrict__ hd, int H,
+                                                           const float* __restrict__ Eout, const float* __restrict__ bout,
+                                                           const float* __restrict__ logq, const float* __restrict__ lq_n,
+                                                           const int* __restrict__ tgt, const int* __restrict__ neg, long row, int K,
+                                                           float inv_denom, float* __restrict__ loss_rows, float* __restrict__ dlt,
+                                                           int vec, int lane) {
     // lane owns logits k = 256*i + 4*lane + e (e < 4): one 16-byte access per lane per chunk when the
     // row is 16-byte aligned (vec), else four dword accesses with the same mapping
     constexpr int NC = KR / 4;
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= n) return;
     const int t = tgt[row];
     float* x = ln + row * ld;
     float v[KR];
@@ -645,6 +679,18 @@ __global__ void sampled_softmax_ce_reg_kernel(float* __restrict__ ln, long ld, c
                 if (k0 + e < K) x[k0 + e] = v[4 * i + e] * sc;
         }
     }
+}
+template <bool ROWS, int KR>
+__global__ void sampled_softmax_ce_reg_kernel(float* __restrict__ ln, long ld, const float* __restrict__ hd, int H,
+                                              const float* __restrict__ Eout, const float* __restrict__ bout,
+                                              const float* __restrict__ logq, const float* __restrict__ lq_n,
+                                              const int* __restrict__ tgt, const int* __restrict__ neg, long n, int K,
+                                              float inv_denom, float* __restrict__ loss_rows, float* __restrict__ dlt, int vec) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row < n)
+        sampled_softmax_ce_reg_row<ROWS, KR>(ln, ld, hd, H, Eout, bout, logq, lq_n, tgt, neg, row, K, inv_denom, loss_rows, dlt,
+                                             vec, lane);
 }
 
 template <bool ROWS>
@@ -1111,15 +1157,23 @@ int fill_opt_plan(int n_dense, float* const* params, float* const* accums, const
 }
 }  // namespace
 
+extern "C" int seqrec_loss_reduce(const float* loss_rows, int64_t n, float* loss_out, void* stream) {
+    if (n <= 0 || !loss_rows || !loss_out) return SEQREC_E_ARG;
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, as_stream(stream), loss_rows, (long)n, loss_out);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int seqrec_opt_sqnorm(int n_dense, const float* const* grads, const int64_t* numel,
-                                 const seqrec_rows_job* jobs_host, int n_jobs, float* sq_accum, void* stream) {
+                                 const seqrec_rows_job* jobs_host, int n_jobs, float* sq_accum,
+                                 const float* loss_rows, int64_t n_loss, float* loss_out, void* stream) {
     OptPlan pl;
     long maxn;
     const int rc = fill_opt_plan(n_dense, nullptr, nullptr, grads, numel, jobs_host, n_jobs, false, pl, maxn);
     if (rc) return rc;
-    if (!sq_accum) return SEQREC_E_ARG;
+    if (!sq_accum || (loss_out && (!loss_rows || n_loss <= 0))) return SEQREC_E_ARG;
+    pl.loss_rows = loss_rows; pl.n_loss = (long)n_loss; pl.loss_out = loss_out;
     const unsigned gx = (unsigned)std::max<long>(32, (maxn + 15) / 16);
-    hipLaunchKernelGGL(opt_sqnorm_kernel, dim3(gx, n_dense + n_jobs), dim3(256), 0, as_stream(stream), pl, sq_accum);
+    hipLaunchKernelGGL(opt_sqnorm_kernel, dim3(gx, n_dense + n_jobs + (loss_out ? 1 : 0)), dim3(256), 0, as_stream(stream), pl, sq_accum);
     SEQREC_LAUNCH_CHECK();
     return 0;
 }
@@ -1129,17 +1183,19 @@ extern "C" int64_t seqrec_opt_sqnorm_ordered_floats(int n_dense, int n_jobs, int
 }
 extern "C" int seqrec_opt_sqnorm_ordered(int n_dense, const float* const* grads, const int64_t* numel,
                                          const seqrec_rows_job* jobs_host, int n_jobs, float* partials,
-                                         int64_t partials_floats, float* sq_out, int accumulate, void* stream) {
+                                         int64_t partials_floats, float* sq_out, int accumulate,
+                                         const float* loss_rows, int64_t n_loss, float* loss_out, void* stream) {
     OptPlan pl;
     long maxn;
     const int rc = fill_opt_plan(n_dense, nullptr, nullptr, grads, numel, jobs_host, n_jobs, false, pl, maxn);
     if (rc) return rc;
-    if (!sq_out || !partials) return SEQREC_E_ARG;
+    if (!sq_out || !partials || (loss_out && (!loss_rows || n_loss <= 0))) return SEQREC_E_ARG;
+    pl.loss_rows = loss_rows; pl.n_loss = (long)n_loss; pl.loss_out = loss_out;
     const unsigned gx = (unsigned)std::max<long>(32, (maxn + 15) / 16);
     const long np = (long)gx * (n_dense + n_jobs);
     if (np > partials_floats) return SEQREC_E_ARG;
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(opt_sqnorm_partial_kernel, dim3(gx, n_dense + n_jobs), dim3(256), 0, st, pl, partials);
+    hipLaunchKernelGGL(opt_sqnorm_partial_kernel, dim3(gx, n_dense + n_jobs + (loss_out ? 1 : 0)), dim3(256), 0, st, pl, partials);
     SEQREC_LAUNCH_CHECK();
     hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, st, partials, np, sq_out, accumulate);
     SEQREC_LAUNCH_CHECK();

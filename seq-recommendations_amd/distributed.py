@@ -378,31 +378,29 @@ class ShardedEngine(Engine):
         loss_rows = self.buf("loss_rows", n)
         call("seqrec_sampled_softmax_ce_rows", ptr(ln), K, ptr(Hd), Hp, ptr(Etgt), ptr(d.get("lq_tgt")), ptr(lq_neg),
              ptr(d["tgt"]), ptr(neg), n, K, inv, ptr(loss_rows), ptr(dlt), st)
-        call("seqrec_reduce_sum", ptr(loss_rows), n, ptr(self.loss_sum), 0, st)
+        call("seqrec_loss_reduce", ptr(loss_rows), n, ptr(self.loss_out), st)
         if not train:
             return
         # -- backward
         ar = d["arange"]
         dHd = self.buf("dHd", n, Hp)
-        self.gemm(1, 0, n, Hp, K, ln, K, Eneg, Hp, dHd, Hp, splitk=self._splitk(n, Hp, K), tag="dH")
-        call("seqrec_gather_rows", ptr(Etgt), ptr(ar), ptr(dHd), n, Hp, ptr(dlt), None, 1, st)
+        self.gemm(1, 0, n, Hp, K, ln, K, Eneg, Hp, dHd, Hp, splitk=self._splitk(n, Hp, K), tag="dH",
+                  fuse=_lib.gemm_fuse(add_table=Etgt, add_index=ar, add_scale=dlt, add_ld=Hp))
         self.gemm(0, 0, K, Hp, n, ln, K, Hd, Hp, dEneg, Hp, splitk=self._splitk(K, Hp, n), tag="dEneg")
         call("seqrec_gather_rows", ptr(Hd), ptr(ar), ptr(dEtgt), n, Hp, ptr(dlt), None, 0, st)
         dPre = self.buf("dPre", n, GHp)
         self._scan_bwd(d, dHd, Hout, gates, aux, dPre)
-        Hprev = self.buf("Hprev", n, Hp)
-        call("seqrec_gather_rows", ptr(Hout), ptr(d["prev"]), ptr(Hprev), n, Hp, None, None, 0, st)
-        if c.cell == "gru":
-            wgrad = [(Hp, 2 * Hp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp),
+        if c.cell == "gru":          # h_{t-1} = Hout read through the prev links inside the GEMM
+            wgrad = [(Hp, 2 * Hp, n, Hout, Hp, dPre, GHp, Gd["U"], GHp, d["prev"]),
                      (Hp, Hp, n, aux, Hp, dPre[:, 2 * Hp:], GHp, Gd["U"][:, 2 * Hp:], GHp)]
         else:
-            wgrad = [(Hp, GHp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp)]
+            wgrad = [(Hp, GHp, n, Hout, Hp, dPre, GHp, Gd["U"], GHp, d["prev"])]
         wgrad.append((Dp, GHp, n, X, Dp, dPre, GHp, Gd["W"], GHp))
         if c.use_bias:                       # db = ones^T . dPre in the same grouped launch (M = 1)
             wgrad.append((1, GHp, n, self._ones(n), 1, dPre, GHp, Gd["b"], GHp))
-        tiles = sum(((m + 63) // 64) * ((nn_ + 63) // 64) for (m, nn_, *_r) in wgrad)
+        tiles = sum(((w_[0] + 63) // 64) * ((w_[1] + 63) // 64) for w_ in wgrad)
         sk = int(max(1, min(32, -(-SPLITK_TARGET_WGS // max(tiles, 1)), n // 128)))
-        wsp = self.buf("gemm_ws", sum(sk * m * nn_ for (m, nn_, *_r) in wgrad)) if sk > 1 else None
+        wsp = self.buf("gemm_ws", sum(sk * w_[0] * w_[1] for w_ in wgrad)) if sk > 1 else None
         call("seqrec_gemm_f32_grouped", len(wgrad), 0, 0, _lib.gemm_descs(wgrad), sk, ptr(wsp), st, tag="dW+dU")
         self.gemm(1, 1, n, Dp, GHp, dPre, GHp, P["W"], GHp, dX, Dp, splitk=self._splitk(n, Dp, GHp), tag="dX")
 

@@ -207,7 +207,8 @@ class Engine:
         self._sq_par = 0
         self.sq = self.sq1
         self.scale = torch.ones(1, **f32)
-        self.loss_sum = z(1)
+        self.loss_out = z(2)            # [sum of the per-token CE, its token mean]: seqrec_loss_reduce / spare block of seqrec_opt_sqnorm
+        self.loss_sum, self.loss_mean = self.loss_out[0:1], self.loss_out[1:2]
         self.upack = torch.empty(int(_lib.load().seqrec_rnn_upack_floats(CELL[c.cell], self.Hp)), **f32)
         self.upack_dirty = True
         self.stepwise = (c.scan == "stepwise") or (c.scan == "auto" and (self.Hp >= 128 or c.drop_rec > 0))
@@ -292,12 +293,19 @@ class Engine:
         return t[:n]
 
     def gemm(self, a_kc, b_kc, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, accumulate=0, splitk=1, tag=None,
-             ws_name="gemm_ws"):
+             ws_name="gemm_ws", fuse=None):
+        """fuse: _lib.gemm_fuse(...) -- gathered A operand and/or the row add of the epilogue (seqrec_gemm_f32_fused)."""
         wsp = None
         if splitk > 1:
             wsp = self.buf(ws_name, splitk * M * N)
-        call("seqrec_gemm_f32", int(a_kc), int(b_kc), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(Cm), ldc, ptr(bias),
-             accumulate, splitk, ptr(wsp), self._cur_st if self._cur_st is not None else self._stream(), tag=tag)
+        st = self._cur_st if self._cur_st is not None else self._stream()
+        if fuse is None:
+            call("seqrec_gemm_f32", int(a_kc), int(b_kc), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(Cm), ldc, ptr(bias),
+                 accumulate, splitk, ptr(wsp), st, tag=tag)
+        else:
+            import ctypes
+            call("seqrec_gemm_f32_fused", int(a_kc), int(b_kc), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(Cm), ldc, ptr(bias),
+                 accumulate, splitk, ptr(wsp), ctypes.addressof(fuse), st, tag=tag)
 
     @staticmethod
     def _splitk(M, N, K):
@@ -596,7 +604,7 @@ class Engine:
                  ptr(gates), ptr(aux), ptr(dPre), ptr(self.upack), st)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, d, train=False, step=0, want_probs=False, negatives=None, stop_at_hidden=False):
+    def forward(self, d, train=False, step=0, want_probs=False, negatives=None, stop_at_hidden=False, defer_loss=False):
         """Runs the graph up to the loss.  Returns a dict of device tensors; in training
         mode the gradient w.r.t. the logits is left in place of the logits."""
         c, P = self.cfg, self.P
@@ -605,7 +613,7 @@ class Engine:
         Hp, GHp = self.Hp, self.GHp
         r = {}
         if n == 0:
-            self.loss_sum.zero_()
+            self.loss_out.zero_()
             return r
         drops = self._drop_masks(d, step) if train else {}
         r["drops"] = drops
@@ -614,7 +622,12 @@ class Engine:
         if c.input == "onehot":
             call("seqrec_gather_rows", ptr(P["Wk"]), ptr(d["ids"]), ptr(XW), n, GHp, ptr(drops.get("in")), ptr(bias), 0, st)
         else:
-            if c.input == "embed":
+            xidx = None
+            if c.input == "embed" and "in" not in drops:
+                # the embedding lookup is fused into the cell's input GEMM: A = E read THROUGH the ids (no X copy)
+                X, xidx = P["E"], d["ids"]
+                Wm, Kd = P["W"], self.Dp
+            elif c.input == "embed":
                 X = self.buf("X", n, self.Dp)
                 call("seqrec_gather_rows", ptr(P["E"]), ptr(d["ids"]), ptr(X), n, self.Dp, None, None, 0, st, tag="E")
                 Wm, Kd = P["W"], self.Dp
@@ -625,8 +638,9 @@ class Engine:
                 Xd = self.buf("Xd", n, Kd)
                 call("seqrec_mul", ptr(X), ptr(drops["in"]), ptr(Xd), n * Kd, st)
                 X = Xd
-            r["X"] = X
-            self.gemm(1, 0, n, GHp, Kd, X, Kd, Wm, GHp, XW, GHp, bias=bias, tag="xw")
+            r["X"], r["X_index"] = X, xidx
+            self.gemm(1, 0, n, GHp, Kd, X, Kd, Wm, GHp, XW, GHp, bias=bias, tag="xw",
+                      fuse=None if xidx is None else _lib.gemm_fuse(a_index=xidx))
         Hout = self.buf("Hout", n, Hp)
         gates = self.buf("gates", n, GHp)
         aux = self.buf("aux", n, Hp)
@@ -677,8 +691,9 @@ class Engine:
             call("seqrec_sampled_softmax_ce", ptr(ln), K, ptr(Hd), Hp, ptr(Et), ptr(P.get("bout")),
                  ptr(lq if c.logq else None), ptr(lq_neg), ptr(tgt), ptr(neg), n, K, inv, ptr(loss_rows), ptr(dlt), st)
             r.update(neg=neg, Eneg=Eneg, dln=ln, dlt=dlt)
-        if tgt is not None:
-            call("seqrec_reduce_sum", ptr(loss_rows), n, ptr(self.loss_sum), 0, st)
+        r["loss_rows"] = loss_rows if tgt is not None else None
+        if tgt is not None and not defer_loss:
+            call("seqrec_loss_reduce", ptr(loss_rows), n, ptr(self.loss_out), st)
         return r
 
     # ------------------------------------------------------------------ training step
@@ -694,8 +709,10 @@ class Engine:
             return torch.zeros(1, device=self.dev)
         st = self._stream()
         Hp, GHp = self.Hp, self.GHp
-        r = self.forward(d, train=True, step=step, negatives=negatives)
+        # the batch loss is reduced by a spare workgroup of the gradient-norm launch (defer_loss) when that launch runs
+        r = self.forward(d, train=True, step=step, negatives=negatives, defer_loss=apply_update)
         drops = r["drops"]
+        lrows = r["loss_rows"]
         Hd = r["Hd"]
         Gd, Gt = self.Gd, self.Gt
         tr = self.trainable
@@ -728,8 +745,9 @@ class Engine:
             tname = "E" if c.tied else "Eout"
             Et = P[tname]
             dln, dlt, neg, Eneg = r["dln"], r["dlt"], r["neg"], r["Eneg"]
-            self.gemm(1, 0, n, Hp, K, dln, K, Eneg, Hp, dHd, Hp, splitk=self._splitk(n, Hp, K), tag="dH")
-            call("seqrec_gather_rows", ptr(Et), ptr(d["tgt"]), ptr(dHd), n, Hp, ptr(dlt), None, 1, st)
+            # dH = dlogits . Eneg + dlt * Eout[tgt]: the target-row term rides in the GEMM's final write
+            self.gemm(1, 0, n, Hp, K, dln, K, Eneg, Hp, dHd, Hp, splitk=self._splitk(n, Hp, K), tag="dH",
+                      fuse=_lib.gemm_fuse(add_table=Et, add_index=d["tgt"], add_scale=dlt, add_ld=Hp))
             if tr[tname]:
                 dEneg = self.buf("dEneg", K, Hp)
                 self.gemm(0, 0, K, Hp, n, dln, K, Hd, Hp, dEneg, Hp, splitk=self._splitk(K, Hp, n), tag="dEneg")
@@ -749,8 +767,11 @@ class Engine:
         if c.use_bias and tr["b"] and not bias_in_group:
             call("seqrec_colsum", ptr(dPre), n, GHp, GHp, ptr(Gd["b"]), 0, ptr(cs_ws), st)
         if tr["U"]:
-            Hprev = self.buf("Hprev", n, Hp)
-            call("seqrec_gather_rows", ptr(r["Hout"]), ptr(d["prev"]), ptr(Hprev), n, Hp, None, None, 0, st)
+            if "rec" in drops:
+                Hprev = self.buf("Hprev", n, Hp)
+                call("seqrec_gather_rows", ptr(r["Hout"]), ptr(d["prev"]), ptr(Hprev), n, Hp, None, None, 0, st)
+            else:
+                Hprev, hidx = r["Hout"], d["prev"]      # h_{t-1} rows are read through the prev links inside the GEMM
             sk = self._splitk(Hp, GHp, n)
             if "rec" in drops:
                 # dU_g = (A_g * m_g)^T . dPre_g with the gate's time-invariant mask expanded to tokens
@@ -766,10 +787,10 @@ class Engine:
                     self.gemm(0, 0, Hp, Hp, n, Am, Hp, dPre[:, g * Hp:], GHp, Gd["U"][:, g * Hp:], GHp,
                               splitk=self._splitk(Hp, Hp, n), tag="dU")
             elif c.cell == "gru":
-                wgrad.append((Hp, 2 * Hp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp))
+                wgrad.append((Hp, 2 * Hp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp, hidx))
                 wgrad.append((Hp, Hp, n, r["aux"], Hp, dPre[:, 2 * Hp:], GHp, Gd["U"][:, 2 * Hp:], GHp))
             else:
-                wgrad.append((Hp, GHp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp))
+                wgrad.append((Hp, GHp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp, hidx))
         if c.input == "onehot":
             if tr["Wk"]:
                 sparse_jobs.append(self._job("Wk", d["ids"], dPre, GHp, drops.get("in"), n, GHp, 0))
@@ -778,7 +799,7 @@ class Engine:
             Kd = X.shape[1]
             wname = "W" if c.input == "embed" else "Wk"
             if tr[wname]:
-                wgrad.append((Kd, GHp, n, X, Kd, dPre, GHp, Gd[wname], GHp))
+                wgrad.append((Kd, GHp, n, X, Kd, dPre, GHp, Gd[wname], GHp, r["X_index"]))
             if c.input == "embed" and tr["E"]:
                 dX = self.buf("dX", n, self.Dp)
                 self.gemm(1, 1, n, self.Dp, GHp, dPre, GHp, P["W"], GHp, dX, self.Dp, splitk=self._splitk(n, self.Dp, GHp), tag="dX")
@@ -794,9 +815,9 @@ class Engine:
                 call("seqrec_colsum", ptr(dPre), n, GHp, GHp, ptr(Gd["b"]), 0, ptr(cs_ws), st)
         if wgrad:
             # the weight gradients A^T . dPre all reduce over the tokens: one grouped split-K launch
-            tiles = sum(((m + 63) // 64) * ((nn_ + 63) // 64) for (m, nn_, *_rest) in wgrad)
+            tiles = sum(((w_[0] + 63) // 64) * ((w_[1] + 63) // 64) for w_ in wgrad)
             sk = int(max(1, min(32, -(-SPLITK_TARGET_WGS // max(tiles, 1)), n // 128)))
-            wsz = sum(sk * m * nn_ for (m, nn_, *_rest) in wgrad)
+            wsz = sum(sk * w_[0] * w_[1] for w_ in wgrad)
             wsp = self.buf("gemm_ws", wsz) if sk > 1 else None
             call("seqrec_gemm_f32_grouped", len(wgrad), 0, 0, _lib.gemm_descs(wgrad), sk, ptr(wsp), st, tag="dW+dU")
         # ---- row-sparse contributions: one launch for (up to 4) scatter lists
@@ -824,9 +845,10 @@ class Engine:
             if c.merge == "sorted":      # the norm without float atomics too: per-block partials added in index order
                 mx = max([j["n"] for j in sparse_jobs] + [0])
                 npart = int(_lib.load().seqrec_opt_sqnorm_ordered_floats(len(dk), cnt, mx))
-                call("seqrec_opt_sqnorm_ordered", len(dk), gp, nn, arr, cnt, ptr(self.buf("sq_partials", npart)), npart, ptr(cur), 0, st)
+                call("seqrec_opt_sqnorm_ordered", len(dk), gp, nn, arr, cnt, ptr(self.buf("sq_partials", npart)), npart, ptr(cur), 0,
+                     ptr(lrows), n, ptr(self.loss_out), st)
             else:
-                call("seqrec_opt_sqnorm", len(dk), gp, nn, arr, cnt, ptr(cur), st)
+                call("seqrec_opt_sqnorm", len(dk), gp, nn, arr, cnt, ptr(cur), ptr(lrows), n, ptr(self.loss_out), st)
             call("seqrec_opt_apply", len(dk), _lib.ptr_array([P[k] for k in dk]) if dk else None,
                  _lib.ptr_array([self.A[k] for k in dk]) if dk else None, gp, nn, arr, cnt, ptr(cur), clip, lr, eps,
                  ptr(self.scale), ptr(nxt), st)
@@ -835,6 +857,7 @@ class Engine:
         else:
             self.sq = self.sq1
             self.sq.zero_()
+            call("seqrec_loss_reduce", ptr(lrows), n, ptr(self.loss_out), st)
             if dk:
                 gp = _lib.ptr_array([Gd[k] for k in dk])
                 nn = _lib.i64_array([Gd[k].numel() for k in dk])
@@ -846,9 +869,9 @@ class Engine:
                 npart = int(max(lib.seqrec_opt_sqnorm_ordered_floats(len(dk), 0, 0), lib.seqrec_opt_sqnorm_ordered_floats(0, 4, mx)))
                 pbuf = self.buf("sq_partials", npart)
                 if dk:
-                    call("seqrec_opt_sqnorm_ordered", len(dk), gp, nn, None, 0, ptr(pbuf), npart, ptr(self.sq), 1, st)
+                    call("seqrec_opt_sqnorm_ordered", len(dk), gp, nn, None, 0, ptr(pbuf), npart, ptr(self.sq), 1, None, 0, None, st)
                 for arr, cnt in packed:
-                    call("seqrec_opt_sqnorm_ordered", 0, None, None, arr, cnt, ptr(pbuf), npart, ptr(self.sq), 1, st)
+                    call("seqrec_opt_sqnorm_ordered", 0, None, None, arr, cnt, ptr(pbuf), npart, ptr(self.sq), 1, None, 0, None, st)
             else:
                 if dk:
                     call("seqrec_sqnorm_multi", len(dk), gp, nn, ptr(self.sq), st)
@@ -866,8 +889,8 @@ class Engine:
             # Keras applies a kernel constraint AFTER the optimizer update: w *= mask (model.py:64)
             call("seqrec_mul", ptr(P["Wxy"]), ptr(self.diag_mask), ptr(P["Wxy"]), P["Wxy"].numel(), st)
         if self.priors:
-            return self.loss_sum / n + self.reg_sum
-        return self.loss_sum / n
+            return self.loss_mean + self.reg_sum
+        return self.loss_mean            # a VIEW of the engine's loss slot: read or consume it before the next step is enqueued
 
     def grads(self, d, step=0, negatives=None):
         """Debug/test hook: loss and UNPADDED gradients of one batch, no update applied.
@@ -885,7 +908,7 @@ class Engine:
             self.Gt[k].zero_()
             self.slot[k].fill_(INT32_MAX)
         reg = float(self.reg_sum.item()) if self.priors else 0.0
-        return float((self.loss_sum / max(n, 1)).item()) + reg, out
+        return float(self.loss_mean.item()) + reg, out
 
     # ------------------------------------------------------------------ evaluation / prediction
     def eval_loss(self, d, negatives=None, step=0):
@@ -895,8 +918,8 @@ class Engine:
         self.forward(d, train=False, step=step, negatives=negatives)
         if self.priors:
             self._apply_priors(False)
-            return self.loss_sum / d["n"] + self.reg_sum
-        return self.loss_sum / d["n"]
+            return self.loss_mean + self.reg_sum
+        return self.loss_mean.clone()
 
     def predict_rows(self, d):
         """Softmax probabilities per real token, [N_tok, V_out] (full softmax only)."""

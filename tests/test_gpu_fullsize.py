@@ -139,7 +139,7 @@ def test_rank_counts_match_torch_reference_on_a_token_sample(world):
     diff = (rk[idx].long() - ref).abs()
     # near-ties at the threshold flip with the summation order of the two matmuls; their number grows with |items|
     # (5M scores of magnitude 1e-4 around each threshold in c5)
-    assert int(diff.max().item()) <= 3 and float((diff == 0).float().mean().item()) > (0.8 if eng.cfg.V_out > 2_000_000 else 0.9), diff
+    assert int(diff.max().item()) <= 3 and float(diff.float().mean().item()) < (0.5 if eng.cfg.V_out > 2_000_000 else 0.1), diff
 
 
 def test_topk_prediction_at_full_catalogue_matches_torch_topk(world):

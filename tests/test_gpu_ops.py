@@ -402,7 +402,7 @@ def test_fused_optimizer_launches_equal_the_separate_kernels():
         sq = torch.zeros(2, device="cuda"); sq[1] = 123.0
         scale = torch.zeros(1, device="cuda")
         if fused:
-            call("seqrec_opt_sqnorm", len(sizes), gp, nn, arr, cnt, ptr(sq[0:1]), st())
+            call("seqrec_opt_sqnorm", len(sizes), gp, nn, arr, cnt, ptr(sq[0:1]), None, 0, None, st())
             call("seqrec_opt_apply", len(sizes), pp, ap, gp, nn, arr, cnt, ptr(sq[0:1]), 0.05, 0.01, 1e-8, ptr(scale), ptr(sq[1:2]), st())
             assert sq[1].item() == 0.0                       # the other norm slot was cleared for the next step
         else:
@@ -611,10 +611,72 @@ def test_ordered_norm_equals_the_atomic_norm_and_is_reproducible():
     for rep in range(2):
         sq = torch.full((1,), float("nan"), device="cuda")
         part.fill_(float(rep))
-        call("seqrec_opt_sqnorm_ordered", 3, gp, nn, arr, cnt, ptr(part), npart, ptr(sq), 0, st())
+        call("seqrec_opt_sqnorm_ordered", 3, gp, nn, arr, cnt, ptr(part), npart, ptr(sq), 0, None, 0, None, st())
         got.append(sq.cpu().numpy().copy())
     np.testing.assert_array_equal(got[0], got[1])
     assert abs(float(got[0][0]) - ref) <= 1e-5 * ref
     sq = torch.zeros(1, device="cuda")
-    call("seqrec_opt_sqnorm", 3, gp, nn, arr, cnt, ptr(sq), st())
+    lrows = dev(rng.random(2603).astype(np.float32) * 12)
+    lo = torch.full((2,), float("nan"), device="cuda")
+    call("seqrec_opt_sqnorm", 3, gp, nn, arr, cnt, ptr(sq), ptr(lrows), 2603, ptr(lo), st())       # + the batch loss in the same launch
     assert abs(float(sq.item()) - ref) <= 1e-5 * ref
+    want = float(lrows.double().sum().item())
+    assert abs(float(lo[0].item()) - want) <= 1e-5 * want and abs(float(lo[1].item()) - want / 2603) <= 1e-5 * want / 2603
+    lo2 = torch.full((2,), float("nan"), device="cuda")
+    call("seqrec_loss_reduce", ptr(lrows), 2603, ptr(lo2), st())
+    assert torch.equal(lo, lo2)                                                                     # same fixed order
+
+
+@pytest.mark.parametrize("splitk", [1, 5])
+def test_gemm_fused_gathered_a_operand_and_row_add(splitk):
+    """seqrec_gemm_f32_fused against numpy: (1) A rows read through an index (x.W with x = E[ids], -1 = zero row),
+    bit-identical to the GEMM on the materialised gather; (2) the index along K for the stored-KxM form
+    (Hout[prev]^T . dPre, ragged sizes); (3) the row add of the final write (dH += dlt * Eout[tgt]) with and
+    without split-K."""
+    import ctypes
+    rng = np.random.default_rng(3 + splitk)
+    V, D, N, n = 700, 100, 200, 333
+    E = rng.normal(size=(V, D)).astype(np.float32)
+    W = rng.normal(size=(D, N)).astype(np.float32)
+    ids = rng.integers(0, V, size=n).astype(np.int32)
+    ids[::17] = -1
+    X = np.where(ids[:, None] >= 0, E[np.maximum(ids, 0)], 0).astype(np.float32)
+    Ed, Wd, idd = dev(E), dev(W), dev(ids)
+    ws = torch.empty(max(1, splitk * max(n, D) * N), device="cuda")
+
+    def fused(a_kc, b_kc, M, N_, K, A, lda, B, ldb, C, ldc, f, bias=None, acc=0):
+        call("seqrec_gemm_f32_fused", a_kc, b_kc, M, N_, K, ptr(A), lda, ptr(B), ldb, ptr(C), ldc, ptr(bias), acc, splitk, ptr(ws),
+             ctypes.addressof(f), st())
+    # (1) row gather, a_kcontig = 1
+    bias = dev(rng.normal(size=N).astype(np.float32))
+    C1 = torch.full((n, N), float("nan"), device="cuda")
+    fused(1, 0, n, N, D, Ed, D, Wd, N, C1, N, L.gemm_fuse(a_index=idd), bias=bias)
+    C0 = torch.full((n, N), float("nan"), device="cuda")
+    gemm(1, 0, n, N, D, dev(X), D, Wd, N, C0, N, bias=bias, splitk=splitk)
+    assert torch.equal(C1, C0)                                                  # same tiles, same order: bit-identical
+    ref = X.astype(np.float64) @ W.astype(np.float64) + bias.cpu().numpy()
+    assert np.abs(C1.cpu().numpy() - ref).max() < 2e-4
+    # (2) gather along K, a_kcontig = 0: C[D, N] = X^T . G with X = E[ids] never materialised
+    G = rng.normal(size=(n, N)).astype(np.float32)
+    C2 = torch.full((D, N), float("nan"), device="cuda")
+    fused(0, 0, D, N, n, Ed, D, dev(G), N, C2, N, L.gemm_fuse(a_index=idd))
+    ref2 = X.astype(np.float64).T @ G.astype(np.float64)
+    assert np.abs(C2.cpu().numpy() - ref2).max() < 5e-4
+    # grouped form with one gathered and one plain problem
+    C3 = torch.full((D, N), float("nan"), device="cuda")
+    C4 = torch.full((D, N), float("nan"), device="cuda")
+    descs = L.gemm_descs([(D, N, n, Ed, D, dev(G), N, C3, N, idd), (D, N, n, dev(X.T.copy().T), D, dev(G), N, C4, N)])
+    call("seqrec_gemm_f32_grouped", 2, 0, 0, descs, splitk, ptr(ws.new_empty(2 * splitk * D * N)) if splitk > 1 else None, st())
+    assert np.abs(C3.cpu().numpy() - ref2).max() < 5e-4 and np.abs(C4.cpu().numpy() - ref2).max() < 5e-4
+    # (3) row add: C[m,:] = A.B + scale[m] * T[idx[m],:]
+    T = rng.normal(size=(V, N + 8)).astype(np.float32)                            # add_ld > N
+    tix = rng.integers(0, V, size=n).astype(np.int32)
+    tix[5] = -1
+    sc = rng.normal(size=n).astype(np.float32)
+    C5 = torch.full((n, N), float("nan"), device="cuda")
+    fused(1, 0, n, N, D, dev(X), D, Wd, N, C5, N, L.gemm_fuse(add_table=dev(T), add_index=dev(tix), add_scale=dev(sc), add_ld=N + 8))
+    add = np.where(tix[:, None] >= 0, T[np.maximum(tix, 0), :N] * sc[:, None], 0)
+    assert np.abs(C5.cpu().numpy() - (X.astype(np.float64) @ W.astype(np.float64) + add)).max() < 2e-4
+    # bad: add table narrower than N
+    with pytest.raises(L.SeqrecError):
+        fused(1, 0, n, N, D, dev(X), D, Wd, N, C5, N, L.gemm_fuse(add_table=dev(T), add_index=dev(tix), add_ld=N - 1))
