@@ -10,9 +10,13 @@
 // slices for free (no in-kernel inter-workgroup protocol, no residency assumption).
 //
 // Workgroup = 256 threads: 16 session rows x 16 output columns with K split over the 4 waves;
-// A operand (h_prev / r*h / dpre rows) staged in LDS [16][K+2]; B operand (U slice) loaded straight
-// into registers from a per-(column block, wave) packed layout, all loads issued up front.
-// Exact fp32 (v_mfma_f32_16x16x4_f32).  Needs the step offsets on the HOST to size the launches.
+// BOTH operands go straight from global memory into MFMA operand registers: the A rows (h_prev / r*h /
+// dpre, or the BPTT factor d recomputed on the fly) through a K-permuted packing of U that lets lane
+// (row, q) of wave w own K/16 consecutive k of its row (one or two 16-byte loads), the B operand (U slice)
+// from a per-(column block, wave) packed layout; every load of the kernel is issued before the first MFMA
+// waits, partial tiles meet in LDS.  Only the LSTM forward step, whose four gate waves share one A tile,
+// stages h_prev in LDS.  Exact fp32 (v_mfma_f32_16x16x4_f32).  Needs the step offsets on the HOST to size
+// the launches.
 #include "common.h"
 #include <cstdlib>
 
@@ -90,13 +94,10 @@ __device__ __forceinline__ bool tile_of(const StepArgs& a, int& r0, int& cb) {
 // Per launch the dependent chain is: loads (one L2 round trip) -> 16..32 MFMAs -> LDS reduce -> store.
 //
 // packed[((cb*4 + w)*(K/64) + i)*64 + lane] (float4): element e <-> MFMA m = 4*i + e of wave w,
-//   value = B[k(w, m, lane>>4)][16*cb + (lane&15)]
-//   LDS-staged A (K > 512):        k = 4*(w*(K/16) + m) + q
-//   register A  (K <= 512, reg=1): k = w*(K/4) + q*(K/16) + m      -- lane (row, q) of wave w then owns K/16
-//                                   CONSECUTIVE k of its A row and loads them straight from global memory
+//   value = B[k(w, m, lane>>4)][16*cb + (lane&15)],  k = w*(K/4) + q*(K/16) + m  -- lane (row, q) of wave w owns
+//   K/16 CONSECUTIVE k of its A row and loads them straight from global memory (every accepted shape: K <= 2048)
 // mode 0: B[k][n] = U[k*ldu + coff + n]           (forward:  K = H)
-// mode 1: B[k][n] = U[n*ldu + coff + k]           (backward: transposed; K = H or 2H)
-constexpr bool reg_operand(int K) { return K <= 2048; }
+// mode 1: B[k][n] = U[n*ldu + coff + k]           (backward: transposed; K = H, 2H or 4H)
 struct PackStepJob { int coff, K, N, mode; long off; };
 struct PackStepArgs { const float* U; float* out; int ldu; PackStepJob job[4]; };
 __global__ void pack_step_kernel(PackStepArgs pa) {
@@ -114,34 +115,13 @@ __global__ void pack_step_kernel(PackStepArgs pa) {
         const int w = (int)(q & 3); q >>= 2;
         const int cb = (int)q;
         const int m = 4 * i + e;
-        const int k = reg_operand(K) ? w * (K / 4) + (l >> 4) * (K / 16) + m : 4 * (w * (K / 16) + m) + (l >> 4);
+        const int k = w * (K / 4) + (l >> 4) * (K / 16) + m;
         const int n = 16 * cb + (l & 15);
         out[o] = mode == 0 ? U[(long)k * ldu + coff + n] : U[(long)n * ldu + coff + k];
     }
 }
 
-// split-K tile product; returns this thread's element C[tid>>4][tid&15].  `ab` must be filled and
-// fenced by the caller's barrier; `red` is [4][256] floats.
-template <int K>
-__device__ __forceinline__ float tile_16x16(const float* __restrict__ ab, float* __restrict__ red, const float4 (&b)[K / 64],
-                                            int tid) {
-    constexpr int LDA = K + 2, G4 = K / 64;
-    const int lane = tid & 63, w = tid >> 6;
-    const float* ap = ab + (lane & 15) * LDA + (lane >> 4) + w * (K / 4);
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < G4; ++i) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 0], b[i].x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 4], b[i].y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 8], b[i].z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 12], b[i].w, acc1, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[w * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc0[r] + acc1[r];
-    __syncthreads();
-    return (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
-}
-// ---- register-operand form (K <= 512): no LDS staging and no barrier in front of the MFMAs.
+// ---- register-operand tile product: no LDS staging and no barrier in front of the MFMAs.
 // lane (row = lane & 15, q = lane >> 4) of wave w owns k in [w*K/4 + q*K/16, +K/16) of its A row.
 template <int K> __device__ __forceinline__ int a_koff(int lane, int w) { return w * (K / 4) + (lane >> 4) * (K / 16); }
 // (plain 16-byte global loads from a CLAMPED row pointer: rows beyond the block's last session read a
@@ -229,7 +209,18 @@ __global__ __launch_bounds__(256) void gru_step_fwd(StepArgs a_in) {
     const int soG = (a.p0 + r0) * GH * 4, soH = (a.p0 + r0) * H * 4, soP = (a.pprev0 + r0) * H * 4;
     const int vg = ok ? (row * GH + col) * 4 : INVALID_OFF;
     const int vh = ok ? (row * H + col) * 4 : INVALID_OFF;
-    // epilogue operands first: their latency hides under the tile product
+    // all loads issued up front in the order their data is needed: A rows, packed U slice, epilogue operands
+    const int mg = PHASE == 1 ? 2 : (col >= H ? 1 : 0);      // gate whose recurrent-dropout mask applies to A
+    float4 b[H / 64];
+    float av[H / 16];
+    const int arow = min(lane & 15, nact - 1), koff = a_koff<H>(lane, w);
+    if (!a.first) {
+        const float4* pk = reinterpret_cast<const float4*>(a.pk) + (size_t)(cb * 4 + w) * (H / 64) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < H / 64; ++i) b[i] = pk[i * 64];
+        // A rows straight into MFMA operand registers: PHASE 0 -> h_prev = Hout[prev step], PHASE 1 -> r*h_prev = aux[this step]
+        gload_vec(av, (PHASE == 0 ? a.Hout + (long)(a.pprev0 + r0 + arow) * H : a.aux + (long)(a.p0 + r0 + arow) * H) + koff);
+    }
     const float xw = bload(rXW, PHASE == 0 ? vg : vg + 2 * H * 4, soG);
     float zg = 0.f, h0 = 0.f;
     if (PHASE == 1) {
@@ -238,17 +229,9 @@ __global__ __launch_bounds__(256) void gru_step_fwd(StepArgs a_in) {
     } else if (col >= H) {
         h0 = bload(rH, (a.first || !ok) ? INVALID_OFF : (row * H + (col - H)) * 4, soP);   // h_prev for r * h_prev
     }
-    const int mg = PHASE == 1 ? 2 : (col >= H ? 1 : 0);      // gate whose recurrent-dropout mask applies to A
+    __builtin_amdgcn_sched_barrier(0);
     float acc = 0.f;
     if (!a.first) {
-        float4 b[H / 64];
-        const float4* pk = reinterpret_cast<const float4*>(a.pk) + (size_t)(cb * 4 + w) * (H / 64) * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < H / 64; ++i) b[i] = pk[i * 64];
-        // A rows straight into MFMA operand registers: PHASE 0 -> h_prev = Hout[prev step], PHASE 1 -> r*h_prev = aux[this step]
-        const int arow = min(lane & 15, nact - 1), koff = a_koff<H>(lane, w);
-        float av[H / 16];
-        gload_vec(av, (PHASE == 0 ? a.Hout + (long)(a.pprev0 + r0 + arow) * H : a.aux + (long)(a.p0 + r0 + arow) * H) + koff);
         if (a.rmask) mask_vec(av, a.rmask, a.B, H, mg, r0 + arow, koff, true);
         acc = tile_16x16_reg<H>(av, b, red, tid);
     }
@@ -274,9 +257,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a_in) {
     //          dpre_z, dpre_r, dpre_h -> dPre;  dcar = dh z + drh r -> tmpc
     // PHASE 1 (grid rows/16 x H/16, skipped at t = 0): dh_prev = tmpc + [dpre_z|dpre_r] . U_zr^T -> dHc[prev token]
     constexpr int H = 64 * J, GH = 3 * H;
-    constexpr int K = PHASE == 0 ? H : 2 * H, LDA = K + 2;
-    constexpr bool REG = reg_operand(K);
-    __shared__ float ab[REG ? 4 : 16 * LDA];
+    constexpr int K = PHASE == 0 ? H : 2 * H;
     __shared__ float red[4 * 256];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nact = min(16, a.bt - r0);
@@ -287,6 +268,30 @@ __global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a_in) {
     const int soG = (a.p0 + r0) * GH * 4, soH = (a.p0 + r0) * H * 4, soP = (a.pprev0 + r0) * H * 4;
     const int vg = ok ? (row * GH + col) * 4 : INVALID_OFF;
     const int vh = ok ? (row * H + col) * 4 : INVALID_OFF;
+    // Every load of the kernel is ISSUED before the first wait: the packed U slice (pinned by its own scheduling
+    // barrier -- hipcc otherwise fetches it only after d has been computed from the A-side rows: two memory
+    // latencies in series in a launch that is all latency), then the A-side rows, then the epilogue operands.
+    const long pt = (long)a.p0 + r0;
+    const bool aok = (lane & 15) < nact;
+    const int arow = min(lane & 15, nact - 1), koff = a_koff<K>(lane, w);
+    const long q = pt + arow;
+    float av[K / 16];
+    float dh[PHASE == 0 ? K / 16 : 1], cc[PHASE == 0 ? K / 16 : 1], zz[PHASE == 0 ? K / 16 : 1], hh[PHASE == 0 ? K / 16 : 1];
+    float4 b[K / 64];
+    const float4* pk = reinterpret_cast<const float4*>(a.pk) + (size_t)(cb * 4 + w) * (K / 64) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < K / 64; ++i) b[i] = pk[i * 64];
+    __builtin_amdgcn_sched_barrier(0);       // the U slice is requested before anything that could wait
+    if constexpr (PHASE == 0) {
+        // A operand in registers: PHASE 0 recomputes d = dh (1-z) act'(h~) for the lane's own k range (the workgroups
+        // of a row block do so redundantly; column block 0 also stores it), PHASE 1 reads dpre
+        gload_vec(dh, a.dHout + q * H + koff);
+        gload_vec(cc, a.dHc + q * H + koff);
+        gload_vec(zz, a.gates + q * GH + koff);
+        gload_vec(hh, a.gates + q * GH + 2 * H + koff);
+    } else {
+        gload_vec(av, a.dPre + q * GH + koff);
+    }
     float e_dh = 0.f, e_z = 0.f, e_r = 0.f, e_hh = 0.f, e_h0 = 0.f, e_t = 0.f;
     if (PHASE == 0) {
         e_dh = bload(rDH, vh, soH) + bload(rC, (ok && r0 + row < a.bnext) ? vh : INVALID_OFF, soH);
@@ -297,64 +302,14 @@ __global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a_in) {
     } else {
         e_t = bload(rT, vh, soH);
     }
-    float4 b[K / 64];
-    const float4* pk = reinterpret_cast<const float4*>(a.pk) + (size_t)(cb * 4 + w) * (K / 64) * 64 + lane;
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PHASE == 0) {
+        const float carry = (r0 + arow < a.bnext) ? 1.f : 0.f;     // dHc rows of sessions that ended here are stale
 #pragma unroll
-    for (int i = 0; i < K / 64; ++i) b[i] = pk[i * 64];
-    const long pt = (long)a.p0 + r0;
-    float acc;
-    if constexpr (REG) {
-        // A operand in registers: PHASE 0 recomputes d = dh (1-z) act'(h~) for the lane's own k range
-        // (the workgroups of a row block do so redundantly; column block 0 also stores it), PHASE 1 reads dpre
-        const bool aok = (lane & 15) < nact;
-        const int arow = min(lane & 15, nact - 1), koff = a_koff<K>(lane, w);
-        const long q = pt + arow;
-        float av[K / 16];
-        if (PHASE == 0) {
-            float dh[K / 16], cc[K / 16], zz[K / 16], hh[K / 16];
-            gload_vec(dh, a.dHout + q * H + koff);
-            gload_vec(cc, a.dHc + q * H + koff);
-            gload_vec(zz, a.gates + q * GH + koff);
-            gload_vec(hh, a.gates + q * GH + 2 * H + koff);
-            const float carry = (r0 + arow < a.bnext) ? 1.f : 0.f;     // dHc rows of sessions that ended here are stale
-#pragma unroll
-            for (int j = 0; j < K / 16; ++j) av[j] = (dh[j] + (carry != 0.f ? cc[j] : 0.f)) * (1.f - zz[j]) * act_grad<ACT>(hh[j]);
-            if (cb == 0 && aok) gstore_vec(av, a.dPre + q * GH + 2 * H + koff);
-        } else {
-            gload_vec(av, a.dPre + q * GH + koff);
-        }
-        acc = tile_16x16_reg<K>(av, b, red, tid);
-    } else {
-#pragma unroll
-        for (int it = 0; it < (16 * (K / 4)) / 256; ++it) {
-            const int idx = tid + 256 * it;
-            const int rr = idx / (K / 4), c4 = idx % (K / 4);
-            float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rr < nact) {
-                const long q = pt + rr;
-                if (PHASE == 0) {
-                    float4 dh = reinterpret_cast<const float4*>(a.dHout + q * H)[c4];
-                    if (r0 + rr < a.bnext) {
-                        const float4 c = reinterpret_cast<const float4*>(a.dHc + q * H)[c4];
-                        dh.x += c.x; dh.y += c.y; dh.z += c.z; dh.w += c.w;
-                    }
-                    const float4 z = reinterpret_cast<const float4*>(a.gates + q * GH)[c4];
-                    const float4 hh = reinterpret_cast<const float4*>(a.gates + q * GH + 2 * H)[c4];
-                    d.x = dh.x * (1.f - z.x) * act_grad<ACT>(hh.x);
-                    d.y = dh.y * (1.f - z.y) * act_grad<ACT>(hh.y);
-                    d.z = dh.z * (1.f - z.z) * act_grad<ACT>(hh.z);
-                    d.w = dh.w * (1.f - z.w) * act_grad<ACT>(hh.w);
-                    if (cb == 0) reinterpret_cast<float4*>(a.dPre + q * GH + 2 * H)[c4] = d;
-                } else {
-                    d = reinterpret_cast<const float4*>(a.dPre + q * GH)[c4];
-                }
-            }
-            float* o = ab + rr * LDA + 4 * c4;
-            o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = d.w;
-        }
-        __syncthreads();
-        acc = tile_16x16<K>(ab, red, b, tid);
+        for (int j = 0; j < K / 16; ++j) av[j] = (dh[j] + (carry != 0.f ? cc[j] : 0.f)) * (1.f - zz[j]) * act_grad<ACT>(hh[j]);
+        if (cb == 0 && aok) gstore_vec(av, a.dPre + q * GH + 2 * H + koff);
     }
+    float acc = tile_16x16_reg<K>(av, b, red, tid);
     const int srow = min(r0 + row, a.B - 1);
     if (PHASE == 0) {
         if (a.rmask) acc *= a.rmask[((long)2 * a.B + srow) * H + col];          // d(r*h*m2) -> d(r*h)
@@ -392,15 +347,18 @@ __device__ __forceinline__ void lstm_step_fwd_body(const StepArgs& a_in) {
     const int soG = (a.p0 + r0) * GH * 4, soH = (a.p0 + r0) * H * 4, soP = (a.pprev0 + r0) * H * 4;
     const int vg = ok ? (row * GH + col) * 4 : INVALID_OFF;
     const int vh = ok ? (row * H + col) * 4 : INVALID_OFF;
+    float4 b[G4];
+    if (!a.first) {          // the gate's U slice first, pinned: it must be in flight while h_prev is staged through LDS
+        const float4* pk = reinterpret_cast<const float4*>(a.pk) + (size_t)(cb * 4 + w) * G4 * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < G4; ++i) b[i] = pk[i * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
     float xw[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) xw[g] = bload(rXW, vg + g * H * 4, soG);
     const float cp = bload(rC, a.first ? INVALID_OFF : vh, soP);
     if (!a.first) {
-        float4 b[G4];
-        const float4* pk = reinterpret_cast<const float4*>(a.pk) + (size_t)(cb * 4 + w) * G4 * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < G4; ++i) b[i] = pk[i * 64];
         const float* src = a.Hout + (long)(a.pprev0 + r0) * H;
 #pragma unroll
         for (int it = 0; it < (16 * (H / 4)) / 256; ++it) {
@@ -467,16 +425,19 @@ __global__ __launch_bounds__(256) void srnn_step_fwd(StepArgs a_in) {
     const rsrc_t rXW = mk_rsrc(a.XW), rH = mk_rsrc(a.Hout);
     const int soH = (a.p0 + r0) * H * 4, soP = (a.pprev0 + r0) * H * 4;
     const int vh = ok ? (row * H + col) * 4 : INVALID_OFF;
-    const float xw = bload(rXW, vh, soH);
     float acc = 0.f;
+    float4 b[H / 64];
+    float av[H / 16];
+    const int arow = min(lane & 15, nact - 1), koff = a_koff<H>(lane, w);
     if (!a.first) {
-        float4 b[H / 64];
         const float4* pk = reinterpret_cast<const float4*>(a.pk) + (size_t)(cb * 4 + w) * (H / 64) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < H / 64; ++i) b[i] = pk[i * 64];
-        const int arow = min(lane & 15, nact - 1), koff = a_koff<H>(lane, w);
-        float av[H / 16];
         gload_vec(av, a.Hout + (long)(a.pprev0 + r0 + arow) * H + koff);
+    }
+    const float xw = bload(rXW, vh, soH);
+    __builtin_amdgcn_sched_barrier(0);       // every load issued before the first wait
+    if (!a.first) {
         if (a.rmask) mask_vec(av, a.rmask, a.B, H, 0, r0 + arow, koff, true);
         acc = tile_16x16_reg<H>(av, b, red, tid);
     }
@@ -523,9 +484,6 @@ __global__ __launch_bounds__(256) void gemm_bwd_step(StepArgs a_in, int H, int l
     const StepArgs a = resolve(a_in);
     int r0, cb;
     if (!tile_of(a, r0, cb)) return;
-    constexpr int LDA = K + 2;
-    constexpr bool REG = reg_operand(K);
-    __shared__ float ab[REG ? 4 : 16 * LDA];
     __shared__ float red[4 * 256];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nact = min(16, a.bt - r0);
@@ -535,25 +493,14 @@ __global__ __launch_bounds__(256) void gemm_bwd_step(StepArgs a_in, int H, int l
     const float4* pk = reinterpret_cast<const float4*>(a.pk) + (size_t)(cb * 4 + w) * (K / 64) * 64 + lane;
 #pragma unroll
     for (int i = 0; i < K / 64; ++i) b[i] = pk[i * 64];
+    __builtin_amdgcn_sched_barrier(0);       // U slice requested first (see gru_step_bwd)
     const long pt = (long)a.p0 + r0;
     float acc;
-    if constexpr (REG) {
+    {
         const int arow = min(lane & 15, nact - 1), koff = a_koff<K>(lane, w);
         float av[K / 16];
         gload_vec(av, a.dPre + (pt + arow) * ldp + koff);
         acc = tile_16x16_reg<K>(av, b, red, tid);
-    } else {
-#pragma unroll
-        for (int it = 0; it < (16 * (K / 4)) / 256; ++it) {
-            const int idx = tid + 256 * it;
-            const int rr = idx / (K / 4), c4 = idx % (K / 4);
-            float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rr < nact) d = reinterpret_cast<const float4*>(a.dPre + (pt + rr) * ldp)[c4];
-            float* o = ab + rr * LDA + 4 * c4;
-            o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = d.w;
-        }
-        __syncthreads();
-        acc = tile_16x16<K>(ab, red, b, tid);
     }
     if (a.rmask) {
         const int srow = min(r0 + row, a.B - 1);

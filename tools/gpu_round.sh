@@ -12,6 +12,20 @@ resident) TMO=400 run bench_resident python bench.py --gpus 1 --steps 200 --warm
 fresh200) TMO=400 run bench_fresh200 python bench.py --gpus 1 --steps 200 --warmup 20 --cpu-seconds 0 --recall-steps 0; tail -c 600 $out/bench_fresh200.log;;
 stall) TMO=200 run stall python tools/stall_probe.py 12; cat $out/stall.log; TMO=200 run stall_freeze python tools/stall_probe.py 12 freeze; cat $out/stall_freeze.log;;
 graph) SEQREC_SCAN_GRAPH=1 TMO=400 run bench_graph python bench.py --gpus 1 --steps 200 --warmup 20 --cpu-seconds 0 --recall-steps 0; tail -c 300 $out/bench_graph.log;;
+prof) root=$PWD; cd /tmp; export TMPDIR=/tmp; P=$root/$out/prof; mkdir -p $P
+   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $P/ks -o ks -- python3 $root/bench.py --steps 40 --warmup 5 --cpu-seconds 0 --recall-steps 0 --profile-steps 0 > $P/bench_under_rocprof.json 2> $P/ks.err; echo "ks rc=$?"
+   timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $P/w -o w -- python3 $root/tools/stall_probe.py 2 > $P/w.log 2>&1; echo "w rc=$?"
+   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $P/f -o f -- python3 $root/tools/stall_probe.py 2 > $P/f.log 2>&1; echo "f rc=$?"
+   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $P/wr -o wr -- python3 $root/tools/stall_probe.py 2 > $P/wr.log 2>&1; echo "wr rc=$?"
+   timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $P/m -o m -- python3 $root/tools/stall_probe.py 2 > $P/m.log 2>&1; echo "m rc=$?"
+   cd $root; find $P -name '*.csv' | head -20
+   python tools/pmc_widths.py $(find $P/w -name '*counter_collection.csv' | head -1) $P/scan_widths.json > $P/scan_widths.txt 2>&1; cat $P/scan_widths.txt
+   python tools/pmc_traffic.py $(find $P/f -name '*counter_collection.csv' | head -1) $(find $P/wr -name '*counter_collection.csv' | head -1) $P/pmc_hbm_traffic.json
+   python tools/pmc_mfma.py $(find $P/m -name '*counter_collection.csv' | head -1) $P/pmc_mfma.json | head -30
+   find $P -name '*kernel_stats.csv' -exec cp {} $P/kernel_stats.csv \;
+   find $P -name '*.csv' -size +3M -delete;;
+kernarg) HIP_FORCE_DEV_KERNARG=1 TMO=400 run bench_kernarg1 python bench.py --gpus 1 --steps 200 --warmup 20 --cpu-seconds 0 --recall-steps 0; tail -c 300 $out/bench_kernarg1.log
+   HIP_FORCE_DEV_KERNARG=0 TMO=400 run bench_kernarg0 python bench.py --gpus 1 --steps 200 --warmup 20 --cpu-seconds 0 --recall-steps 0; tail -c 300 $out/bench_kernarg0.log;;
 dbgtopk) TMO=300 run dbgtopk python tools/debug_topk.py c5; cat $out/dbgtopk.log;;
 trace) root=$PWD; cd /tmp; export TMPDIR=/tmp
    timeout -k 10 300 rocprofv3 --hip-trace --kernel-trace --output-format csv -d $root/$out/trace -- python3 $root/tools/stall_probe.py 8 > $root/$out/trace.log 2>&1; echo "trace rc=$?"
