@@ -423,12 +423,18 @@ def main(argv=None):
         resident = [eng.upload(Bt.pack_flat(flat, starts, stream.sel(i))) for i in range(nb)]
 
     tok_seen = []
+    window = {}         # sharded: the routing of the next WINDOW batches is planned together (2 collectives, 1 host sync)
+    WINDOW = 32
 
     def next_batch(i):
         if resident:
             d = resident[i % len(resident)]
         elif sharded:
-            d = eng.upload(Bt.pack_flat(flat, starts, stream.sel(i)))
+            if i not in window:
+                window.clear()
+                rbs = [Bt.pack_flat(flat, starts, stream.sel(j)) for j in range(i, i + WINDOW)]
+                window.update(zip(range(i, i + WINDOW), eng.prepare(rbs)))
+            d = window.pop(i)
         else:
             d = eng.upload_device(ds, stream.sel(i))
         return d
@@ -635,6 +641,7 @@ def main(argv=None):
                        "global_batch": a.batch * world, "seq_len": 50, "tokens_per_step_per_gpu": round(n_tok_mean, 1),
                        "t_mean": round(t_mean, 1), "t_max": t_max, "settle_steps": a.settle, "batches": mode,
                        "train_sessions_per_gpu": n_train, "test_sessions": n_test,
+                       "routing_window": WINDOW if (sharded and not resident) else None,
                        "parallelism": ("dp%d+row-sharded-tables" % world) if sharded else "single"},
             "tokens_per_s": round(tokens_per_s, 1), "final_loss": round(last_loss, 5), "recall_at_20": recall,
             "recall_after_steps": step if recall is not None else None,

@@ -267,7 +267,11 @@ int seqrec_opt_sqnorm_ordered(int n_dense, const float* const* grads, const int6
                               const float* loss_rows, int64_t n_loss, float* loss_out, void* stream);
 int seqrec_opt_apply(int n_dense, float* const* params, float* const* accums, const float* const* grads,
                      const int64_t* numel, const seqrec_rows_job* jobs_host, int n_jobs, const float* sq,
-                     float clipnorm, float lr, float eps, float* scale_out, float* zero_next, void* stream);
+                     float clipnorm, float lr, float eps, float* scale_out, float* zero_next,
+                     const float* grad_div, void* stream);
+/*      grad_div (nullable DEVICE scalar): the gradients in memory are sums still to be divided by *grad_div -- the
+ *      global token count of a multi-GPU step, which only exists after the all-reduce; norm, clip scale and update
+ *      then use g / *grad_div, so no step needs the count on the host.  *scale_out receives clip_scale / *grad_div. */
 
 /* ---- counter RNG (specification: oracle/rng.py).  Alias-method draw of K negatives for
  *      training step `step`; inverted-dropout multipliers out[r*ld + j] (j < width) drawn with

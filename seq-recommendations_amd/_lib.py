@@ -60,7 +60,7 @@ _SIGS = {
     "seqrec_topk_finish": [P, P, L, I, P, P, P],
     "seqrec_opt_sqnorm": [I, P, P, P, I, P, P, L, P, P],
     "seqrec_loss_reduce": [P, L, P, P],
-    "seqrec_opt_apply": [I, P, P, P, P, P, I, P, F, F, F, P, P, P],
+    "seqrec_opt_apply": [I, P, P, P, P, P, I, P, F, F, F, P, P, P, P],
     "seqrec_prior_grad": [P, P, L, C.c_float, P, P, P],
     "seqrec_pack_batch": [P, P, P, P, I, I, P, P, P, P],
     "seqrec_history_features": [P, P, P, P, I, I, I, L, I, P, P],

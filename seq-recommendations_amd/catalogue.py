@@ -113,9 +113,18 @@ class SampledRNNModel:
         eng, opt = self.engine, self.optimizer
         tot = torch.zeros(1, device=eng.dev)
         cnt = 0
-        for s in range(0, len(order), batch_size):
-            sel = order[s:s + batch_size]
-            d = eng.upload_device(ds, sel) if ds is not None else eng.upload(batching.pack_flat(flat, starts, sel))
+        sels = [order[s:s + batch_size] for s in range(0, len(order), batch_size)]
+        pending = []
+        for i, sel in enumerate(sels):
+            if ds is not None:
+                d = eng.upload_device(ds, sel)
+            elif self.dist is not None:
+                # row-sharded engine: route a window of batches at once (two collectives and one host sync per window)
+                if not pending:
+                    pending = eng.prepare([batching.pack_flat(flat, starts, x) for x in sels[i:i + 32]])
+                d = pending.pop(0)
+            else:
+                d = eng.upload(batching.pack_flat(flat, starts, sel))
             if d["n"] == 0:
                 continue
             if train:

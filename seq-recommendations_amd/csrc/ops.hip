@@ -470,9 +470,12 @@ __global__ void opt_sqnorm_partial_kernel(OptPlan pl, float* __restrict__ partia
     if (threadIdx.x == 0) partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 __global__ void opt_apply_kernel(OptPlan pl, const float* __restrict__ sq, float clipnorm, float lr, float eps,
-                                 float* __restrict__ scale_out, float* __restrict__ zero_next) {
-    const float nrm = sqrtf(sq[0]);
-    const float sc = (clipnorm > 0.f && nrm >= clipnorm) ? clipnorm / nrm : 1.f;   // Keras clip_norm (== clip_scale_kernel)
+                                 float* __restrict__ scale_out, float* __restrict__ zero_next, const float* __restrict__ grad_div) {
+    // grad_div (nullable device scalar): the gradients in memory are SUMS still to be divided by it (the global token
+    // count of a multi-GPU step, known only after the all-reduce): norm and update use g / grad_div
+    const float inv_div = grad_div ? 1.f / grad_div[0] : 1.f;
+    const float nrm = sqrtf(sq[0]) * inv_div;
+    const float sc = ((clipnorm > 0.f && nrm >= clipnorm) ? clipnorm / nrm : 1.f) * inv_div;   // Keras clip_norm (== clip_scale_kernel)
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         scale_out[0] = sc;
         if (zero_next) zero_next[0] = 0.f;            // the OTHER norm slot: nobody reads or adds to it during this step
@@ -1203,7 +1206,8 @@ extern "C" int seqrec_opt_sqnorm_ordered(int n_dense, const float* const* grads,
 }
 extern "C" int seqrec_opt_apply(int n_dense, float* const* params, float* const* accums, const float* const* grads,
                                 const int64_t* numel, const seqrec_rows_job* jobs_host, int n_jobs, const float* sq,
-                                float clipnorm, float lr, float eps, float* scale_out, float* zero_next, void* stream) {
+                                float clipnorm, float lr, float eps, float* scale_out, float* zero_next,
+                                const float* grad_div, void* stream) {
     OptPlan pl;
     long maxn;
     const int rc = fill_opt_plan(n_dense, params, accums, grads, numel, jobs_host, n_jobs, true, pl, maxn);
@@ -1211,7 +1215,7 @@ extern "C" int seqrec_opt_apply(int n_dense, float* const* params, float* const*
     if (!sq || !scale_out) return SEQREC_E_ARG;
     const unsigned gx = (unsigned)std::max<long>(n_dense ? 256 : 1, (maxn + 3) / 4);
     hipLaunchKernelGGL(opt_apply_kernel, dim3(gx, n_dense + n_jobs), dim3(256), 0, as_stream(stream), pl, sq, clipnorm, lr, eps,
-                       scale_out, zero_next);
+                       scale_out, zero_next, grad_div);
     SEQREC_LAUNCH_CHECK();
     return 0;
 }

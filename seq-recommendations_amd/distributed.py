@@ -23,9 +23,15 @@ routing plan covers input rows, target rows and the stratified negatives:
       forward   ONE all-to-all: [requested E rows | requested Eout rows | K/R negative rows | their ids]
       backward  ONE all-to-all of the matching row gradients (same routes reversed), one scatter list
       update    ONE all-reduce of [flat dense gradients | squared norm of the owned row gradients]
-No step contains a host synchronisation: the per-batch routing (counts, positions) is exchanged at
-upload time.  With D != H the tables keep separate widths and the step uses one exchange per table
-(seven collectives).
+No step contains a host synchronisation, and neither does batch upload: the routing of MANY batches
+(per-peer request counts, requested local rows) is exchanged by ShardedEngine.prepare() in two collectives
+and ONE device -> host copy for the whole group of batches (an epoch, or a window of the batch stream), all
+index arithmetic is host numpy and reaches the device as one blob per batch; the global token count rides in
+the update all-reduce and divides the gradients on the device (seqrec_opt_apply grad_div).  The dense all-reduce
+is issued asynchronously on a side stream / second communicator as soon as the weight gradients exist, so it
+runs under the row-gradient exchange, the scatter and the dX GEMM (BASELINE config 5: "grad all-reduce overlap");
+only two scalars (row-gradient norm, token count) are reduced on the critical path.  With D != H the tables keep
+separate widths and the step uses one exchange per table (seven collectives, per-batch planning).
 
 ``RowExchange`` is device-agnostic torch code (unit-tested with gloo on CPU, world size 2 and 3);
 ``ShardedEngine`` wires it to the HIP kernels.
@@ -60,10 +66,18 @@ class HostStagedDist:
                                  input_split_sizes=input_split_sizes)
         out.copy_(o)
 
-    def all_reduce(self, t, op=None, group=None):
+    class _Done:
+        def wait(self):
+            return True
+
+    def new_group(self, *a, **k):
+        return None                      # one gloo group: the staged transport is synchronous anyway
+
+    def all_reduce(self, t, op=None, group=None, async_op=False):
         c = t.detach().cpu()
         self.d.all_reduce(c, op=self.d.ReduceOp.SUM if op is None else op)
         t.copy_(c)
+        return HostStagedDist._Done() if async_op else None
 
     def all_gather(self, outs, t, group=None):
         cs = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
@@ -100,7 +114,7 @@ class SegPlan:
       own_extra int32[R,extra]  rows of the extras in the owner-side buffer
       back_src  int32[n_tot]  request index of every requester-side row (-1 at the extras)"""
     __slots__ = ("n", "extra", "n_tot", "m_tot", "req_split", "own_split", "req_pos", "req_extra", "own_rows",
-                 "own_extra", "back_src")
+                 "own_extra", "back_src", "host")
 
 
 class RowExchange:
@@ -178,6 +192,65 @@ class RowExchange:
         p.own_extra = (rc_end[:, None] + extra * ar_r[:, None] + ar_e[None, :]).to(torch.int32)
         return p
 
+    def plan_seg_many(self, reqs, extra=0):
+        """plan_seg for M batches at once: reqs = [(owner int array [n_b], want int array [n_b]), ...] (host numpy).
+        TWO collectives and ONE host synchronisation for all M batches instead of two + two per batch: the per-peer
+        request counts of every batch travel in one all-to-all (then one device -> host copy), the requested local
+        rows of every batch in a second one.  All index arithmetic is host numpy; each plan's tensors are created
+        on self.dev.  Returns the same SegPlan objects plan_seg would build batch by batch."""
+        R, dist, dev = self.R, self.dist, self.dev
+        M = len(reqs)
+        owners = [np.asarray(o, dtype=np.int64) for o, _ in reqs]
+        wants = [np.asarray(w, dtype=np.int32) for _, w in reqs]
+        perms = [np.argsort(o, kind="stable") for o in owners]
+        SC = np.stack([np.bincount(o, minlength=R) for o in owners]).astype(np.int64) if M else np.zeros((0, R), np.int64)
+        # counts: row j of the send matrix goes to peer j -> I receive, from peer i, its counts towards me per batch
+        sc_dev = torch.from_numpy(np.ascontiguousarray(SC.T)).to(dev)                    # [R, M]
+        rc_dev = torch.empty_like(sc_dev)
+        dist.all_to_all_single(rc_dev, sc_dev, group=self.group)
+        RC = rc_dev.cpu().numpy().T.copy()                                               # [M, R]   (the ONE host sync)
+        # wants: for peer j the concatenation over batches of the local rows I ask it for
+        segs = [[wants[b][perms[b]][SC[b, :j].sum():SC[b, :j + 1].sum()] for b in range(M)] for j in range(R)]
+        send = np.concatenate([x for j in range(R) for x in segs[j]]) if M else np.zeros(0, np.int32)
+        in_split = [int(SC[:, j].sum()) for j in range(R)]
+        out_split = [int(RC[:, i].sum()) for i in range(R)]
+        got_all = torch.empty(int(sum(out_split)), dtype=torch.int32, device=dev)
+        dist.all_to_all_single(got_all, torch.from_numpy(send.astype(np.int32)).to(dev), output_split_sizes=out_split,
+                               input_split_sizes=in_split, group=self.group)
+        peer_off = np.concatenate([[0], np.cumsum(out_split)])[:-1]                      # start of peer i's block in got_all
+        within = np.cumsum(RC, axis=0) - RC                                              # [M, R] offset of batch b inside peer i's block
+        plans = []
+        ar_e = np.arange(extra, dtype=np.int64)
+        for b in range(M):
+            n = owners[b].shape[0]
+            sc, rc = SC[b], RC[b]
+            m = int(rc.sum())
+            p = SegPlan()
+            p.n, p.extra = n, extra
+            p.req_split = [int(c) + extra for c in sc]
+            p.own_split = [int(c) + extra for c in rc]
+            p.n_tot, p.m_tot = n + R * extra, m + R * extra
+            perm = perms[b]
+            req_pos = np.empty(n, np.int64)
+            req_pos[perm] = np.arange(n) + extra * owners[b][perm]
+            sc_end, rc_end = np.cumsum(sc), np.cumsum(rc)
+            req_extra = sc_end[:, None] + extra * np.arange(R)[:, None] + ar_e[None, :]
+            back = np.full(p.n_tot, -1, np.int64)
+            back[req_pos] = np.arange(n)
+            seg = np.repeat(np.arange(R), rc)
+            own_pos = np.arange(m) + extra * seg                                         # rows of the requests in the owner-side buffer
+            src = np.concatenate([peer_off[i] + within[b, i] + np.arange(rc[i]) for i in range(R)]) if m else np.zeros(0, np.int64)
+            own_extra = rc_end[:, None] + extra * np.arange(R)[:, None] + ar_e[None, :]
+            i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+            p.req_pos, p.req_extra, p.back_src, p.own_extra = i32(req_pos), i32(req_extra), i32(back), i32(own_extra)
+            own_rows = torch.full((p.m_tot,), -1, dtype=torch.int32, device=dev)
+            if m:
+                own_rows[torch.from_numpy(own_pos).to(dev)] = got_all[torch.from_numpy(src).to(dev)]
+            p.own_rows = own_rows
+            p.host = dict(req_pos=req_pos, req_extra=req_extra, back=back, own_extra=own_extra)   # numpy copies for host-side derivations
+            plans.append(p)
+        return plans
+
     def fetch_seg(self, plan, rows):
         """rows [m_tot, w] in the owner-side layout -> [n_tot, w] in the requester-side layout."""
         out = torch.empty((plan.n_tot,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=self.dev)
@@ -253,13 +326,23 @@ class ShardedEngine(Engine):
         # gradients): the step's only all-reduce runs in place on it
         names = sorted(self.Gd)
         tot = sum(self.Gd[k].numel() for k in names)
-        self.gflat = torch.zeros(tot + 1, dtype=torch.float32, device=self.dev)
+        self.gflat = torch.zeros(tot + 2, dtype=torch.float32, device=self.dev)
         o = 0
         for k in names:
             nk = self.Gd[k].numel()
             self.Gd[k] = self.gflat[o:o + nk].view_as(self.Gd[k])
             o += nk
+        self.n_dense = tot
         self.sq = self.gflat[tot:tot + 1]
+        self.ntok = self.gflat[tot + 1:tot + 2]      # global token count of the step (after the all-reduce)
+        # the dense all-reduce runs on its own stream and (RCCL) its own communicator, under the row-gradient exchange
+        self.side = torch.cuda.Stream(device=self.dev)
+        self.dense_group = group
+        if self.R > 1 and hasattr(dist, "new_group"):
+            g2 = dist.new_group()
+            if g2 is not None:
+                self.dense_group = g2
+        self._dense_work = None
         # unified item table: E rows then Eout rows in one allocation (same padded width)
         self.unified = self.Dp == self.Hp
         if self.unified:
@@ -309,41 +392,67 @@ class ShardedEngine(Engine):
             for j in range(R):
                 g[j::R] = allq[j][: shard_size(self.V_global, j, R)]
             self.logq_global = g
+            self.logq_global_host = g.cpu().numpy()
 
     def upload(self, rb):
-        d = Engine.upload(self, rb)
-        c, R, n = self.cfg, self.R, d["n"]
-        if n == 0:
-            raise ValueError("ShardedEngine: every rank needs at least one transition per step (collectives are unconditional)")
-        nt = torch.tensor([n], dtype=torch.float64, device=self.dev)
-        self.dist.all_reduce(nt, group=self.group)
-        d["n_total"] = float(nt.item())
-        if c.logq and self.logq_global is not None:
-            d["lq_tgt"] = self.logq_global[d["tgt"].long()]         # fixed per batch
-        d["arange"] = torch.arange(n, device=self.dev, dtype=torch.int32)
+        return self.prepare([rb])[0]
+
+    def prepare(self, rbs):
+        """Host RaggedBatches -> device batches incl. their routing.  Collective.  For the unified tables (every
+        BASELINE config) the routing of ALL the batches costs two collectives and one device -> host copy
+        (RowExchange.plan_seg_many), every derived index array is host numpy and one int32 blob per batch crosses
+        PCIe: call it with an epoch's -- or a window's -- worth of batches and no training step waits for the host."""
+        c, R = self.cfg, self.R
+        ds = [Engine.upload(self, rb) for rb in rbs]
+        for d in ds:
+            if d["n"] == 0:
+                raise ValueError("ShardedEngine: every rank needs at least one transition per step (collectives are unconditional)")
         if not self.unified:
-            d["plan_in"] = self.ex.plan(d["ids"])
-            d["plan_tgt"] = self.ex.plan(d["tgt"])
-            return d
+            for d in ds:
+                n = d["n"]
+                nt = torch.tensor([n], dtype=torch.float64, device=self.dev)
+                self.dist.all_reduce(nt, group=self.group)
+                d["n_total"] = float(nt.item())
+                if c.logq and self.logq_global is not None:
+                    d["lq_tgt"] = self.logq_global[d["tgt"].long()]         # fixed per batch
+                d["arange"] = torch.arange(n, device=self.dev, dtype=torch.int32)
+                d["plan_in"] = self.ex.plan(d["ids"])
+                d["plan_tgt"] = self.ex.plan(d["tgt"])
+            return ds
         # ---- unified routing: requests = [input rows ; target rows], extras = Kr negatives + id rows
         w, Kr = self.Hp, c.K // R
         nid = -(-Kr // w)                                            # rows that carry the negatives' ids
-        ids, tgt = d["ids"].long(), d["tgt"].long()
-        o_in, o_tg = ids % R, tgt % R
-        off = torch.zeros_like(o_tg) if c.tied else (self.gcfg.V_in - o_tg + R - 1) // R     # E rows held by the owner
-        plan = self.ex.plan_seg(torch.cat([o_in, o_tg]), torch.cat([ids // R, tgt // R + off]), extra=Kr + nid)
-        d["plan"] = plan
-        i32 = lambda t: t.to(torch.int32).contiguous()
-        q = torch.arange(Kr, device=self.dev)
-        d["send_idx"] = plan.own_rows.clone()                        # negatives' rows are written per step
-        d["neg_slots"] = i32(plan.own_extra[:, :Kr].reshape(-1))
-        d["id_slots"] = i32((plan.own_extra.long()[:, Kr + q // w] * w + (q % w)[None, :]).reshape(-1))
-        d["take_idx"] = i32(torch.cat([plan.req_pos.long(), plan.req_extra.long()[:, :Kr].reshape(-1)]))
-        d["negid_idx"] = i32((plan.req_extra.long()[:, Kr + q // w] * w + (q % w)[None, :]).reshape(-1))
-        back = plan.back_src.clone().long()
-        back[plan.req_extra.long()[:, :Kr].reshape(-1)] = 2 * n + torch.arange(R * Kr, device=self.dev)
-        d["back_idx"] = i32(back)
-        return d
+        reqs = []
+        for rb in rbs:
+            ids, tgt = rb.ids.astype(np.int64), rb.tgt.astype(np.int64)
+            o_in, o_tg = ids % R, tgt % R
+            off = np.zeros_like(o_tg) if c.tied else (self.gcfg.V_in - o_tg + R - 1) // R     # E rows held by the owner
+            reqs.append((np.concatenate([o_in, o_tg]), np.concatenate([ids // R, tgt // R + off])))
+        plans = self.ex.plan_seg_many(reqs, extra=Kr + nid)
+        q = np.arange(Kr)
+        for d, rb, plan in zip(ds, rbs, plans):
+            n, h = d["n"], plan.host
+            oe, re_ = h["own_extra"], h["req_extra"]
+            neg_slots = oe[:, :Kr].reshape(-1)
+            id_slots = (oe[:, Kr + q // w] * w + (q % w)[None, :]).reshape(-1)
+            take_idx = np.concatenate([h["req_pos"], re_[:, :Kr].reshape(-1)])
+            negid_idx = (re_[:, Kr + q // w] * w + (q % w)[None, :]).reshape(-1)
+            back = h["back"].copy()
+            back[re_[:, :Kr].reshape(-1)] = 2 * n + np.arange(R * Kr)
+            parts = [neg_slots, id_slots, take_idx, negid_idx, back, np.arange(n)]
+            if c.logq and self.logq_global is not None:
+                parts.append(self.logq_global_host[rb.tgt].view(np.int32))
+            blob = torch.from_numpy(np.concatenate([np.asarray(x, dtype=np.int32) for x in parts])).to(self.dev, non_blocking=True)
+            o = 0
+            for name, x in zip(("neg_slots", "id_slots", "take_idx", "negid_idx", "back_idx", "arange"), parts):
+                d[name] = blob[o:o + len(x)]
+                o += len(x)
+            if len(parts) > 6:
+                d["lq_tgt"] = blob[o:o + n].view(torch.float32)
+            d["plan"] = plan
+            d["send_idx"] = plan.own_rows                                # negatives' rows are written per step
+            d["route_blob"] = blob
+        return ds
 
     # ---- one training step ----------------------------------------------------------------------------
     def train_step(self, d, lr=0.01, eps=1e-8, clipnorm=1.0, step=None, negatives=None, apply_update=True):
@@ -354,13 +463,15 @@ class ShardedEngine(Engine):
             return self._step_unified(d, lr, eps, clipnorm, step, apply_update)
         return self._step_split(d, lr, eps, clipnorm, step, apply_update)
 
-    def _cell_and_loss(self, d, X, Etgt, Eneg, neg, dX, dEtgt, dEneg, train=True):
+    def _cell_and_loss(self, d, X, Etgt, Eneg, neg, dX, dEtgt, dEneg, train=True, reduce_dense=True):
         """Everything between the two exchanges: x.W, scan, sampled softmax CE, BPTT, dense weight
         gradients; writes the three row-gradient blocks."""
         c, P = self.cfg, self.P
         st = self._stream()
         n, Hp, GHp, Dp, K = d["n"], self.Hp, self.GHp, self.Dp, c.K
-        inv = 1.0 / d["n_total"]
+        # unified path: gradients are left as SUMS; the global token count is only known on the device after the update's
+        # all-reduce and divides them there (seqrec_opt_apply grad_div) -- no host round trip per batch
+        inv = 1.0 / d["n_total"] if "n_total" in d else 1.0
         Gd = self.Gd
         lq_neg = None
         if c.logq:
@@ -402,23 +513,60 @@ class ShardedEngine(Engine):
         sk = int(max(1, min(32, -(-SPLITK_TARGET_WGS // max(tiles, 1)), n // 128)))
         wsp = self.buf("gemm_ws", sum(sk * w_[0] * w_[1] for w_ in wgrad)) if sk > 1 else None
         call("seqrec_gemm_f32_grouped", len(wgrad), 0, 0, _lib.gemm_descs(wgrad), sk, ptr(wsp), st, tag="dW+dU")
+        if self.unified and reduce_dense:
+            self._start_dense_allreduce()        # the dense gradients are final: reduce them under everything that follows
         self.gemm(1, 1, n, Dp, GHp, dPre, GHp, P["W"], GHp, dX, Dp, splitk=self._splitk(n, Dp, GHp), tag="dX")
 
-    def _dense_update(self, lr, eps, clipnorm, rows_job=None):
-        """After the owned row norms were added into self.sq: ONE all-reduce of [dense grads | sq],
-        dense norms on top (identical on every rank), then ONE launch for the Keras clip scale, the dense
-        Adagrad and (rows_job = (jobs array, count)) the row-sparse Adagrad of the owned rows."""
+    def _start_dense_allreduce(self):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            self._dense_work = self.dist.all_reduce(self.gflat[: self.n_dense], group=self.dense_group, async_op=True)
+
+    def _dense_update(self, lr, eps, clipnorm, rows_job=None, n_local=None):
+        """After the owned row norms were added into self.sq.  Unified path (n_local given): the dense gradients are
+        already being reduced on the side stream (_start_dense_allreduce); only [row-gradient norm, token count] is
+        reduced here, then the dense norms go on top (identical on every rank) and ONE launch applies the Keras clip
+        scale, the 1 / token-count division, the dense Adagrad and (rows_job = (jobs array, count)) the row-sparse
+        Adagrad of the owned rows.  Split path: one all-reduce of [dense grads | sq]."""
         st = self._stream()
         P, Gd = self.P, self.Gd
-        self.dist.all_reduce(self.gflat, group=self.group)
+        div = None
+        if n_local is not None:
+            call("seqrec_fill_f32", ptr(self.ntok), float(n_local), 1, st)
+            self.dist.all_reduce(self.gflat[self.n_dense:], group=self.group)
+            if self._dense_work is not None:
+                self._dense_work.wait()
+                self._dense_work = None
+            torch.cuda.current_stream(self.dev).wait_stream(self.side)
+            div = self.ntok
+        else:
+            self.dist.all_reduce(self.gflat[: self.n_dense + 1], group=self.group)
         dk = sorted(Gd)
         gp = _lib.ptr_array([Gd[k] for k in dk])
         nn = _lib.i64_array([Gd[k].numel() for k in dk])
         call("seqrec_sqnorm_multi", len(dk), gp, nn, ptr(self.sq), st)
         arr, cnt = rows_job if rows_job is not None else (None, 0)
         call("seqrec_opt_apply", len(dk), _lib.ptr_array([P[k] for k in dk]), _lib.ptr_array([self.A[k] for k in dk]), gp, nn,
-             arr, cnt, ptr(self.sq), float(clipnorm if clipnorm else 0.0), lr, eps, ptr(self.scale), None, st)
+             arr, cnt, ptr(self.sq), float(clipnorm if clipnorm else 0.0), lr, eps, ptr(self.scale), None, ptr(div), st)
         self.upack_dirty = True
+
+    def grads(self, d, step=0, negatives=None):
+        """Test hook (Engine.grads): this rank's loss and gradient CONTRIBUTIONS, normalised by the global token count
+        like the trained quantities (the unified step keeps sums and divides on the device in the update)."""
+        loss, out = Engine.grads(self, d, step=step, negatives=negatives)
+        if self.unified:
+            nt = float(self._global_tokens(d).item())
+            loss = float(self.loss_sum.item()) * self.R / nt
+            out = {k: v / np.float32(nt) for k, v in out.items()}
+        return loss, out
+
+    def _global_tokens(self, d):
+        """Device scalar: the step's token count summed over the ranks (evaluation paths; no host sync)."""
+        nt = torch.full((1,), float(d["n"]), dtype=torch.float32, device=self.dev)
+        self.dist.all_reduce(nt, group=self.group)
+        return nt
 
     def _rows_in(self, d, step):
         """Forward exchange of the unified path (collective 1): -> (xen [2n + K, w] = input rows, target
@@ -451,7 +599,7 @@ class ShardedEngine(Engine):
         n = d["n"]
         xen, neg = self._rows_in(d, step)
         self._cell_and_loss(d, xen[:n], xen[n:2 * n], xen[2 * n:], neg, None, None, None, train=False)
-        return self.loss_sum * (self.R / d["n_total"])
+        return self.loss_sum * float(self.R) / self._global_tokens(d)
 
     def rank_counts(self, d):
         """Global rank of every target of THIS rank's tokens (Recall@K = mean(rank < K)): hidden rows and
@@ -562,7 +710,8 @@ class ShardedEngine(Engine):
         send_idx = d["send_idx"]
         xen, neg = self._rows_in(d, step)
         gall = self.buf("gall", 2 * n + K, w)
-        self._cell_and_loss(d, xen[:n], xen[n:2 * n], xen[2 * n:], neg, gall[:n], gall[n:2 * n], gall[2 * n:])
+        self._cell_and_loss(d, xen[:n], xen[n:2 * n], xen[2 * n:], neg, gall[:n], gall[n:2 * n], gall[2 * n:],
+                            reduce_dense=apply_update)
         # -- row gradients travel the same routes back; one scatter list into the unified gradient table
         backbuf = self.buf("backbuf", plan.n_tot, w)
         self._take(gall, d["back_idx"], backbuf)
@@ -574,8 +723,8 @@ class ShardedEngine(Engine):
             return None
         call("seqrec_fill_f32", ptr(self.sq), 0.0, 1, st)
         call("seqrec_rows_sqnorm_multi", job, cnt, ptr(self.sq), st)
-        self._dense_update(lr, eps, clipnorm, (job, cnt))                       # collective 3
-        return self.loss_sum * (self.R / d["n_total"])      # this rank's share, scaled so the mean over ranks is the global loss
+        self._dense_update(lr, eps, clipnorm, (job, cnt), n_local=n)            # collective 3 (+ the overlapped dense one)
+        return self.loss_sum * float(self.R) / self.ntok    # this rank's share, scaled so the mean over ranks is the global loss
 
     def _step_split(self, d, lr, eps, clipnorm, step, apply_update):
         """D != H: the two tables have different row widths, one exchange per table."""

@@ -851,7 +851,7 @@ class Engine:
                 call("seqrec_opt_sqnorm", len(dk), gp, nn, arr, cnt, ptr(cur), ptr(lrows), n, ptr(self.loss_out), st)
             call("seqrec_opt_apply", len(dk), _lib.ptr_array([P[k] for k in dk]) if dk else None,
                  _lib.ptr_array([self.A[k] for k in dk]) if dk else None, gp, nn, arr, cnt, ptr(cur), clip, lr, eps,
-                 ptr(self.scale), ptr(nxt), st)
+                 ptr(self.scale), ptr(nxt), None, st)
             self._sq_par ^= 1
             self.sq = cur
         else:

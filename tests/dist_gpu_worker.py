@@ -57,8 +57,10 @@ def main():
             per_rank = [make_sessions(data_rng, 24 + 5 * r, V, 2, 10) for r in range(R)]
             steps.append(per_rank)
         losses = []
+        # both steps' batches are routed at once: two collectives + one host sync for the whole window (ShardedEngine.prepare)
+        prepared = eng.prepare([Bt.pack_sessions(per_rank[rank]) for per_rank in steps])
         for s, per_rank in enumerate(steps):
-            d = eng.upload(Bt.pack_sessions(per_rank[rank]))
+            d = prepared[s]
             if eng.unified and s == 0:
                 ev = float(eng.eval_loss(d, step=s).item())          # forward only, same negatives, same weights
             l = eng.train_step(d, lr=0.01, eps=1e-8, clipnorm=1.0, step=s)

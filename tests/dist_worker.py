@@ -74,6 +74,29 @@ def seg_plan_checks(D, ex, E, rank, R):
         assert torch.allclose(acc[nE:], D.shard_rows(refF2, rank, R), atol=1e-12), "push_seg F mismatch (case %d)" % case
 
 
+def many_plan_checks(D, ex, rank, R):
+    """plan_seg_many (two collectives + one host sync for M batches, host index arithmetic) must build exactly the
+    plans plan_seg builds batch by batch -- including an empty request list and an owner nobody asks."""
+    import numpy as np
+    gr = np.random.default_rng(500 + rank)
+    V = 997
+    reqs = []
+    for b in range(5):
+        n = 0 if (b == 3 and rank == R - 1) else int(gr.integers(20, 90))
+        ids = gr.integers(0, V, size=n)
+        if b == 1:
+            ids = ids // R * R                     # everything goes to owner 0
+        reqs.append((ids % R, (ids // R).astype(np.int32)))
+    for extra in (0, 4):
+        many = ex.plan_seg_many(reqs, extra=extra)
+        for (o, w), pm in zip(reqs, many):
+            ps = ex.plan_seg(torch.from_numpy(o), torch.from_numpy(w), extra=extra)
+            assert (pm.n, pm.extra, pm.n_tot, pm.m_tot) == (ps.n, ps.extra, ps.n_tot, ps.m_tot)
+            assert pm.req_split == ps.req_split and pm.own_split == ps.own_split
+            for f in ("req_pos", "req_extra", "own_rows", "own_extra", "back_src"):
+                assert torch.equal(getattr(pm, f).long(), getattr(ps, f).long()), (f, extra)
+
+
 def main():
     dist.init_process_group("gloo")
     rank, R = dist.get_rank(), dist.get_world_size()
@@ -116,6 +139,7 @@ def main():
             ref.index_add_(0, i, gg)
         assert torch.allclose(gshard, D.shard_rows(ref, rank, R), atol=1e-12), "push mismatch (case %d)" % case
     seg_plan_checks(D, ex, E, rank, R)
+    many_plan_checks(D, ex, rank, R)
     x = torch.arange(R * 3, dtype=torch.float32).view(R, 3) + 100 * rank
     y = ex.swap_fixed(x)
     for i in range(R):

@@ -311,7 +311,8 @@ def test_bench_single_gpu_line_carries_cpu_baseline_and_parity():
 
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_engine_ranks_share_one_gpu_vs_global_oracle(world):
-    """2 / 4 processes share cuda:0 (collectives staged through gloo) and train the row-sharded model
+    """2 / 4 processes (the GPU box kills a run with more than 6 processes on its card -- 4 ranks + this test
+    process is the most that fits; the 8-rank routing itself runs on CPU in test_distributed_cpu.py) share cuda:0 (collectives staged through gloo) and train the row-sharded model
     for two steps; rank 0 checks global loss, replicated weights and every table shard against the
     oracle run on the global model with the same stratified negatives, plus the sharded eval loss
     and Recall@K rank counting (tests/dist_gpu_worker.py)."""

@@ -403,7 +403,7 @@ def test_fused_optimizer_launches_equal_the_separate_kernels():
         scale = torch.zeros(1, device="cuda")
         if fused:
             call("seqrec_opt_sqnorm", len(sizes), gp, nn, arr, cnt, ptr(sq[0:1]), None, 0, None, st())
-            call("seqrec_opt_apply", len(sizes), pp, ap, gp, nn, arr, cnt, ptr(sq[0:1]), 0.05, 0.01, 1e-8, ptr(scale), ptr(sq[1:2]), st())
+            call("seqrec_opt_apply", len(sizes), pp, ap, gp, nn, arr, cnt, ptr(sq[0:1]), 0.05, 0.01, 1e-8, ptr(scale), ptr(sq[1:2]), None, st())
             assert sq[1].item() == 0.0                       # the other norm slot was cleared for the next step
         else:
             call("seqrec_sqnorm_multi", len(sizes), gp, nn, ptr(sq[0:1]), st())
