@@ -430,10 +430,11 @@ def main(argv=None):
         if resident:
             d = resident[i % len(resident)]
         elif sharded:
-            if i not in window:
-                window.clear()
-                rbs = [Bt.pack_flat(flat, starts, stream.sel(j)) for j in range(i, i + WINDOW)]
-                window.update(zip(range(i, i + WINDOW), eng.prepare(rbs)))
+            # the next WINDOW batches are routed while the GPU still has half a window of steps queued
+            if i not in window or (i + WINDOW // 2) not in window:
+                lo = max(window) + 1 if window else i
+                rbs = [Bt.pack_flat(flat, starts, stream.sel(j)) for j in range(lo, lo + WINDOW)]
+                window.update(zip(range(lo, lo + WINDOW), eng.prepare(rbs)))
             d = window.pop(i)
         else:
             d = eng.upload_device(ds, stream.sel(i))

@@ -114,7 +114,7 @@ class SegPlan:
       own_extra int32[R,extra]  rows of the extras in the owner-side buffer
       back_src  int32[n_tot]  request index of every requester-side row (-1 at the extras)"""
     __slots__ = ("n", "extra", "n_tot", "m_tot", "req_split", "own_split", "req_pos", "req_extra", "own_rows",
-                 "own_extra", "back_src", "host")
+                 "own_extra", "back_src", "host", "got_pad")
 
 
 class RowExchange:
@@ -192,13 +192,16 @@ class RowExchange:
         p.own_extra = (rc_end[:, None] + extra * ar_r[:, None] + ar_e[None, :]).to(torch.int32)
         return p
 
-    def plan_seg_many(self, reqs, extra=0):
+    def plan_seg_many(self, reqs, extra=0, device_fields=True, group="default"):
         """plan_seg for M batches at once: reqs = [(owner int array [n_b], want int array [n_b]), ...] (host numpy).
         TWO collectives and ONE host synchronisation for all M batches instead of two + two per batch: the per-peer
         request counts of every batch travel in one all-to-all (then one device -> host copy), the requested local
         rows of every batch in a second one.  All index arithmetic is host numpy; each plan's tensors are created
-        on self.dev.  Returns the same SegPlan objects plan_seg would build batch by batch."""
+        on self.dev.  Returns the same SegPlan objects plan_seg would build batch by batch.  device_fields=False leaves
+        the index tensors to the caller (plan.host holds them as numpy, plan.got_pad the received rows + a -1 sentinel:
+        own_rows = got_pad[host['own_src']]), so that ONE blob per batch crosses PCIe (ShardedEngine.prepare)."""
         R, dist, dev = self.R, self.dist, self.dev
+        grp = self.group if isinstance(group, str) else group          # planning may run on its own communicator
         M = len(reqs)
         owners = [np.asarray(o, dtype=np.int64) for o, _ in reqs]
         wants = [np.asarray(w, dtype=np.int32) for _, w in reqs]
@@ -207,7 +210,7 @@ class RowExchange:
         # counts: row j of the send matrix goes to peer j -> I receive, from peer i, its counts towards me per batch
         sc_dev = torch.from_numpy(np.ascontiguousarray(SC.T)).to(dev)                    # [R, M]
         rc_dev = torch.empty_like(sc_dev)
-        dist.all_to_all_single(rc_dev, sc_dev, group=self.group)
+        dist.all_to_all_single(rc_dev, sc_dev, group=grp)
         RC = rc_dev.cpu().numpy().T.copy()                                               # [M, R]   (the ONE host sync)
         # wants: for peer j the concatenation over batches of the local rows I ask it for
         segs = [[wants[b][perms[b]][SC[b, :j].sum():SC[b, :j + 1].sum()] for b in range(M)] for j in range(R)]
@@ -216,7 +219,8 @@ class RowExchange:
         out_split = [int(RC[:, i].sum()) for i in range(R)]
         got_all = torch.empty(int(sum(out_split)), dtype=torch.int32, device=dev)
         dist.all_to_all_single(got_all, torch.from_numpy(send.astype(np.int32)).to(dev), output_split_sizes=out_split,
-                               input_split_sizes=in_split, group=self.group)
+                               input_split_sizes=in_split, group=grp)
+        got_pad = torch.cat([got_all, torch.full((1,), -1, dtype=torch.int32, device=dev)])
         peer_off = np.concatenate([[0], np.cumsum(out_split)])[:-1]                      # start of peer i's block in got_all
         within = np.cumsum(RC, axis=0) - RC                                              # [M, R] offset of batch b inside peer i's block
         plans = []
@@ -241,13 +245,17 @@ class RowExchange:
             own_pos = np.arange(m) + extra * seg                                         # rows of the requests in the owner-side buffer
             src = np.concatenate([peer_off[i] + within[b, i] + np.arange(rc[i]) for i in range(R)]) if m else np.zeros(0, np.int64)
             own_extra = rc_end[:, None] + extra * np.arange(R)[:, None] + ar_e[None, :]
-            i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
-            p.req_pos, p.req_extra, p.back_src, p.own_extra = i32(req_pos), i32(req_extra), i32(back), i32(own_extra)
-            own_rows = torch.full((p.m_tot,), -1, dtype=torch.int32, device=dev)
-            if m:
-                own_rows[torch.from_numpy(own_pos).to(dev)] = got_all[torch.from_numpy(src).to(dev)]
-            p.own_rows = own_rows
-            p.host = dict(req_pos=req_pos, req_extra=req_extra, back=back, own_extra=own_extra)   # numpy copies for host-side derivations
+            # owner-side rows as ONE gather index into [got_all | -1]: requests take their received local row, extras -1
+            own_src = np.full(p.m_tot, got_all.numel(), np.int64)
+            own_src[own_pos] = src
+            p.host = dict(req_pos=req_pos, req_extra=req_extra, back=back, own_extra=own_extra, own_src=own_src)
+            if device_fields:
+                i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+                p.req_pos, p.req_extra, p.back_src, p.own_extra = i32(req_pos), i32(req_extra), i32(back), i32(own_extra)
+                p.own_rows = got_pad[torch.from_numpy(own_src).to(dev)]
+            else:
+                p.req_pos = p.req_extra = p.back_src = p.own_extra = p.own_rows = None
+            p.got_pad = got_pad
             plans.append(p)
         return plans
 
@@ -320,6 +328,8 @@ class ShardedEngine(Engine):
         local = dataclasses.replace(cfg, V_in=shard_size(cfg.V_in, self.rank, self.R),
                                     V_out=shard_size(cfg.V_out, self.rank, self.R))
         Engine.__init__(self, local, device)
+        # (hipGraph replay of the scan, SEQREC_SCAN_GRAPH=1, was measured for this engine too: 1.27 against 1.19 ms per step
+        # in steady state on one rank -- the device-side step-table lookups cost more than the saved host time)
         self.gcfg = cfg
         self.ex = RowExchange(dist, group, self.dev)
         # dense gradients live in ONE flat buffer (+1 slot for the squared norm of the owned row
@@ -343,6 +353,14 @@ class ShardedEngine(Engine):
             if g2 is not None:
                 self.dense_group = g2
         self._dense_work = None
+        # batch routing is planned on a third stream / communicator: ShardedEngine.prepare() then waits only for its own
+        # two tiny collectives, not for the training steps already queued, and its host arithmetic overlaps them
+        self.plan_stream = torch.cuda.Stream(device=self.dev)
+        self.plan_group = group
+        if self.R > 1 and hasattr(dist, "new_group"):
+            g3 = dist.new_group()
+            if g3 is not None:
+                self.plan_group = g3
         # unified item table: E rows then Eout rows in one allocation (same padded width)
         self.unified = self.Dp == self.Hp
         if self.unified:
@@ -403,10 +421,10 @@ class ShardedEngine(Engine):
         (RowExchange.plan_seg_many), every derived index array is host numpy and one int32 blob per batch crosses
         PCIe: call it with an epoch's -- or a window's -- worth of batches and no training step waits for the host."""
         c, R = self.cfg, self.R
-        ds = [Engine.upload(self, rb) for rb in rbs]
-        for d in ds:
-            if d["n"] == 0:
+        for rb in rbs:
+            if rb.n_tok == 0:
                 raise ValueError("ShardedEngine: every rank needs at least one transition per step (collectives are unconditional)")
+        ds = [Engine.upload(self, rb) for rb in rbs] if not self.unified else None
         if not self.unified:
             for d in ds:
                 n = d["n"]
@@ -420,6 +438,19 @@ class ShardedEngine(Engine):
                 d["plan_tgt"] = self.ex.plan(d["tgt"])
             return ds
         # ---- unified routing: requests = [input rows ; target rows], extras = Kr negatives + id rows
+        main = torch.cuda.current_stream(self.dev)
+        with torch.cuda.stream(self.plan_stream):
+            ds = self._prepare_unified(rbs)
+            ready = torch.cuda.Event()
+            ready.record(self.plan_stream)
+        for d in ds:
+            d["ready"] = ready
+            for t in (d["blob"], d["send_idx"]):
+                t.record_stream(main)            # allocated on the planning stream, consumed on the training stream
+        return ds
+
+    def _prepare_unified(self, rbs):
+        c, R = self.cfg, self.R
         w, Kr = self.Hp, c.K // R
         nid = -(-Kr // w)                                            # rows that carry the negatives' ids
         reqs = []
@@ -428,30 +459,33 @@ class ShardedEngine(Engine):
             o_in, o_tg = ids % R, tgt % R
             off = np.zeros_like(o_tg) if c.tied else (self.gcfg.V_in - o_tg + R - 1) // R     # E rows held by the owner
             reqs.append((np.concatenate([o_in, o_tg]), np.concatenate([ids // R, tgt // R + off])))
-        plans = self.ex.plan_seg_many(reqs, extra=Kr + nid)
+        plans = self.ex.plan_seg_many(reqs, extra=Kr + nid, device_fields=False, group=self.plan_group)
         q = np.arange(Kr)
-        for d, rb, plan in zip(ds, rbs, plans):
-            n, h = d["n"], plan.host
+        ds = []
+        for rb, plan in zip(rbs, plans):
+            n, h = rb.n_tok, plan.host
             oe, re_ = h["own_extra"], h["req_extra"]
-            neg_slots = oe[:, :Kr].reshape(-1)
-            id_slots = (oe[:, Kr + q // w] * w + (q % w)[None, :]).reshape(-1)
-            take_idx = np.concatenate([h["req_pos"], re_[:, :Kr].reshape(-1)])
-            negid_idx = (re_[:, Kr + q // w] * w + (q % w)[None, :]).reshape(-1)
             back = h["back"].copy()
             back[re_[:, :Kr].reshape(-1)] = 2 * n + np.arange(R * Kr)
-            parts = [neg_slots, id_slots, take_idx, negid_idx, back, np.arange(n)]
+            parts = [("step_off", rb.step_off), ("prev", rb.prev), ("ids", rb.ids), ("tgt", rb.tgt),
+                     ("neg_slots", oe[:, :Kr].reshape(-1)),
+                     ("id_slots", (oe[:, Kr + q // w] * w + (q % w)[None, :]).reshape(-1)),
+                     ("take_idx", np.concatenate([h["req_pos"], re_[:, :Kr].reshape(-1)])),
+                     ("negid_idx", (re_[:, Kr + q // w] * w + (q % w)[None, :]).reshape(-1)),
+                     ("back_idx", back), ("arange", np.arange(n)), ("own_src", h["own_src"])]
             if c.logq and self.logq_global is not None:
-                parts.append(self.logq_global_host[rb.tgt].view(np.int32))
-            blob = torch.from_numpy(np.concatenate([np.asarray(x, dtype=np.int32) for x in parts])).to(self.dev, non_blocking=True)
+                parts.append(("lq_tgt", self.logq_global_host[rb.tgt].view(np.int32)))
+            # everything the step needs from the host in ONE int32 blob: the batch's index arrays and its routing
+            blob = torch.from_numpy(np.concatenate([np.asarray(x, dtype=np.int32) for _, x in parts])).to(self.dev, non_blocking=True)
+            d = {"n": n, "T": rb.T, "B": rb.B, "rb": rb, "blob": blob, "plan": plan}
             o = 0
-            for name, x in zip(("neg_slots", "id_slots", "take_idx", "negid_idx", "back_idx", "arange"), parts):
+            for name, x in parts:
                 d[name] = blob[o:o + len(x)]
                 o += len(x)
-            if len(parts) > 6:
-                d["lq_tgt"] = blob[o:o + n].view(torch.float32)
-            d["plan"] = plan
-            d["send_idx"] = plan.own_rows                                # negatives' rows are written per step
-            d["route_blob"] = blob
+            if "lq_tgt" in d:
+                d["lq_tgt"] = d["lq_tgt"].view(torch.float32)
+            d["send_idx"] = plan.got_pad[d.pop("own_src").long()]       # owner-side local rows (-1 at the extras; negatives written per step)
+            ds.append(d)
         return ds
 
     # ---- one training step ----------------------------------------------------------------------------
@@ -459,6 +493,7 @@ class ShardedEngine(Engine):
         if step is None:
             step = self.step_count
         self.step_count = step + 1
+        self._wait_ready(d)
         if self.unified:
             return self._step_unified(d, lr, eps, clipnorm, step, apply_update)
         return self._step_split(d, lr, eps, clipnorm, step, apply_update)
@@ -562,6 +597,11 @@ class ShardedEngine(Engine):
             out = {k: v / np.float32(nt) for k, v in out.items()}
         return loss, out
 
+    def _wait_ready(self, d):
+        ev = d.get("ready")
+        if ev is not None:
+            torch.cuda.current_stream(self.dev).wait_event(ev)     # the batch's routing was produced on the planning stream
+
     def _global_tokens(self, d):
         """Device scalar: the step's token count summed over the ranks (evaluation paths; no host sync)."""
         nt = torch.full((1,), float(d["n"]), dtype=torch.float32, device=self.dev)
@@ -597,6 +637,7 @@ class ShardedEngine(Engine):
         if not self.unified:
             raise NotImplementedError("sharded evaluation needs the unified tables (D == H)")
         n = d["n"]
+        self._wait_ready(d)
         xen, neg = self._rows_in(d, step)
         self._cell_and_loss(d, xen[:n], xen[n:2 * n], xen[2 * n:], neg, None, None, None, train=False)
         return self.loss_sum * float(self.R) / self._global_tokens(d)
@@ -609,6 +650,7 @@ class ShardedEngine(Engine):
             raise NotImplementedError("sharded evaluation needs the unified tables (D == H)")
         c, R, st = self.cfg, self.R, self._stream()
         n, w = d["n"], self.Hp
+        self._wait_ready(d)
         xen, _ = self._rows_in(d, 0)
         Hd = self._hidden(d, xen[:n])
         thr = self.buf("thr", n)
@@ -650,6 +692,7 @@ class ShardedEngine(Engine):
             raise ValueError("1 <= k <= 64")
         c, R, st = self.cfg, self.R, self._stream()
         n, w = d["n"], self.Hp
+        self._wait_ready(d)
         xen, _ = self._rows_in(d, 0)
         Hd = self._hidden(d, xen[:n])
         if rows is not None:

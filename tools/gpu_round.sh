@@ -27,6 +27,7 @@ prof) root=$PWD; cd /tmp; export TMPDIR=/tmp; P=$root/$out/prof; mkdir -p $P
 kernarg) HIP_FORCE_DEV_KERNARG=1 TMO=400 run bench_kernarg1 python bench.py --gpus 1 --steps 200 --warmup 20 --cpu-seconds 0 --recall-steps 0; tail -c 300 $out/bench_kernarg1.log
    HIP_FORCE_DEV_KERNARG=0 TMO=400 run bench_kernarg0 python bench.py --gpus 1 --steps 200 --warmup 20 --cpu-seconds 0 --recall-steps 0; tail -c 300 $out/bench_kernarg0.log;;
 sharded) TMO=400 run bench_sharded python bench.py --gpus 1 --steps 200 --warmup 20 --cpu-seconds 0 --recall-steps 200 --force-sharded; tail -c 400 $out/bench_sharded.log;;
+hostprof) TMO=300 run hostprof python tools/host_profile.py; head -50 $out/hostprof.log; TMO=300 run hostprof_sh python tools/host_profile.py sharded; head -60 $out/hostprof_sh.log;;
 dbgtopk) TMO=300 run dbgtopk python tools/debug_topk.py c5; cat $out/dbgtopk.log;;
 trace) root=$PWD; cd /tmp; export TMPDIR=/tmp
    timeout -k 10 300 rocprofv3 --hip-trace --kernel-trace --output-format csv -d $root/$out/trace -- python3 $root/tools/stall_probe.py 8 > $root/$out/trace.log 2>&1; echo "trace rc=$?"

@@ -10,23 +10,43 @@ Sy = importlib.import_module("seq-recommendations_amd.synthetic")
 Sm = importlib.import_module("seq-recommendations_amd.sampling")
 cd = bench.CONFIGS["c3"]; V = cd["V"]
 cfg = E.NetConfig(cell="gru", act="relu", H=256, V_in=V, V_out=V, input="embed", D=256, output="sampled", K=2000, logq=True, seed=1)
-eng = E.Engine(cfg)
+SH = len(sys.argv) > 1 and sys.argv[1] == "sharded"
+if SH:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29591")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    Dm = importlib.import_module("seq-recommendations_amd.distributed")
+    Bt = importlib.import_module("seq-recommendations_amd.batching")
+    eng = Dm.ShardedEngine(cfg, "cuda:0", dist)
+else:
+    eng = E.Engine(cfg)
 bench.init_params_device(eng, cd, 1)
 gen = Sy.SyntheticSessions(V, seed=1234)
 p = Sm.log_uniform_probs(V, gen.proposal_rank()); th, al = Sm.build_alias_table(p); eng.set_sampler(th, al, np.log(p).astype(np.float32))
 flat, starts = gen.generate(120_000)
-ds = eng.put_dataset(flat, starts)
-eng.reserve(512 * 49)
+if not SH:
+    ds = eng.put_dataset(flat, starts)
+    eng.reserve(512 * 49)
 stream = bench.BatchStream(0, 120_000, 512, 1)
 gc.collect(); gc.freeze()
 step = 0
 def run(n):
     global step
+    if SH:
+        for w0 in range(0, n, 32):
+            dsb = eng.prepare([Bt.pack_flat(flat, starts, stream.sel(step + j)) for j in range(min(32, n - w0))])
+            for d in dsb:
+                eng.train_step(d, step=step); step += 1
+        return
     for i in range(n):
         d = eng.upload_device(ds, stream.sel(step))
         eng.train_step(d, step=step); step += 1
-run(30); torch.cuda.synchronize()
-t0 = time.perf_counter(); run(100); th_ = time.perf_counter() - t0; torch.cuda.synchronize(); tw = time.perf_counter() - t0
-print("host enqueue ms/step %.3f   wall ms/step %.3f" % (th_ * 10, tw * 10))
-pr = cProfile.Profile(); pr.enable(); run(100); pr.disable(); torch.cuda.synchronize()
-st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
+WARM = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+run(WARM); torch.cuda.synchronize()
+t0 = time.perf_counter(); run(96); th_ = time.perf_counter() - t0; torch.cuda.synchronize(); tw = time.perf_counter() - t0
+print("host enqueue ms/step %.3f   wall ms/step %.3f" % (th_ / 96 * 1e3, tw / 96 * 1e3))
+t0 = time.perf_counter(); run(288); th_ = time.perf_counter() - t0; torch.cuda.synchronize(); tw = time.perf_counter() - t0
+print("again, 288 steps: host enqueue ms/step %.3f   wall ms/step %.3f   (graph=%s)" % (th_ / 288 * 1e3, tw / 288 * 1e3, eng.use_graph))
+if len(sys.argv) > 3:
+    pr = cProfile.Profile(); pr.enable(); run(96); pr.disable(); torch.cuda.synchronize()
+    st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
