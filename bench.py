@@ -75,6 +75,7 @@ def parse(argv=None):
                     help="round-1 measurement: cycle <= --distinct-batches pre-built batches instead of fresh ones")
     ap.add_argument("--distinct-batches", type=int, default=64)
     ap.add_argument("--settle", type=int, default=8, help="untimed steps before --warmup (see DESIGN.md 5)")
+    ap.add_argument("--tune-steps", type=int, default=96, help="untimed steps of the eager-vs-graph scan-issue calibration (0 = off)")
     ap.add_argument("--profile-steps", type=int, default=10)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--parity-steps", type=int, default=8, help="steps whose loss is compared GPU vs CPU (>= 5)")
@@ -480,6 +481,18 @@ def main(argv=None):
     import gc
     gc.collect()
     gc.freeze()
+    # how the scan's launches are issued is decided per box (fast host core: eager; slow one: rewritten hipGraph) on
+    # untimed training steps -- Engine.autotune_scan; SEQREC_SCAN_GRAPH=0/1 pins it
+    scan_issue = None
+    if not sharded and "SEQREC_SCAN_GRAPH" not in os.environ and a.tune_steps > 0:
+        def _one():
+            nonlocal step
+            train(step)
+            step += 1
+            return tok_seen[-1][1]
+        scan_issue = eng.autotune_scan(_one, blocks=3, block_steps=max(4, a.tune_steps // 6), warm=max(8, a.tune_steps // 3))
+    else:
+        scan_issue = {"scan_issue": ("graph" if getattr(eng, "use_graph", False) else "eager"), "pinned": True}
     for i in range(a.settle):
         train(step)
         step += 1
@@ -640,7 +653,7 @@ def main(argv=None):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cd["desc"] + (" (saturated: 50 items/session)" if a.saturated else " (MSNBC-shaped lengths)"),
                        "global_batch": a.batch * world, "seq_len": 50, "tokens_per_step_per_gpu": round(n_tok_mean, 1),
-                       "t_mean": round(t_mean, 1), "t_max": t_max, "settle_steps": a.settle, "batches": mode,
+                       "t_mean": round(t_mean, 1), "t_max": t_max, "settle_steps": a.settle, "batches": mode, "scan": scan_issue,
                        "train_sessions_per_gpu": n_train, "test_sessions": n_test,
                        "routing_window": WINDOW if (sharded and not resident) else None,
                        "parallelism": ("dp%d+row-sharded-tables" % world) if sharded else "single"},

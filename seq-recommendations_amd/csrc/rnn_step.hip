@@ -19,6 +19,9 @@
 // the launches.
 #include "common.h"
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <vector>
 
 namespace {
 
@@ -40,8 +43,7 @@ __device__ __forceinline__ void bstore(rsrc_t r, int voff, int soff, float v) {
 struct StepArgs {
     int H, H_real;
     int p0, pprev0, bt, bnext, first;        // token offset of this step / previous step, rows, rows of step t+1
-    const int* step_off;                      // DEVICE step offsets: the per-step values above are read from it
-    int t, T;                                 //   (kernel-side) so that a captured launch graph is batch-independent
+    int tag;                                  // launch index inside the scan call (orders the nodes of a captured graph)
     const float* XW; float* Hout; float* gates; float* aux;
     const float* pk;                          // packed B for this launch
     const float* dHout; float* dPre; float* dHc; float* tmpc;
@@ -49,18 +51,6 @@ struct StepArgs {
     int B;
     int cbn, xcd;                             // column blocks of this launch; XCD-aware tile placement on/off
 };
-
-// per-step geometry from the device-resident step offsets (uniform scalar loads)
-__device__ __forceinline__ StepArgs resolve(StepArgs a) {
-    if (!a.step_off) return a;               // eager launches carry the host-resolved values
-    const int* so = a.step_off;
-    a.p0 = so[a.t];
-    a.bt = so[a.t + 1] - a.p0;
-    a.pprev0 = a.t > 0 ? so[a.t - 1] : 0;
-    a.bnext = a.t + 1 < a.T ? so[a.t + 2] - so[a.t + 1] : 0;
-    a.first = a.t == 0;
-    return a;
-}
 
 // Tile placement (speed only, never correctness): the launch is 1-D and workgroup ids are dealt
 // round-robin to the 8 XCDs, each with its own L2.  Row block rb is pinned to XCD rb % 8 with ALL its
@@ -194,7 +184,7 @@ __global__ void pack_lstm_fwd_kernel(const float* __restrict__ U, int H, float* 
 
 template <int J, int ACT, int PHASE>
 __global__ __launch_bounds__(256) void gru_step_fwd(StepArgs a_in) {
-    const StepArgs a = resolve(a_in);
+    const StepArgs& a = a_in;
     int r0, cb;
     if (!tile_of(a, r0, cb)) return;
     // PHASE 0: [z|r] = hs(xw + h_prev.U_zr), r*h_prev        grid (rows/16, 2H/16)
@@ -250,7 +240,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd(StepArgs a_in) {
 
 template <int J, int ACT, int PHASE>
 __global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a_in) {
-    const StepArgs a = resolve(a_in);
+    const StepArgs& a = a_in;
     int r0, cb;
     if (!tile_of(a, r0, cb)) return;
     // PHASE 0 (grid rows/16 x H/16): d = dh (1-z) act'(h~) for the whole row -> LDS; drh = d . U_h^T (own cols);
@@ -333,7 +323,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a_in) {
 // ---------------------------------------------------------------------------------------------
 template <int J, int ACT, bool RD>
 __device__ __forceinline__ void lstm_step_fwd_body(const StepArgs& a_in) {
-    const StepArgs a = resolve(a_in);
+    const StepArgs& a = a_in;
     int r0, cb;
     if (!tile_of(a, r0, cb)) return;
     constexpr int H = 64 * J, LDA = H + 2, GH = 4 * H, G4 = H / 16;
@@ -413,7 +403,7 @@ template <int J, int ACT> __global__ __launch_bounds__(256) void lstm_step_fwd_n
 template <int J, int ACT> __global__ __launch_bounds__(256) void lstm_step_fwd_rd(StepArgs a) { lstm_step_fwd_body<J, ACT, true>(a); }
 template <int J, int ACT>
 __global__ __launch_bounds__(256) void srnn_step_fwd(StepArgs a_in) {
-    const StepArgs a = resolve(a_in);
+    const StepArgs& a = a_in;
     int r0, cb;
     if (!tile_of(a, r0, cb)) return;
     constexpr int H = 64 * J;
@@ -450,7 +440,7 @@ __global__ __launch_bounds__(256) void srnn_step_fwd(StepArgs a_in) {
 // LSTM, the carried dc (dCc).  One thread per (row, hidden col).  grid = ceil(bt*H / 256)
 template <int CELL, int ACT>
 __global__ void pointwise_bwd_step(StepArgs a_in) {
-    const StepArgs a = resolve(a_in);
+    const StepArgs& a = a_in;
     const int H = a.H;
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (long)a.bt * H) return;
@@ -481,7 +471,7 @@ __global__ void pointwise_bwd_step(StepArgs a_in) {
 // dHc[prev token][own 16 cols] = dPre[p][0:K] . packed(U^T)      (K = G*H), skipped at t = 0
 template <int K>
 __global__ __launch_bounds__(256) void gemm_bwd_step(StepArgs a_in, int H, int ldp) {
-    const StepArgs a = resolve(a_in);
+    const StepArgs& a = a_in;
     int r0, cb;
     if (!tile_of(a, r0, cb)) return;
     __shared__ float red[4 * 256];
@@ -526,11 +516,24 @@ unsigned place_grid(dim3 grid, StepArgs& a) {
     a.xcd = xcd_placement() ? 1 : 0;
     return a.xcd ? 8u * grid.y * ((grid.x + 7) / 8) : grid.x * grid.y;
 }
-template <typename KF> int launch_step(KF kern, dim3 grid, const StepArgs& a_in, hipStream_t st) {
-    StepArgs a = a_in;
-    const unsigned n = place_grid(grid, a);
-    hipLaunchKernelGGL(kern, dim3(n), dim3(256), 0, st, a);
-    SEQREC_LAUNCH_CHECK();
+
+// One scan call = a PLAN: the ordered list of its dependent launches (kernel, grid, arguments).  The plan is either
+// issued eagerly (one hipLaunchKernel per entry) or replayed through a captured hipGraph whose kernel nodes are
+// REWRITTEN with this batch's exact geometry before every replay (hipGraphExecKernelNodeSetParams): the kernels
+// keep taking everything from their arguments -- no device-side step table, no oversized grids -- while the host
+// pays ~0.6 us per node plus one graph launch instead of ~3 us per launch (tools/graph_update_probe.hip).
+struct Launch { const void* fn; unsigned grid; StepArgs a; int i0, i1; int nargs; };
+typedef std::vector<Launch> Plan;
+
+template <typename KF> int plan_step(Plan& pl, KF kern, dim3 grid, const StepArgs& a_in) {
+    Launch L;
+    L.fn = reinterpret_cast<const void*>(kern);
+    L.a = a_in;
+    L.grid = place_grid(grid, L.a);
+    L.a.tag = (int)pl.size();
+    L.i0 = L.i1 = 0;
+    L.nargs = 1;
+    pl.push_back(L);
     return 0;
 }
 
@@ -538,18 +541,18 @@ template <typename KF> int launch_step(KF kern, dim3 grid, const StepArgs& a_in,
     do {                                                                                        \
         int rc__ = SEQREC_E_SHAPE;                                                              \
         switch (J * 4 + act) {                                                                  \
-            case 4 * 1 + 0: rc__ = launch_step(KERN<1, 0, PHASE>, GRID, a, st); break;          \
-            case 4 * 1 + 1: rc__ = launch_step(KERN<1, 1, PHASE>, GRID, a, st); break;          \
-            case 4 * 1 + 2: rc__ = launch_step(KERN<1, 2, PHASE>, GRID, a, st); break;          \
-            case 4 * 2 + 0: rc__ = launch_step(KERN<2, 0, PHASE>, GRID, a, st); break;          \
-            case 4 * 2 + 1: rc__ = launch_step(KERN<2, 1, PHASE>, GRID, a, st); break;          \
-            case 4 * 2 + 2: rc__ = launch_step(KERN<2, 2, PHASE>, GRID, a, st); break;          \
-            case 4 * 4 + 0: rc__ = launch_step(KERN<4, 0, PHASE>, GRID, a, st); break;          \
-            case 4 * 4 + 1: rc__ = launch_step(KERN<4, 1, PHASE>, GRID, a, st); break;          \
-            case 4 * 4 + 2: rc__ = launch_step(KERN<4, 2, PHASE>, GRID, a, st); break;          \
-            case 4 * 8 + 0: rc__ = launch_step(KERN<8, 0, PHASE>, GRID, a, st); break;          \
-            case 4 * 8 + 1: rc__ = launch_step(KERN<8, 1, PHASE>, GRID, a, st); break;          \
-            case 4 * 8 + 2: rc__ = launch_step(KERN<8, 2, PHASE>, GRID, a, st); break;          \
+            case 4 * 1 + 0: rc__ = plan_step(pl, KERN<1, 0, PHASE>, GRID, a); break;            \
+            case 4 * 1 + 1: rc__ = plan_step(pl, KERN<1, 1, PHASE>, GRID, a); break;            \
+            case 4 * 1 + 2: rc__ = plan_step(pl, KERN<1, 2, PHASE>, GRID, a); break;            \
+            case 4 * 2 + 0: rc__ = plan_step(pl, KERN<2, 0, PHASE>, GRID, a); break;            \
+            case 4 * 2 + 1: rc__ = plan_step(pl, KERN<2, 1, PHASE>, GRID, a); break;            \
+            case 4 * 2 + 2: rc__ = plan_step(pl, KERN<2, 2, PHASE>, GRID, a); break;            \
+            case 4 * 4 + 0: rc__ = plan_step(pl, KERN<4, 0, PHASE>, GRID, a); break;            \
+            case 4 * 4 + 1: rc__ = plan_step(pl, KERN<4, 1, PHASE>, GRID, a); break;            \
+            case 4 * 4 + 2: rc__ = plan_step(pl, KERN<4, 2, PHASE>, GRID, a); break;            \
+            case 4 * 8 + 0: rc__ = plan_step(pl, KERN<8, 0, PHASE>, GRID, a); break;            \
+            case 4 * 8 + 1: rc__ = plan_step(pl, KERN<8, 1, PHASE>, GRID, a); break;            \
+            case 4 * 8 + 2: rc__ = plan_step(pl, KERN<8, 2, PHASE>, GRID, a); break;            \
         }                                                                                       \
         if (rc__) return rc__;                                                                  \
     } while (0)
@@ -558,44 +561,53 @@ template <typename KF> int launch_step(KF kern, dim3 grid, const StepArgs& a_in,
     do {                                                                                        \
         int rc__ = SEQREC_E_SHAPE;                                                              \
         switch (J * 4 + act) {                                                                  \
-            case 4 * 1 + 0: rc__ = launch_step(KERN<1, 0>, GRID, a, st); break;                 \
-            case 4 * 1 + 1: rc__ = launch_step(KERN<1, 1>, GRID, a, st); break;                 \
-            case 4 * 1 + 2: rc__ = launch_step(KERN<1, 2>, GRID, a, st); break;                 \
-            case 4 * 2 + 0: rc__ = launch_step(KERN<2, 0>, GRID, a, st); break;                 \
-            case 4 * 2 + 1: rc__ = launch_step(KERN<2, 1>, GRID, a, st); break;                 \
-            case 4 * 2 + 2: rc__ = launch_step(KERN<2, 2>, GRID, a, st); break;                 \
-            case 4 * 4 + 0: rc__ = launch_step(KERN<4, 0>, GRID, a, st); break;                 \
-            case 4 * 4 + 1: rc__ = launch_step(KERN<4, 1>, GRID, a, st); break;                 \
-            case 4 * 4 + 2: rc__ = launch_step(KERN<4, 2>, GRID, a, st); break;                 \
-            case 4 * 8 + 0: rc__ = launch_step(KERN<8, 0>, GRID, a, st); break;                 \
-            case 4 * 8 + 1: rc__ = launch_step(KERN<8, 1>, GRID, a, st); break;                 \
-            case 4 * 8 + 2: rc__ = launch_step(KERN<8, 2>, GRID, a, st); break;                 \
+            case 4 * 1 + 0: rc__ = plan_step(pl, KERN<1, 0>, GRID, a); break;                   \
+            case 4 * 1 + 1: rc__ = plan_step(pl, KERN<1, 1>, GRID, a); break;                   \
+            case 4 * 1 + 2: rc__ = plan_step(pl, KERN<1, 2>, GRID, a); break;                   \
+            case 4 * 2 + 0: rc__ = plan_step(pl, KERN<2, 0>, GRID, a); break;                   \
+            case 4 * 2 + 1: rc__ = plan_step(pl, KERN<2, 1>, GRID, a); break;                   \
+            case 4 * 2 + 2: rc__ = plan_step(pl, KERN<2, 2>, GRID, a); break;                   \
+            case 4 * 4 + 0: rc__ = plan_step(pl, KERN<4, 0>, GRID, a); break;                   \
+            case 4 * 4 + 1: rc__ = plan_step(pl, KERN<4, 1>, GRID, a); break;                   \
+            case 4 * 4 + 2: rc__ = plan_step(pl, KERN<4, 2>, GRID, a); break;                   \
+            case 4 * 8 + 0: rc__ = plan_step(pl, KERN<8, 0>, GRID, a); break;                   \
+            case 4 * 8 + 1: rc__ = plan_step(pl, KERN<8, 1>, GRID, a); break;                   \
+            case 4 * 8 + 2: rc__ = plan_step(pl, KERN<8, 2>, GRID, a); break;                   \
         }                                                                                       \
         if (rc__) return rc__;                                                                  \
     } while (0)
 
-template <int CELL> int launch_pointwise(int act, const StepArgs& a, hipStream_t st) {
-    const unsigned blocks = (unsigned)(((long)a.bt * a.H + 255) / 256);
-    if (act == 0) hipLaunchKernelGGL((pointwise_bwd_step<CELL, 0>), dim3(blocks), dim3(256), 0, st, a);
-    else if (act == 1) hipLaunchKernelGGL((pointwise_bwd_step<CELL, 1>), dim3(blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((pointwise_bwd_step<CELL, 2>), dim3(blocks), dim3(256), 0, st, a);
-    SEQREC_LAUNCH_CHECK();
+template <int CELL> int plan_pointwise(Plan& pl, int act, const StepArgs& a) {
+    Launch L;
+    L.fn = act == 0 ? reinterpret_cast<const void*>(pointwise_bwd_step<CELL, 0>)
+         : act == 1 ? reinterpret_cast<const void*>(pointwise_bwd_step<CELL, 1>)
+                    : reinterpret_cast<const void*>(pointwise_bwd_step<CELL, 2>);
+    L.a = a;
+    L.a.tag = (int)pl.size();
+    L.grid = (unsigned)(((long)a.bt * a.H + 255) / 256);
+    L.i0 = L.i1 = 0;
+    L.nargs = 1;
+    pl.push_back(L);
     return 0;
 }
 
-int launch_gemm_bwd(int K, dim3 grid2, const StepArgs& a_in, int H, int ldp, hipStream_t st) {
-    StepArgs a = a_in;
-    const dim3 grid(place_grid(grid2, a));
+int plan_gemm_bwd(Plan& pl, int K, dim3 grid2, const StepArgs& a_in, int H, int ldp) {
+    Launch L;
     switch (K) {
-        case 64: hipLaunchKernelGGL(gemm_bwd_step<64>, grid, dim3(256), 0, st, a, H, ldp); break;
-        case 128: hipLaunchKernelGGL(gemm_bwd_step<128>, grid, dim3(256), 0, st, a, H, ldp); break;
-        case 256: hipLaunchKernelGGL(gemm_bwd_step<256>, grid, dim3(256), 0, st, a, H, ldp); break;
-        case 512: hipLaunchKernelGGL(gemm_bwd_step<512>, grid, dim3(256), 0, st, a, H, ldp); break;
-        case 1024: hipLaunchKernelGGL(gemm_bwd_step<1024>, grid, dim3(256), 0, st, a, H, ldp); break;
-        case 2048: hipLaunchKernelGGL(gemm_bwd_step<2048>, grid, dim3(256), 0, st, a, H, ldp); break;
+        case 64: L.fn = reinterpret_cast<const void*>(gemm_bwd_step<64>); break;
+        case 128: L.fn = reinterpret_cast<const void*>(gemm_bwd_step<128>); break;
+        case 256: L.fn = reinterpret_cast<const void*>(gemm_bwd_step<256>); break;
+        case 512: L.fn = reinterpret_cast<const void*>(gemm_bwd_step<512>); break;
+        case 1024: L.fn = reinterpret_cast<const void*>(gemm_bwd_step<1024>); break;
+        case 2048: L.fn = reinterpret_cast<const void*>(gemm_bwd_step<2048>); break;
         default: return SEQREC_E_SHAPE;
     }
-    SEQREC_LAUNCH_CHECK();
+    L.a = a_in;
+    L.grid = place_grid(grid2, L.a);
+    L.a.tag = (int)pl.size();
+    L.i0 = H; L.i1 = ldp;
+    L.nargs = 3;
+    pl.push_back(L);
     return 0;
 }
 
@@ -605,6 +617,15 @@ bool ok_shape(int cell, int act, int H, int H_real, int T, int B) {
     if (H_real < 1 || H_real > H || T < 0 || B < 0) return false;
     if ((long)B * T * 4 * H * 4 >= 0x7FFFFFF0L) return false;
     return true;
+}
+
+int issue_eager(Plan& pl, hipStream_t st) {
+    for (Launch& L : pl) {
+        void* argv[3] = {&L.a, &L.i0, &L.i1};
+        const hipError_t e = hipLaunchKernel(L.fn, dim3(L.grid), dim3(256), argv, 0, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
 }
 
 }  // namespace
@@ -646,140 +667,108 @@ extern "C" int seqrec_rnn_pack_u_stepwise(int cell, int H, const float* U, float
     return 0;
 }
 
-// ---- launch-graph cache: one instantiated hipGraph per distinct argument tuple (the kernels read all
-// batch-dependent geometry from the device step table, so a graph only depends on T, B and pointers)
-#include <map>
-#include <mutex>
-#include <tuple>
-#include <vector>
+// ---- launch-graph cache: one instantiated hipGraph per launch SEQUENCE (the ordered kernel functions of a plan:
+// cell, activation, H, direction and T decide it); every replay rewrites all nodes with the batch's arguments
 namespace {
-typedef std::vector<unsigned long long> GraphKey;
-std::map<GraphKey, hipGraphExec_t> g_graphs;
+struct GraphEntry { hipGraph_t graph; hipGraphExec_t exec; std::vector<hipGraphNode_t> nodes; };   // the node handles live in `graph`
+std::map<std::vector<const void*>, GraphEntry> g_graphs;
 std::mutex g_graph_mu;
 
-hipStream_t g_capture_stream = nullptr;       // capture never runs on the caller's stream (it may be the null stream)
-
-template <typename F> int run_maybe_graph(bool use_graph, const GraphKey& key, hipStream_t st, F&& enqueue) {
-    if (!use_graph) return enqueue(st);
+int issue_graph(Plan& pl, hipStream_t st) {
+    std::vector<const void*> key(pl.size());
+    for (size_t i = 0; i < pl.size(); ++i) key[i] = pl[i].fn;
     std::lock_guard<std::mutex> lk(g_graph_mu);
     auto it = g_graphs.find(key);
     if (it == g_graphs.end()) {
+        // build the chain explicitly (node i depends on node i - 1): the node handles are then known in launch order
         hipError_t e;
-        if (!g_capture_stream) {
-            e = hipStreamCreateWithFlags(&g_capture_stream, hipStreamNonBlocking);
-            if (e != hipSuccess) return (int)e;
-        }
         hipGraph_t graph;
-        e = hipStreamBeginCapture(g_capture_stream, hipStreamCaptureModeThreadLocal);
+        e = hipGraphCreate(&graph, 0);
         if (e != hipSuccess) return (int)e;
-        const int rc = enqueue(g_capture_stream);
-        e = hipStreamEndCapture(g_capture_stream, &graph);
-        if (rc) { if (e == hipSuccess) (void)hipGraphDestroy(graph); return rc; }
-        if (e != hipSuccess) return (int)e;
-        hipGraphExec_t exec;
-        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (e != hipSuccess) return (int)e;
-        if (g_graphs.size() >= 256) {                      // bounded: drop everything, rebuild on demand
-            for (auto& kv : g_graphs) (void)hipGraphExecDestroy(kv.second);
+        GraphEntry ent;
+        ent.nodes.reserve(pl.size());
+        for (size_t i = 0; i < pl.size(); ++i) {
+            Launch& L = pl[i];
+            void* argv[3] = {&L.a, &L.i0, &L.i1};
+            hipKernelNodeParams p = {};
+            p.func = const_cast<void*>(L.fn);
+            p.gridDim = dim3(L.grid); p.blockDim = dim3(256); p.sharedMemBytes = 0;
+            p.kernelParams = argv; p.extra = nullptr;
+            hipGraphNode_t node;
+            e = hipGraphAddKernelNode(&node, graph, i ? &ent.nodes[i - 1] : nullptr, i ? 1 : 0, &p);
+            if (e != hipSuccess) { (void)hipGraphDestroy(graph); return (int)e; }
+            ent.nodes.push_back(node);
+        }
+        e = hipGraphInstantiate(&ent.exec, graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) { (void)hipGraphDestroy(graph); return (int)e; }
+        ent.graph = graph;
+        if (g_graphs.size() >= 512) {                      // bounded: drop everything, rebuild on demand
+            for (auto& kv : g_graphs) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
             g_graphs.clear();
         }
-        it = g_graphs.emplace(key, exec).first;
+        it = g_graphs.emplace(key, ent).first;
+    } else {
+        GraphEntry& ent = it->second;
+        for (size_t i = 0; i < pl.size(); ++i) {
+            Launch& L = pl[i];
+            void* argv[3] = {&L.a, &L.i0, &L.i1};
+            hipKernelNodeParams p = {};
+            p.func = const_cast<void*>(L.fn);
+            p.gridDim = dim3(L.grid); p.blockDim = dim3(256); p.sharedMemBytes = 0;
+            p.kernelParams = argv; p.extra = nullptr;
+            const hipError_t e = hipGraphExecKernelNodeSetParams(ent.exec, ent.nodes[i], &p);
+            if (e != hipSuccess) return (int)e;
+        }
     }
-    const hipError_t e = hipGraphLaunch(it->second, st);
+    const hipError_t e = hipGraphLaunch(it->second.exec, st);
     return e == hipSuccess ? 0 : (int)e;
 }
-unsigned long long pk_(const void* p) { return (unsigned long long)reinterpret_cast<uintptr_t>(p); }
 }  // namespace
 
 extern "C" int seqrec_graph_cache_clear(void) {
     std::lock_guard<std::mutex> lk(g_graph_mu);
-    for (auto& kv : g_graphs) (void)hipGraphExecDestroy(kv.second);
+    for (auto& kv : g_graphs) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
     g_graphs.clear();
     return 0;
 }
-
-namespace {
-// Launch-graph grids.  A captured graph must not depend on the batch, but sizing every launch for B
-// rows (1 536 workgroups at B = 512, almost all of which exit at once) costs more than the replay
-// saves.  With the XCD placement the grid only depends on j_t = ceil(row blocks / 8), which decays
-// with t; it is covered by a geometric ENVELOPE  env_t = max(1, jmax >> (t / S))  with the smallest
-// halving stride S from a fixed menu that dominates the batch's j_t, so batches of equal T share a
-// graph (MSNBC-shaped batches: S = 5; every session full length: S = inf).
-struct Envelope { int jmax, S; };
-Envelope pick_envelope(const int32_t* soh, int T, int B) {
-    int jmax = 1;
-    const int jb = ((B + 15) / 16 + 7) / 8;
-    while (jmax < jb) jmax <<= 1;
-    static const int menu[] = {3, 5, 8, 12, 1 << 30};
-    for (int S : menu) {
-        bool ok = true;
-        for (int t = 0; t < T && ok; ++t) {
-            const int bt = soh[t + 1] - soh[t];
-            const int j = ((bt + 15) / 16 + 7) / 8;
-            const int sh = t / S;
-            const int env = sh >= 30 ? 1 : (jmax >> sh > 1 ? jmax >> sh : 1);
-            ok = j <= env;
-        }
-        if (ok) return Envelope{jmax, S};
-    }
-    return Envelope{jmax, 1 << 30};
-}
-inline int env_rows(const Envelope& e, int t, int B) {
-    const int sh = t / e.S;
-    const int j = sh >= 30 ? 1 : (e.jmax >> sh > 1 ? e.jmax >> sh : 1);
-    const int rows = j * 8 * 16;
-    return rows < B ? rows : B;
-}
-}  // namespace
 
 extern "C" int seqrec_rnn_fwd_stepwise(int cell, int act, int H, int H_real, int T, int B,
                                        const int32_t* step_off, const int32_t* step_off_host, const float* XW,
                                        float* Hout, float* gates, float* aux, const float* upack,
                                        const float* rmask, int use_graph, void* stream) {
+    (void)step_off;                                             // kept in the signature; the kernels take their geometry as arguments
     if (!ok_shape(cell, act, H, H_real, T, B)) return SEQREC_E_SHAPE;
     if (T == 0 || B == 0) return 0;
-    if (!step_off || !XW || !Hout || !upack) return SEQREC_E_ARG;
+    if (!step_off_host || !XW || !Hout || !upack) return SEQREC_E_ARG;
     if (cell != SEQREC_CELL_SIMPLERNN && (!gates || !aux)) return SEQREC_E_ARG;
     hipStream_t st = as_stream(stream);
     const int J = H / 64;
     const long HH = (long)H * H;
-    const bool graph = use_graph != 0;
-    const int32_t* soh = graph ? nullptr : step_off_host;       // a graph must not bake host-side sizes in
-    const Envelope env = (graph && step_off_host) ? pick_envelope(step_off_host, T, B) : Envelope{1 << 20, 1 << 30};
-    auto enqueue = [&](hipStream_t st) -> int {
-        StepArgs a = {};
-        a.H = H; a.H_real = H_real; a.XW = XW; a.Hout = Hout; a.gates = gates; a.aux = aux;
-        a.rmask = rmask; a.B = B; a.step_off = step_off; a.T = T;
-        for (int t = 0; t < T; ++t) {
-            a.t = t;
-            const int bt = soh ? soh[t + 1] - soh[t] : env_rows(env, t, B);   // exact rows (eager) or the envelope (graph)
-            if (bt <= 0) break;
-            if (soh) {
-                a.step_off = nullptr;
-                a.p0 = soh[t]; a.bt = bt; a.pprev0 = t > 0 ? soh[t - 1] : 0; a.first = t == 0;
-                a.bnext = t + 1 < T ? soh[t + 2] - soh[t + 1] : 0;
-            }
-            const unsigned rb = (unsigned)((bt + 15) / 16);
-            a.pk = upack;
-            if (cell == SEQREC_CELL_GRU) {
-                STEP_DISPATCH(gru_step_fwd, 0, dim3(rb, 2 * H / 16));
-                a.pk = upack + 2 * HH;
-                STEP_DISPATCH(gru_step_fwd, 1, dim3(rb, H / 16));
-            } else if (cell == SEQREC_CELL_LSTM) {
-                if (rmask) { CELL_DISPATCH(lstm_step_fwd_rd, dim3(rb, H / 16)); }
-                else { CELL_DISPATCH(lstm_step_fwd_nd, dim3(rb, H / 16)); }
-            } else {
-                CELL_DISPATCH(srnn_step_fwd, dim3(rb, H / 16));
-            }
+    const int32_t* soh = step_off_host;
+    Plan pl;
+    pl.reserve(2 * (size_t)T);
+    StepArgs a = {};
+    a.H = H; a.H_real = H_real; a.XW = XW; a.Hout = Hout; a.gates = gates; a.aux = aux;
+    a.rmask = rmask; a.B = B;
+    for (int t = 0; t < T; ++t) {
+        const int bt = soh[t + 1] - soh[t];
+        if (bt <= 0) break;
+        a.p0 = soh[t]; a.bt = bt; a.pprev0 = t > 0 ? soh[t - 1] : 0; a.first = t == 0;
+        a.bnext = t + 1 < T ? soh[t + 2] - soh[t + 1] : 0;
+        const unsigned rb = (unsigned)((bt + 15) / 16);
+        a.pk = upack;
+        if (cell == SEQREC_CELL_GRU) {
+            STEP_DISPATCH(gru_step_fwd, 0, dim3(rb, 2 * H / 16));
+            a.pk = upack + 2 * HH;
+            STEP_DISPATCH(gru_step_fwd, 1, dim3(rb, H / 16));
+        } else if (cell == SEQREC_CELL_LSTM) {
+            if (rmask) { CELL_DISPATCH(lstm_step_fwd_rd, dim3(rb, H / 16)); }
+            else { CELL_DISPATCH(lstm_step_fwd_nd, dim3(rb, H / 16)); }
+        } else {
+            CELL_DISPATCH(srnn_step_fwd, dim3(rb, H / 16));
         }
-        return 0;
-    };
-    const GraphKey key = {0ull, (unsigned long long)cell, (unsigned long long)act, (unsigned long long)H,
-                          (unsigned long long)H_real, (unsigned long long)T, (unsigned long long)B,
-                          (unsigned long long)env.jmax, (unsigned long long)env.S, pk_(step_off), pk_(XW),
-                          pk_(Hout), pk_(gates), pk_(aux), pk_(upack), pk_(rmask)};
-    return run_maybe_graph(graph, key, st, enqueue);
+    }
+    return use_graph ? issue_graph(pl, st) : issue_eager(pl, st);
 }
 
 // workspace: 2 * N_tok * H floats (carried dh per token, dcar / carried dc per token)
@@ -788,57 +777,45 @@ extern "C" int seqrec_rnn_bwd_stepwise(int cell, int act, int H, int H_real, int
                                        const float* dHout, const float* Hout, const float* gates, const float* aux,
                                        float* dPre, const float* upack, float* workspace, const float* rmask,
                                        int use_graph, void* stream) {
+    (void)step_off;
     if (!ok_shape(cell, act, H, H_real, T, B)) return SEQREC_E_SHAPE;
     if (T == 0 || B == 0) return 0;
-    if (!step_off || !dHout || !Hout || !dPre || !upack || !workspace || n_tok <= 0) return SEQREC_E_ARG;
+    if (!step_off_host || !dHout || !Hout || !dPre || !upack || !workspace || n_tok <= 0) return SEQREC_E_ARG;
     if (cell != SEQREC_CELL_SIMPLERNN && (!gates || !aux)) return SEQREC_E_ARG;
     hipStream_t st = as_stream(stream);
     const int J = H / 64;
     const long HH = (long)H * H;
-    const bool graph = use_graph != 0;
-    const int32_t* soh = graph ? nullptr : step_off_host;
-    const Envelope env = (graph && step_off_host) ? pick_envelope(step_off_host, T, B) : Envelope{1 << 20, 1 << 30};
-    auto enqueue = [&](hipStream_t st) -> int {
-        StepArgs a = {};
-        a.H = H; a.H_real = H_real; a.Hout = const_cast<float*>(Hout); a.gates = const_cast<float*>(gates);
-        a.aux = const_cast<float*>(aux); a.dHout = dHout; a.dPre = dPre;
-        a.dHc = workspace; a.tmpc = workspace + n_tok * H;
-        a.rmask = rmask; a.B = B; a.step_off = step_off; a.T = T;
-        for (int t = T - 1; t >= 0; --t) {
-            a.t = t;
-            const int bt = soh ? soh[t + 1] - soh[t] : env_rows(env, t, B);
-            if (bt <= 0) continue;
-            if (soh) {
-                a.step_off = nullptr;
-                a.p0 = soh[t]; a.bt = bt; a.pprev0 = t > 0 ? soh[t - 1] : 0; a.first = t == 0;
-                a.bnext = t + 1 < T ? soh[t + 2] - soh[t + 1] : 0;
+    const int32_t* soh = step_off_host;
+    Plan pl;
+    pl.reserve(2 * (size_t)T);
+    StepArgs a = {};
+    a.H = H; a.H_real = H_real; a.Hout = const_cast<float*>(Hout); a.gates = const_cast<float*>(gates);
+    a.aux = const_cast<float*>(aux); a.dHout = dHout; a.dPre = dPre;
+    a.dHc = workspace; a.tmpc = workspace + n_tok * H;
+    a.rmask = rmask; a.B = B;
+    for (int t = T - 1; t >= 0; --t) {
+        const int bt = soh[t + 1] - soh[t];
+        if (bt <= 0) continue;
+        a.p0 = soh[t]; a.bt = bt; a.pprev0 = t > 0 ? soh[t - 1] : 0; a.first = t == 0;
+        a.bnext = t + 1 < T ? soh[t + 2] - soh[t + 1] : 0;
+        const unsigned rb = (unsigned)((bt + 15) / 16);
+        if (cell == SEQREC_CELL_GRU) {
+            a.pk = upack + 3 * HH;
+            STEP_DISPATCH(gru_step_bwd, 0, dim3(rb, H / 16));
+            if (t > 0) {
+                a.pk = upack + 4 * HH;
+                STEP_DISPATCH(gru_step_bwd, 1, dim3(rb, H / 16));
             }
-            const unsigned rb = (unsigned)((bt + 15) / 16);
-            if (cell == SEQREC_CELL_GRU) {
-                a.pk = upack + 3 * HH;
-                STEP_DISPATCH(gru_step_bwd, 0, dim3(rb, H / 16));
-                if (t > 0) {
-                    a.pk = upack + 4 * HH;
-                    STEP_DISPATCH(gru_step_bwd, 1, dim3(rb, H / 16));
-                }
-            } else {
-                const int G = cell == SEQREC_CELL_LSTM ? 4 : 1;
-                if (!soh) a.bt = bt;                            // only sizes the pointwise grid
-                int rc = cell == SEQREC_CELL_LSTM ? launch_pointwise<SEQREC_CELL_LSTM>(act, a, st)
-                                                  : launch_pointwise<SEQREC_CELL_SIMPLERNN>(act, a, st);
-                if (rc) return rc;
-                if (t > 0) {
-                    a.pk = upack + (long)G * HH;
-                    if ((rc = launch_gemm_bwd(G * H, dim3(rb, H / 16), a, H, G * H, st))) return rc;
-                }
+        } else {
+            const int G = cell == SEQREC_CELL_LSTM ? 4 : 1;
+            int rc = cell == SEQREC_CELL_LSTM ? plan_pointwise<SEQREC_CELL_LSTM>(pl, act, a)
+                                              : plan_pointwise<SEQREC_CELL_SIMPLERNN>(pl, act, a);
+            if (rc) return rc;
+            if (t > 0) {
+                a.pk = upack + (long)G * HH;
+                if ((rc = plan_gemm_bwd(pl, G * H, dim3(rb, H / 16), a, H, G * H))) return rc;
             }
         }
-        return 0;
-    };
-    const GraphKey key = {1ull, (unsigned long long)cell, (unsigned long long)act, (unsigned long long)H,
-                          (unsigned long long)H_real, (unsigned long long)T, (unsigned long long)B,
-                          (unsigned long long)env.jmax, (unsigned long long)env.S, pk_(step_off),
-                          (unsigned long long)n_tok, pk_(dHout), pk_(Hout), pk_(gates), pk_(aux), pk_(dPre), pk_(upack),
-                          pk_(workspace), pk_(rmask)};
-    return run_maybe_graph(graph, key, st, enqueue);
+    }
+    return use_graph ? issue_graph(pl, st) : issue_eager(pl, st);
 }

@@ -215,9 +215,9 @@ class Engine:
         if c.drop_rec > 0 and not self.stepwise:
             raise NotImplementedError("recurrent (z_to_z) dropout needs scan='stepwise' (or 'auto')")
         import os
-        self.use_graph = self.stepwise and os.environ.get("SEQREC_SCAN_GRAPH", "0") != "0"   # hipGraph replay of the scan launches (measured: no gain, GPU-bound)
-        self._so_fixed = None
-        self._so_token = object()
+        # the scan's ~135 dependent launches per step ride a captured hipGraph whose nodes are rewritten with every batch's
+        # exact geometry (csrc/rnn_step.hip issue_graph); SEQREC_SCAN_GRAPH=0 issues them eagerly
+        self.use_graph = self.stepwise and os.environ.get("SEQREC_SCAN_GRAPH", "1") != "0"
         self.sampler = None       # (thresh uint32-as-int32 tensor, alias int32 tensor, logq float tensor)
         self.step_count = 0
 
@@ -249,6 +249,38 @@ class Engine:
             self._views.clear()
         self._views[key] = v
         return v
+
+    def autotune_scan(self, run_step, blocks=3, block_steps=16, warm=40, margin=0.015):
+        """Pick how the scan's dependent launches are issued on THIS box.  Eager issue is paced by the host (~2.3-3 us per
+        hipLaunchKernel): on a fast host core it beats the graph replay by ~3 % of a step, on a slow one it loses up to
+        10 % (measured, profiles/README.md); the graph replay costs ~0.6 us of host time per launch and is GPU-paced.
+        run_step() must run ONE training step on the next batch and return that batch's T.  `warm` steps per mode first
+        (graphs of the common T values get built), then `blocks` alternating blocks of `block_steps` steps per mode, wall
+        time per block normalised by the blocks' expected cost (a + b T).  Eager is chosen only if it is faster by
+        `margin`.  Returns the decision record; sets self.use_graph."""
+        import time
+        if not self.stepwise:
+            return {"scan_issue": "persistent"}
+        for mode in (True, False):
+            self.use_graph = mode
+            for _ in range(warm):
+                run_step()
+        tot = {True: [0.0, 0.0], False: [0.0, 0.0]}
+        for b in range(2 * blocks):
+            mode = (b % 2 == 0)
+            self.use_graph = mode
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            cost = 0.0
+            for _ in range(block_steps):
+                cost += 0.30 + 0.0125 * float(run_step())          # expected ms of a c3-like step with T time steps
+            torch.cuda.synchronize()
+            tot[mode][0] += time.perf_counter() - t0
+            tot[mode][1] += cost
+        rate = {m: tot[m][0] / max(tot[m][1], 1e-9) for m in tot}
+        self.use_graph = not (rate[False] < rate[True] * (1.0 - margin))
+        return {"scan_issue": "graph" if self.use_graph else "eager", "eager_over_graph": round(rate[False] / rate[True], 4),
+                "steps_per_mode": blocks * block_steps}
 
     def reserve(self, n_tok_max):
         """Size every grow-only workspace of a training step for batches of up to n_tok_max transitions,
@@ -559,16 +591,6 @@ class Engine:
             arr, cnt = _lib.rows_jobs(js)
             call("seqrec_rows_merge_sorted", arr, cnt, ptr(ws), nbytes, st)
 
-    def _step_table(self, d):
-        """Device step offsets for the step-wise scan.  In graph mode every batch's table is copied
-        into ONE fixed buffer so the captured launch graph (keyed by pointers, T, B) is reusable."""
-        if not self.use_graph:
-            return d["step_off"]
-        if self._so_fixed is None or self._so_fixed.numel() < d["T"] + 1:
-            self._so_fixed = torch.zeros(max(64, d["T"] + 1), dtype=torch.int32, device=self.dev)
-        self._so_fixed[: d["T"] + 1].copy_(d["step_off"], non_blocking=True)
-        return self._so_fixed
-
     # ------------------------------------------------------------------ recurrent scan
     def _scan_fwd(self, d, XW, Hout, gates, aux, rmask=None):
         c, st = self.cfg, self._stream()
@@ -579,8 +601,7 @@ class Engine:
             self.upack_dirty = False
         if self.stepwise:
             so = d["rb"].step_off
-            sod = self._sod_cur = self._step_table(d)
-            call("seqrec_rnn_fwd_stepwise", CELL[c.cell], ACT[c.act], Hp, c.H, d["T"], d["B"], ptr(sod), so.ctypes.data, ptr(XW),
+            call("seqrec_rnn_fwd_stepwise", CELL[c.cell], ACT[c.act], Hp, c.H, d["T"], d["B"], None, so.ctypes.data, ptr(XW),
                  ptr(Hout), ptr(gates), ptr(aux), ptr(self.upack), ptr(rmask), int(self.use_graph), st)
         else:
             call("seqrec_rnn_fwd", CELL[c.cell], ACT[c.act], Hp, c.H, d["T"], d["B"], ptr(d["step_off"]), ptr(XW),
@@ -592,11 +613,8 @@ class Engine:
         if self.stepwise:
             so = d["rb"].step_off
             cap = d["n"]
-            if self.use_graph:           # a captured graph bakes the workspace split in: keep it batch-independent
-                cap = self._tok_cap = max(getattr(self, "_tok_cap", 0), (d["n"] + 4095) // 4096 * 4096)
             wsp = self.buf("scan_ws", 2 * cap * Hp)
-            sod = self._sod_cur          # the table the forward scan of this step installed
-            call("seqrec_rnn_bwd_stepwise", CELL[c.cell], ACT[c.act], Hp, c.H, d["T"], d["B"], ptr(sod), so.ctypes.data, cap,
+            call("seqrec_rnn_bwd_stepwise", CELL[c.cell], ACT[c.act], Hp, c.H, d["T"], d["B"], None, so.ctypes.data, cap,
                  ptr(dHout), ptr(Hout), ptr(gates), ptr(aux), ptr(dPre), ptr(self.upack), ptr(wsp), ptr(rmask),
                  int(self.use_graph), st)
         else:
@@ -929,6 +947,24 @@ class Engine:
         dd.pop("tgt", None)
         r = self.forward(dd, train=False, want_probs=True)
         return r["probs"]
+
+    def probs_from_hidden(self, H):
+        """softmax(H . Wout + bout (+ byy)) for m given hidden rows [m, Hp] (device tensor): the output Keras' TimeDistributed
+        Dense produces at a PAD step, where the masked scan carries the previous state and the unmasked y_to_y / x_to_y
+        inputs are all-zero rows (only their biases remain).  Full softmax only."""
+        c, P = self.cfg, self.P
+        if c.output != "full":
+            raise ValueError("dense probabilities exist only for output='full'")
+        m = H.shape[0]
+        st = self._stream()
+        logits = self.buf("pad_logits", m, self.Vp)
+        self.gemm(1, 0, m, c.V_out, self.Hp, H, self.Hp, P["Wout"], self.Vp, logits, self.Vp, bias=P.get("bout"), tag="logits")
+        if c.y_to_y and c.yy_bias:
+            zero = torch.zeros(m, dtype=torch.int32, device=self.dev)
+            call("seqrec_gather_rows", ptr(P["byy"]), ptr(zero), ptr(logits), m, self.Vp, None, None, 1, st)     # += byy
+        probs = torch.empty((m, c.V_out), dtype=torch.float32, device=self.dev)
+        call("seqrec_full_softmax_ce", ptr(logits), self.Vp, None, m, c.V_out, 0.0, None, ptr(probs), st)
+        return probs
 
     def hidden_rows(self, d):
         r = self.forward(d, train=False, stop_at_hidden=True)

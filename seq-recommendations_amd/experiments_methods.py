@@ -21,7 +21,9 @@ from .model import (MarkovModel, ModelResults, MultinomialModel, NoRecurrenceMod
                     ValLossHistoryCut)
 from .preprocessor import BaselinePreprocessor, FullModelPreprocessor
 
-CHECKPOINT_TEMPLATE = ".{epoch:02d}-{val_loss:.2f}.hdf5"      # ref :30 (file-name pattern kept verbatim)
+# ref :30 writes "<name>.{epoch:02d}-{val_loss:.2f}.hdf5" through h5py; h5py is absent here and the payload is a numpy
+# .npz container (keys weight0..N), so the file is NAMED for what it holds -- the reference's load_weights cannot read it
+CHECKPOINT_TEMPLATE = ".{epoch:02d}-{val_loss:.2f}.npz"
 PATIENCE = 15                                                  # ref :37
 
 

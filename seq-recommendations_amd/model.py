@@ -289,7 +289,15 @@ class SeqModel:
     def non_trainable_weights(self):
         return ["%s/%s" % (l.name, k) for l in self.layers if not l.trainable for k in l.keys]
 
+    @staticmethod
+    def _npz_path(filepath):
+        """Weight files are numpy .npz containers: a path that claims HDF5 (.h5 / .hdf5, as the reference's callers
+        pass) gets the true extension appended instead of holding npz bytes under an HDF5 name."""
+        fp = str(filepath)
+        return fp + ".npz" if fp.lower().endswith((".h5", ".hdf5")) else fp
+
     def save_weights(self, filepath):
+        filepath = self._npz_path(filepath)
         d = os.path.dirname(filepath)
         if d and not os.path.exists(d):
             os.makedirs(d)
@@ -297,6 +305,8 @@ class SeqModel:
             np.savez(f, **{"weight%d" % i: a for i, a in enumerate(self.get_weights())})
 
     def load_weights(self, filepath, by_name=False):
+        if not os.path.exists(filepath) and os.path.exists(self._npz_path(filepath)):
+            filepath = self._npz_path(filepath)
         with np.load(filepath, allow_pickle=False) as z:
             self.set_weights([z["weight%d" % i] for i in range(len(z.files))])
 
@@ -489,8 +499,12 @@ class SeqModel:
         return [loss, loss]
 
     def predict(self, x, batch_size=32, verbose=0):
-        """(N, T, n_classes) softmax outputs; masked steps repeat the previous output, steps
-        before the first real one are the softmax of the (zero-state) bias -- Keras' behaviour."""
+        """(N, T, n_classes) softmax outputs, pad positions included like Keras' Model.predict: the masked scan carries
+        its state through a pad step and the per-step Dense still runs there, so a pad step shows
+        softmax(Wout . h_carried + bout) -- the previous step's output, or softmax(bout) before the first real step.
+        With the y_to_y / x_to_y branches the previous step's output also contained that step's Wyy row / feature term,
+        which a pad step (all-zero unmasked inputs) does not have: those rows are recomputed from the carried state
+        (+ the y_to_y bias), as the reference graph does (model.py:375-397)."""
         prep = self._prepare(x)
         mask = prep[0]
         eng = self._ensure_engine(prep[4])
@@ -504,6 +518,14 @@ class SeqModel:
                 continue
             pr = eng.predict_rows(eng.upload(rb)).cpu().numpy()
             out[idx[rb.tok_b], tcol] = pr
+        if (self.y_to_y or self.x_to_y) and not mask.all():
+            import torch
+            hc = self.hidden(x, batch_size=batch_size)                     # carried state at every position (zeros before the first step)
+            pi, pt = np.nonzero(~mask)
+            Hp = np.zeros((len(pi), eng.Hp), np.float32)
+            Hp[:, : self.z_dim] = hc[pi, pt]
+            out[pi, pt] = eng.probs_from_hidden(torch.from_numpy(Hp).to(eng.dev)).cpu().numpy()
+            return out
         b = self._get("bout") if self.out_bias else np.zeros(V, np.float32)
         p0 = np.exp(b - b.max())
         p0 = (p0 / p0.sum()).astype(np.float32)
