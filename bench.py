@@ -75,6 +75,8 @@ def parse(argv=None):
                     help="round-1 measurement: cycle <= --distinct-batches pre-built batches instead of fresh ones")
     ap.add_argument("--distinct-batches", type=int, default=64)
     ap.add_argument("--settle", type=int, default=8, help="untimed steps before --warmup (see DESIGN.md 5)")
+    ap.add_argument("--merge", default="atomic", choices=["atomic", "sorted"],
+                    help="row-gradient merge: float atomics, or the deterministic sort + ordered segment sum (csrc/merge.hip)")
     ap.add_argument("--tune-steps", type=int, default=96, help="untimed steps of the eager-vs-graph scan-issue calibration (0 = off)")
     ap.add_argument("--profile-steps", type=int, default=10)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU-baseline sample (0 = skip)")
@@ -172,6 +174,8 @@ def kernel_model(cfgd, n_tok, K, B):
         "seqrec_rnn_fwd_stepwise": ("mfma", 2.0 * G * H * H * n_tok),
         "seqrec_rnn_bwd_stepwise": ("mfma", 2.0 * G * H * H * n_tok),
         "seqrec_gemm_f32[xw]": ("mfma", 2.0 * n_tok * D * G * H),
+        "seqrec_gemm_f32_fused[xw]": ("mfma", 2.0 * n_tok * D * G * H),      # embedding rows read through the ids
+        "seqrec_gemm_f32_fused[dH]": ("mfma", 2.0 * n_tok * K * H),          # + the target-row term in the final write
         "seqrec_gemm_f32[logits]": ("mfma", 2.0 * n_tok * K * H),
         "seqrec_gemm_f32[dH]": ("mfma", 2.0 * n_tok * K * H),
         "seqrec_gemm_f32[dEneg]": ("mfma", 2.0 * n_tok * K * H),
@@ -377,7 +381,7 @@ def main(argv=None):
     SEED = 1234
     dev = "cuda:%d" % local
     ncfg = E.NetConfig(cell=cd["cell"], act="relu", H=H, V_in=V, V_out=V, input="embed", D=D, output="sampled", K=K,
-                       tied=bool(cd.get("tied", False)), use_bias=True, out_bias=False, logq=True, seed=SEED)
+                       tied=bool(cd.get("tied", False)), use_bias=True, out_bias=False, logq=True, seed=SEED, merge=a.merge)
     sharded = dist is not None
     notes = []          # a failing OPTIONAL leg (single process only) must not take the throughput line with it
     do_cpu = rank == 0 and world == 1 and not sharded and a.cpu_seconds > 0
@@ -653,7 +657,7 @@ def main(argv=None):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cd["desc"] + (" (saturated: 50 items/session)" if a.saturated else " (MSNBC-shaped lengths)"),
                        "global_batch": a.batch * world, "seq_len": 50, "tokens_per_step_per_gpu": round(n_tok_mean, 1),
-                       "t_mean": round(t_mean, 1), "t_max": t_max, "settle_steps": a.settle, "batches": mode, "scan": scan_issue,
+                       "t_mean": round(t_mean, 1), "t_max": t_max, "settle_steps": a.settle, "batches": mode, "scan": scan_issue, "row_gradient_merge": a.merge,
                        "train_sessions_per_gpu": n_train, "test_sessions": n_test,
                        "routing_window": WINDOW if (sharded and not resident) else None,
                        "parallelism": ("dp%d+row-sharded-tables" % world) if sharded else "single"},

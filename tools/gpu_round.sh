@@ -28,6 +28,12 @@ kernarg) HIP_FORCE_DEV_KERNARG=1 TMO=400 run bench_kernarg1 python bench.py --gp
    HIP_FORCE_DEV_KERNARG=0 TMO=400 run bench_kernarg0 python bench.py --gpus 1 --steps 200 --warmup 20 --cpu-seconds 0 --recall-steps 0; tail -c 300 $out/bench_kernarg0.log;;
 sharded) TMO=400 run bench_sharded python bench.py --gpus 1 --steps 200 --warmup 20 --cpu-seconds 0 --recall-steps 200 --force-sharded; tail -c 400 $out/bench_sharded.log;;
 hostprof) TMO=300 run hostprof python tools/host_profile.py; head -50 $out/hostprof.log; TMO=300 run hostprof_sh python tools/host_profile.py sharded; head -60 $out/hostprof_sh.log;;
+others) for c in c2 c4 c5; do TMO=400 run bench_$c python bench.py --config $c --steps 200 --warmup 20 --cpu-seconds 0 --recall-steps 300; python -c "
+import json; d=json.loads(open('$out/bench_$c.log').read().strip().splitlines()[-1]); print('$c', d['value'], d['ms_per_step'], d['recall_at_20'], d['config']['scan'])"; done
+   TMO=400 run bench_sorted python bench.py --steps 200 --warmup 20 --cpu-seconds 0 --recall-steps 0 --merge sorted; python -c "
+import json; d=json.loads(open('$out/bench_sorted.log').read().strip().splitlines()[-1]); print('sorted', d['value'], d['ms_per_step'], [(k,v['avg_us']) for k,v in d['kernels'].items() if 'merge' in k or 'scatter' in k or 'sqnorm' in k])"
+   TMO=400 run bench_sat python bench.py --saturated --steps 40 --warmup 5 --cpu-seconds 0 --recall-steps 0 --train-sessions 40000; python -c "
+import json; d=json.loads(open('$out/bench_sat.log').read().strip().splitlines()[-1]); print('saturated', d['value'], d['ms_per_step'], d['tokens_per_s'], [(k[7:],v.get('frac')) for k,v in d['kernels'].items() if v.get('frac')])";;
 dbgtopk) TMO=300 run dbgtopk python tools/debug_topk.py c5; cat $out/dbgtopk.log;;
 trace) root=$PWD; cd /tmp; export TMPDIR=/tmp
    timeout -k 10 300 rocprofv3 --hip-trace --kernel-trace --output-format csv -d $root/$out/trace -- python3 $root/tools/stall_probe.py 8 > $root/$out/trace.log 2>&1; echo "trace rc=$?"
