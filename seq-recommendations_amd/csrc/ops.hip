@@ -4,6 +4,7 @@
 // one wave per table row so that a 256-float row is exactly one 1-KiB coalesced wave access.
 #include "common.h"
 #include <limits.h>
+#include <cstdlib>
 #include <algorithm>
 
 namespace {
@@ -700,7 +701,11 @@ template <bool ROWS>
 int launch_sampled(float* ln, long ld, const float* hd, int H, const float* Eout, const float* bout, const float* logq,
                    const float* lq_n, const int* tgt, const int* neg, long n, int K, float inv_denom, float* loss_rows,
                    float* dlt, hipStream_t st) {
-    const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+    // one wave per row; with few rows (an MSNBC-shaped batch has ~2.5 k) single-wave workgroups spread evenly over the
+    // 256 CUs (10 per CU) where 4-wave workgroups leave some CUs with 3 and some with 2 (tuning switch: SEQREC_CE_BLOCK)
+    static const int ce_block = getenv("SEQREC_CE_BLOCK") ? atoi(getenv("SEQREC_CE_BLOCK")) : 64;
+    const int wpb = (ce_block == 256 || n > 16384) ? 4 : 1;
+    const dim3 grid((unsigned)((n + wpb - 1) / wpb)), block(64 * wpb);
     const int vec = ((reinterpret_cast<uintptr_t>(ln) & 15) == 0) && (ld % 4 == 0);
 #define SS_ARGS ln, ld, hd, H, Eout, bout, logq, lq_n, tgt, neg, n, K, inv_denom, loss_rows, dlt
 #define SS_ARGSV SS_ARGS, vec

@@ -636,7 +636,9 @@ bool check_common(int cell, int act, int H, int H_real, int T, int B) {
 
 extern "C" int64_t seqrec_rnn_upack_floats(int cell, int H) {
     const int G = cell == SEQREC_CELL_LSTM ? 4 : (cell == SEQREC_CELL_GRU ? 3 : 1);
-    return (int64_t)2 * G * H * H;       // forward layouts, then backward (transposed) layouts
+    // forward layouts, then backward (transposed) layouts; GRU: + U_h^T once more in the full-K-per-wave order of the
+    // step-wise scan's wide BPTT tile (rnn_step.hip gru_step_bwd0_wide)
+    return (int64_t)2 * G * H * H + (cell == SEQREC_CELL_GRU ? (int64_t)H * H : 0);
 }
 
 extern "C" int seqrec_rnn_pack_u(int cell, int H, const float* U, float* upack, void* stream) {

@@ -88,8 +88,10 @@ __device__ __forceinline__ bool tile_of(const StepArgs& a, int& r0, int& cb) {
 //   K/16 CONSECUTIVE k of its A row and loads them straight from global memory (every accepted shape: K <= 2048)
 // mode 0: B[k][n] = U[k*ldu + coff + n]           (forward:  K = H)
 // mode 1: B[k][n] = U[n*ldu + coff + k]           (backward: transposed; K = H, 2H or 4H)
-struct PackStepJob { int coff, K, N, mode; long off; };
-struct PackStepArgs { const float* U; float* out; int ldu; PackStepJob job[4]; };
+// wide != 0: the full-K-per-wave order of the wide tiles: out[((cb*(K/16) + i)*64 + lane)] (float4), element e <-> MFMA
+//   m = 4*i + e of the wave that owns column block cb, k = q*(K/4) + m -- lane (row, q) owns K/4 consecutive k of its A row
+struct PackStepJob { int coff, K, N, mode; long off; int wide; };
+struct PackStepArgs { const float* U; float* out; int ldu; PackStepJob job[5]; };
 __global__ void pack_step_kernel(PackStepArgs pa) {
     const PackStepJob jb = pa.job[blockIdx.y];
     const float* __restrict__ U = pa.U;
@@ -101,11 +103,17 @@ __global__ void pack_step_kernel(PackStepArgs pa) {
         long q = o;
         const int e = (int)(q & 3); q >>= 2;
         const int l = (int)(q & 63); q >>= 6;
-        const int i = (int)(q % G4); q /= G4;
-        const int w = (int)(q & 3); q >>= 2;
-        const int cb = (int)q;
-        const int m = 4 * i + e;
-        const int k = w * (K / 4) + (l >> 4) * (K / 16) + m;
+        int k, cb;
+        if (jb.wide) {
+            const int i = (int)(q % (K / 16)); q /= (K / 16);
+            cb = (int)q;
+            k = (l >> 4) * (K / 4) + 4 * i + e;
+        } else {
+            const int i = (int)(q % G4); q /= G4;
+            const int w = (int)(q & 3); q >>= 2;
+            cb = (int)q;
+            k = w * (K / 4) + (l >> 4) * (K / 16) + 4 * i + e;
+        }
         const int n = 16 * cb + (l & 15);
         out[o] = mode == 0 ? U[(long)k * ldu + coff + n] : U[(long)n * ldu + coff + k];
     }
@@ -312,6 +320,94 @@ __global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a_in) {
                   (red[512 + tid] + red[768 + tid]) * a.rmask[((long)1 * a.B + srow) * H + col];
         }
         bstore(rC, vh, soP, e_t + acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wide BPTT phase 0 (launches with more than 8 row blocks): workgroup = 16 session rows x 64 columns, each wave owns
+// 16 columns over the FULL K (64 MFMAs, no split-K, no LDS reduce).  The A operand d = dh (1-z) act'(h~) is computed
+// ONCE per workgroup (every thread 16 elements), stored by column group 0, and staged in LDS [16][K+4] -- in the
+// narrow tile each of a row block's 16 column-block workgroups recomputes it from 64 KB of loads, which is what the
+// issue stalls of the wide launches scale with (profiles/r02_v1_c3_scan_widths_pmc.json).  Same arithmetic order per
+// output element?  No: K is summed in one chain per wave instead of four partial chains -> results differ from the
+// narrow tile in the last bits (both are exact-fp32 FMA chains; parity tests cover both).
+// packed: the `wide` order of pack_step_kernel.
+// ---------------------------------------------------------------------------------------------
+template <int J, int ACT>
+__global__ __launch_bounds__(256) void gru_step_bwd0_wide(StepArgs a_in) {
+    const StepArgs& a = a_in;
+    int r0, cbw;
+    if (!tile_of(a, r0, cbw)) return;
+    constexpr int H = 64 * J, GH = 3 * H, K = H, LDA = K + 4;
+    __shared__ float ab[16 * LDA];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nact = min(16, a.bt - r0);
+    const long pt = (long)a.p0 + r0;
+    // the wave's U slice: 16 columns x full K
+    float4 b[K / 16];
+    const float4* pk = reinterpret_cast<const float4*>(a.pk) + (size_t)(cbw * 4 + w) * (K / 16) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < K / 16; ++i) b[i] = pk[i * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    // d, cooperatively: thread (row = tid >> 4, seg = tid & 15) owns k in [seg*K/16, +K/16)
+    constexpr int KT = K / 16;
+    const int drow = tid >> 4, dk0 = (tid & 15) * KT;
+    const bool dok = drow < nact;
+    const long dq = pt + min(drow, nact - 1);
+    float dh[KT], cc[KT], zz[KT], hh[KT];
+    gload_vec(dh, a.dHout + dq * H + dk0);
+    gload_vec(cc, a.dHc + dq * H + dk0);
+    gload_vec(zz, a.gates + dq * GH + dk0);
+    gload_vec(hh, a.gates + dq * GH + 2 * H + dk0);
+    // epilogue operands of this lane's 4 output elements: rows 4q + r, column col
+    const int q = lane >> 4, col = 64 * cbw + 16 * w + (lane & 15);
+    const rsrc_t rDH = mk_rsrc(a.dHout), rH = mk_rsrc(a.Hout), rG = mk_rsrc(a.gates), rDP = mk_rsrc(a.dPre),
+                 rC = mk_rsrc(a.dHc), rT = mk_rsrc(a.tmpc);
+    const int soG = (a.p0 + r0) * GH * 4, soH = (a.p0 + r0) * H * 4, soP = (a.pprev0 + r0) * H * 4;
+    float e_dh[4], e_z[4], e_r[4], e_hh[4], e_h0[4];
+    int vg[4], vh[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * q + r;
+        const bool ok = row < nact;
+        vg[r] = ok ? (row * GH + col) * 4 : INVALID_OFF;
+        vh[r] = ok ? (row * H + col) * 4 : INVALID_OFF;
+        e_dh[r] = bload(rDH, vh[r], soH) + bload(rC, (ok && r0 + row < a.bnext) ? vh[r] : INVALID_OFF, soH);
+        e_z[r] = bload(rG, vg[r], soG);
+        e_r[r] = bload(rG, vg[r] + H * 4, soG);
+        e_hh[r] = bload(rG, vg[r] + 2 * H * 4, soG);
+        e_h0[r] = bload(rH, a.first ? INVALID_OFF : vh[r], soP);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const float carry = (r0 + drow < a.bnext) ? 1.f : 0.f;
+        float dv[KT];
+#pragma unroll
+        for (int j = 0; j < KT; ++j) dv[j] = (dh[j] + (carry != 0.f ? cc[j] : 0.f)) * (1.f - zz[j]) * act_grad<ACT>(hh[j]);
+        if (cbw == 0 && dok) gstore_vec(dv, a.dPre + (pt + drow) * GH + 2 * H + dk0);
+        float* o = ab + drow * LDA + dk0;
+#pragma unroll
+        for (int j = 0; j < KT / 4; ++j) reinterpret_cast<float4*>(o)[j] = make_float4(dv[4 * j], dv[4 * j + 1], dv[4 * j + 2], dv[4 * j + 3]);
+    }
+    __syncthreads();
+    // A operand: lane (row, q) owns k in [q*K/4, +K/4) of its row
+    const float* ap = ab + (lane & 15) * LDA + q * (K / 4);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < K / 16; ++i) {
+        const float4 av = reinterpret_cast<const float4*>(ap)[i];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b[i].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b[i].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b[i].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b[i].w, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float acc = acc0[r] + acc1[r];
+        if (a.rmask) acc *= a.rmask[((long)2 * a.B + min(r0 + 4 * q + r, a.B - 1)) * H + col];      // d(r*h*m2) -> d(r*h)
+        bstore(rDP, vg[r], soG, e_dh[r] * (e_h0[r] - e_hh[r]) * hard_sigmoid_grad(e_z[r]));
+        bstore(rDP, vg[r] + H * 4, soG, acc * e_h0[r] * hard_sigmoid_grad(e_r[r]));
+        bstore(rT, vh[r], soH, e_dh[r] * e_z[r] + acc * e_r[r]);
     }
 }
 
@@ -662,7 +758,8 @@ extern "C" int seqrec_rnn_pack_u_stepwise(int cell, int H, const float* U, float
     pa.job[1] = PackStepJob{2 * H, H, H, 0, 2 * HH};
     pa.job[2] = PackStepJob{2 * H, H, H, 1, 3 * HH};
     pa.job[3] = PackStepJob{0, 2 * H, H, 1, 4 * HH};
-    hipLaunchKernelGGL(pack_step_kernel, dim3(128, 4), dim3(256), 0, st, pa);
+    pa.job[4] = PackStepJob{2 * H, H, H, 1, 6 * HH, 1};        // U_h^T for the wide BPTT tile
+    hipLaunchKernelGGL(pack_step_kernel, dim3(128, 5), dim3(256), 0, st, pa);
     SEQREC_LAUNCH_CHECK();
     return 0;
 }
@@ -800,8 +897,14 @@ extern "C" int seqrec_rnn_bwd_stepwise(int cell, int act, int H, int H_real, int
         a.bnext = t + 1 < T ? soh[t + 2] - soh[t + 1] : 0;
         const unsigned rb = (unsigned)((bt + 15) / 16);
         if (cell == SEQREC_CELL_GRU) {
-            a.pk = upack + 3 * HH;
-            STEP_DISPATCH(gru_step_bwd, 0, dim3(rb, H / 16));
+            static const int wide_rb = getenv("SEQREC_SCAN_WIDE_RB") ? atoi(getenv("SEQREC_SCAN_WIDE_RB")) : 9;   // A/B switch (0 = never)
+            if (wide_rb > 0 && (int)rb >= wide_rb && H >= 128) {
+                a.pk = upack + 6 * HH;
+                CELL_DISPATCH(gru_step_bwd0_wide, dim3(rb, H / 64));
+            } else {
+                a.pk = upack + 3 * HH;
+                STEP_DISPATCH(gru_step_bwd, 0, dim3(rb, H / 16));
+            }
             if (t > 0) {
                 a.pk = upack + 4 * HH;
                 STEP_DISPATCH(gru_step_bwd, 1, dim3(rb, H / 16));

@@ -488,7 +488,9 @@ def test_rank_count_vs_numpy():
 @pytest.mark.parametrize("graph", [0, 1])
 @pytest.mark.parametrize("H,B,maxlen,act", [(64, 5, 6, "relu"), (64, 37, 12, "tanh"), (128, 100, 9, "relu"),
                                             (256, 70, 20, "relu"), (256, 512, 49, "tanh"), (128, 40, 10, "linear"),
-                                            (512, 33, 7, "relu")])
+                                            (512, 33, 7, "relu"),
+                                            # > 8 row blocks: the wide BPTT tile of the GRU (16 x 64, full K per wave)
+                                            (128, 300, 8, "relu"), (512, 160, 5, "relu"), (256, 200, 6, "linear")])
 def test_stepwise_scan_vs_oracle_and_persistent(cell, H, B, maxlen, act, graph):
     """The launch-per-step scan (rnn_step.hip) against the oracle, and close to the persistent scan
     (same fp32 MFMA chains, only the accumulation split differs)."""
