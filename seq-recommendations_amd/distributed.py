@@ -318,6 +318,8 @@ class ShardedEngine(Engine):
             raise ValueError("ShardedEngine shards item tables: it needs input='embed', output='sampled'")
         if cfg.out_bias or cfg.drop_in or cfg.drop_out or cfg.drop_rec:
             raise NotImplementedError("ShardedEngine: output bias / dropout are not wired into the sharded step")
+        if cfg.merge != "atomic":
+            raise NotImplementedError("ShardedEngine: the sorted (bitwise-reproducible) row-gradient merge is single-GPU only")
         self.dist, self.group = dist, group
         self.R = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -348,7 +350,7 @@ class ShardedEngine(Engine):
         # the dense all-reduce runs on its own stream and (RCCL) its own communicator, under the row-gradient exchange
         self.side = torch.cuda.Stream(device=self.dev)
         self.dense_group = group
-        if self.R > 1 and hasattr(dist, "new_group"):
+        if hasattr(dist, "new_group"):                      # also on one rank: the communicator path is the one N > 1 uses
             g2 = dist.new_group()
             if g2 is not None:
                 self.dense_group = g2
@@ -357,7 +359,7 @@ class ShardedEngine(Engine):
         # two tiny collectives, not for the training steps already queued, and its host arithmetic overlaps them
         self.plan_stream = torch.cuda.Stream(device=self.dev)
         self.plan_group = group
-        if self.R > 1 and hasattr(dist, "new_group"):
+        if hasattr(dist, "new_group"):
             g3 = dist.new_group()
             if g3 is not None:
                 self.plan_group = g3
