@@ -324,6 +324,46 @@ __global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a_in) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// GRU, time step 0: h_prev = 0, so nothing crosses columns -- the step is pointwise.  One launch instead of the two
+// widest forward launches of the scan, and the widest BPTT launch without its (all-zero-weighted) recurrent product:
+//   forward   z = hs(xw_z), r = hs(xw_r), h~ = act(xw_h), h = (1 - z) h~, r*h_prev = 0
+//   backward  d = dh (1 - z) act'(h~) = dpre_h;  dpre_z = -dh h~ hs'(z);  dpre_r = 0   (no carry leaves step 0)
+// One thread per (session row, hidden column); grid = ceil(bt * H / 256).
+// ---------------------------------------------------------------------------------------------
+template <int ACT>
+__global__ void gru_first_step_fwd(StepArgs a_in) {
+    const StepArgs& a = a_in;
+    const int H = a.H;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)a.bt * H) return;
+    const int row = (int)(e / H), col = (int)(e % H);
+    const long q = (long)a.p0 + row, GH = 3L * H;
+    const float* xw = a.XW + q * GH + col;
+    const float z = hard_sigmoid(xw[0]), r = hard_sigmoid(xw[H]), hh = act_fwd<ACT>(xw[2 * H]);
+    float* g = a.gates + q * GH + col;
+    g[0] = z; g[H] = r; g[2 * H] = hh;
+    a.aux[q * H + col] = 0.f;
+    a.Hout[q * H + col] = col >= a.H_real ? 0.f : (1.f - z) * hh;
+}
+template <int ACT>
+__global__ void gru_first_step_bwd(StepArgs a_in) {
+    const StepArgs& a = a_in;
+    const int H = a.H;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)a.bt * H) return;
+    const int row = (int)(e / H), col = (int)(e % H);
+    const long q = (long)a.p0 + row, GH = 3L * H;
+    float dh = a.dHout[q * H + col];
+    if (row < a.bnext) dh += a.dHc[q * H + col];
+    const float* g = a.gates + q * GH + col;
+    const float z = g[0], hh = g[2 * H];
+    float* o = a.dPre + q * GH + col;
+    o[0] = dh * (0.f - hh) * hard_sigmoid_grad(z);
+    o[H] = 0.f;
+    o[2 * H] = dh * (1.f - z) * act_grad<ACT>(hh);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Wide BPTT phase 0 (launches with more than 8 row blocks): workgroup = 16 session rows x 64 columns, each wave owns
 // 16 columns over the FULL K (64 MFMAs, no split-K, no LDS reduce).  The A operand d = dh (1-z) act'(h~) is computed
 // ONCE per workgroup (every thread 16 elements), stored by column group 0, and staged in LDS [16][K+4] -- in the
@@ -687,6 +727,21 @@ template <int CELL> int plan_pointwise(Plan& pl, int act, const StepArgs& a) {
     return 0;
 }
 
+int plan_gru_first(Plan& pl, int act, bool bwd, const StepArgs& a) {
+    Launch L;
+    if (bwd) L.fn = act == 0 ? reinterpret_cast<const void*>(gru_first_step_bwd<0>)
+                  : act == 1 ? reinterpret_cast<const void*>(gru_first_step_bwd<1>) : reinterpret_cast<const void*>(gru_first_step_bwd<2>);
+    else L.fn = act == 0 ? reinterpret_cast<const void*>(gru_first_step_fwd<0>)
+              : act == 1 ? reinterpret_cast<const void*>(gru_first_step_fwd<1>) : reinterpret_cast<const void*>(gru_first_step_fwd<2>);
+    L.a = a;
+    L.a.tag = (int)pl.size();
+    L.grid = (unsigned)(((long)a.bt * a.H + 255) / 256);
+    L.i0 = L.i1 = 0;
+    L.nargs = 1;
+    pl.push_back(L);
+    return 0;
+}
+
 int plan_gemm_bwd(Plan& pl, int K, dim3 grid2, const StepArgs& a_in, int H, int ldp) {
     Launch L;
     switch (K) {
@@ -854,7 +909,9 @@ extern "C" int seqrec_rnn_fwd_stepwise(int cell, int act, int H, int H_real, int
         a.bnext = t + 1 < T ? soh[t + 2] - soh[t + 1] : 0;
         const unsigned rb = (unsigned)((bt + 15) / 16);
         a.pk = upack;
-        if (cell == SEQREC_CELL_GRU) {
+        if (cell == SEQREC_CELL_GRU && t == 0) {
+            plan_gru_first(pl, act, false, a);                     // h_prev = 0: the whole step is pointwise
+        } else if (cell == SEQREC_CELL_GRU) {
             STEP_DISPATCH(gru_step_fwd, 0, dim3(rb, 2 * H / 16));
             a.pk = upack + 2 * HH;
             STEP_DISPATCH(gru_step_fwd, 1, dim3(rb, H / 16));
@@ -896,7 +953,9 @@ extern "C" int seqrec_rnn_bwd_stepwise(int cell, int act, int H, int H_real, int
         a.p0 = soh[t]; a.bt = bt; a.pprev0 = t > 0 ? soh[t - 1] : 0; a.first = t == 0;
         a.bnext = t + 1 < T ? soh[t + 2] - soh[t + 1] : 0;
         const unsigned rb = (unsigned)((bt + 15) / 16);
-        if (cell == SEQREC_CELL_GRU) {
+        if (cell == SEQREC_CELL_GRU && t == 0) {
+            plan_gru_first(pl, act, true, a);                      // no recurrent product at step 0
+        } else if (cell == SEQREC_CELL_GRU) {
             static const int wide_rb = getenv("SEQREC_SCAN_WIDE_RB") ? atoi(getenv("SEQREC_SCAN_WIDE_RB")) : 9;   // A/B switch (0 = never)
             if (wide_rb > 0 && (int)rb >= wide_rb && H >= 128) {
                 a.pk = upack + 6 * HH;
