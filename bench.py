@@ -565,8 +565,11 @@ def main(argv=None):
             dom = next((k for k in kern if "bound" in kern[k]), None)
             if dom:
                 e = kern[dom]
+                tr = pmc_traffic(dom, t_prof, a)
                 roof = {"kernel": dom, "bound": e["bound"], "achieved": e["achieved"], "peak": e["peak"], "unit": e["unit"],
-                        "frac": e["frac"], "traffic": pmc_traffic(dom, t_prof, a), "pmc_mfma_util": pmc_mfma_util(dom, a),
+                        "frac": e["frac"], "traffic": tr["bytes_per_call"] if tr else None,
+                        "traffic_unit": "HBM-side bytes per call (FETCH_SIZE x2 + WRITE_SIZE, isolated dispatches)" if tr else None,
+                        "traffic_source": tr["source"] if tr else None, "pmc_mfma_util": pmc_mfma_util(dom, a),
                         "avg_us": e["avg_us"], "share_of_step": e["share"], "tokens_per_call": round(n_prof, 1)}
         except Exception as e:                                   # noqa: BLE001
             if dist is not None:

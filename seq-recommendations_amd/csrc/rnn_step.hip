@@ -52,6 +52,33 @@ struct StepArgs {
     int cbn, xcd;                             // column blocks of this launch; XCD-aware tile placement on/off
 };
 
+// Diagnostic build only (-DSEQREC_STAMP, tools/stamp_probe.py): s_memtime stamps of ONE workgroup per launch (row
+// block 0, column block 1, wave 0) into a device array of the code object; no stamp exists in the product build.
+#ifdef SEQREC_STAMP
+__device__ unsigned long long g_stamp[256 * 8];
+#define STAMP(i)                                                                                              \
+    do {                                                                                                      \
+        if (stamp_me) {                                                                                       \
+            unsigned long long t_;                                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+            if (threadIdx.x == 0) g_stamp[(a.tag & 255) * 8 + (i)] = t_;                                      \
+        }                                                                                                     \
+    } while (0)
+#define STAMP_REAL(i)                                                                                         \
+    do {                                                                                                      \
+        if (stamp_me) {                                                                                       \
+            unsigned long long t_;                                                                            \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+            if (threadIdx.x == 0) g_stamp[(a.tag & 255) * 8 + (i)] = t_;                                      \
+        }                                                                                                     \
+    } while (0)
+#else
+#define STAMP(i)
+#define STAMP_REAL(i)
+#endif
+
 // Tile placement (speed only, never correctness): the launch is 1-D and workgroup ids are dealt
 // round-robin to the 8 XCDs, each with its own L2.  Row block rb is pinned to XCD rb % 8 with ALL its
 // column blocks, at every step and in both directions: the h / r*h / dpre rows one launch writes are
@@ -200,6 +227,9 @@ __global__ __launch_bounds__(256) void gru_step_fwd(StepArgs a_in) {
     constexpr int H = 64 * J, GH = 3 * H;
     __shared__ float red[4 * 256];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    [[maybe_unused]] const bool stamp_me = r0 == 0 && cb == 1 && w == 0;
+    STAMP_REAL(6);
+    STAMP(0);
     const int nact = min(16, a.bt - r0);
     const int row = tid >> 4, col = 16 * cb + (tid & 15);     // this thread's output element
     const bool ok = row < nact;
@@ -228,11 +258,17 @@ __global__ __launch_bounds__(256) void gru_step_fwd(StepArgs a_in) {
         h0 = bload(rH, (a.first || !ok) ? INVALID_OFF : (row * H + (col - H)) * 4, soP);   // h_prev for r * h_prev
     }
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(1);
     float acc = 0.f;
     if (!a.first) {
         if (a.rmask) mask_vec(av, a.rmask, a.B, H, mg, r0 + arow, koff, true);
+#ifdef SEQREC_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(2);
+#endif
         acc = tile_16x16_reg<H>(av, b, red, tid);
     }
+    STAMP(3);
     if (PHASE == 0) {
         const float g = hard_sigmoid(acc + xw);
         bstore(rG, vg, soG, g);
@@ -244,6 +280,11 @@ __global__ __launch_bounds__(256) void gru_step_fwd(StepArgs a_in) {
         bstore(rH, vh, soH, hn);
         bstore(rG, vg + 2 * H * 4, soG, hh);
     }
+#ifdef SEQREC_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    STAMP(4);
+    STAMP_REAL(7);
 }
 
 template <int J, int ACT, int PHASE>
@@ -258,6 +299,9 @@ __global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a_in) {
     constexpr int K = PHASE == 0 ? H : 2 * H;
     __shared__ float red[4 * 256];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    [[maybe_unused]] const bool stamp_me = r0 == 0 && cb == 1 && w == 0;
+    STAMP_REAL(6);
+    STAMP(0);
     const int nact = min(16, a.bt - r0);
     const int row = tid >> 4, col = 16 * cb + (tid & 15);
     const bool ok = row < nact;
@@ -274,23 +318,34 @@ __global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a_in) {
     const int arow = min(lane & 15, nact - 1), koff = a_koff<K>(lane, w);
     const long q = pt + arow;
     float av[K / 16];
-    float dh[PHASE == 0 ? K / 16 : 1], cc[PHASE == 0 ? K / 16 : 1], zz[PHASE == 0 ? K / 16 : 1], hh[PHASE == 0 ? K / 16 : 1];
+    float dh[PHASE == 0 ? K / 16 : 1], zz[PHASE == 0 ? K / 16 : 1], hh[PHASE == 0 ? K / 16 : 1];
+    // PHASE 0: rows whose session goes on at step t+1 ("carried", row < bnext) find d = dh (1-z) act'(h~) READY in dPre:
+    // the thread of PHASE 1 (step t+1) that finished dh_prev[row, col] also finished d[row, col] (one more element-wise
+    // product in its epilogue).  Only the rows of sessions that END here compute d themselves, from dHout alone.  The
+    // stamped build showed why it matters: this launch spent 1.3 us ISSUING its 26 loads per wave (86 KB per workgroup
+    // through one CU's 64 B/clk vector-memory path, every one of the 16 column-block workgroups of a row block
+    // re-reading the same four A-side arrays) against 0.24 us in the forward step; now 38 KB, like the forward step.
+    const bool carried = PHASE == 0 && (r0 + arow) < a.bnext;
     float4 b[K / 64];
     const float4* pk = reinterpret_cast<const float4*>(a.pk) + (size_t)(cb * 4 + w) * (K / 64) * 64 + lane;
 #pragma unroll
     for (int i = 0; i < K / 64; ++i) b[i] = pk[i * 64];
     __builtin_amdgcn_sched_barrier(0);       // the U slice is requested before anything that could wait
     if constexpr (PHASE == 0) {
-        // A operand in registers: PHASE 0 recomputes d = dh (1-z) act'(h~) for the lane's own k range (the workgroups
-        // of a row block do so redundantly; column block 0 also stores it), PHASE 1 reads dpre
-        gload_vec(dh, a.dHout + q * H + koff);
-        gload_vec(cc, a.dHc + q * H + koff);
-        gload_vec(zz, a.gates + q * GH + koff);
-        gload_vec(hh, a.gates + q * GH + 2 * H + koff);
+        // d is loaded by EVERY lane (a row that ends here reads a slot it is about to overwrite: valid memory, value unused):
+        // a load inside the `carried` branch makes hipcc merge the two definitions of av with waits in front of the
+        // remaining loads
+        gload_vec(av, a.dPre + q * GH + 2 * H + koff);
+        if (!carried) {
+            gload_vec(dh, a.dHout + q * H + koff);
+            gload_vec(zz, a.gates + q * GH + koff);
+            gload_vec(hh, a.gates + q * GH + 2 * H + koff);
+        }
     } else {
         gload_vec(av, a.dPre + q * GH + koff);
     }
-    float e_dh = 0.f, e_z = 0.f, e_r = 0.f, e_hh = 0.f, e_h0 = 0.f, e_t = 0.f;
+    float e_dh = 0.f, e_z = 0.f, e_r = 0.f, e_hh = 0.f, e_h0 = 0.f, e_t = 0.f, p_dh = 0.f, p_z = 0.f, p_hh = 0.f;
+    const int soGp = (a.pprev0 + r0) * GH * 4;
     if (PHASE == 0) {
         e_dh = bload(rDH, vh, soH) + bload(rC, (ok && r0 + row < a.bnext) ? vh : INVALID_OFF, soH);
         e_z = bload(rG, vg, soG);
@@ -299,15 +354,26 @@ __global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a_in) {
         e_h0 = bload(rH, a.first ? INVALID_OFF : vh, soP);
     } else {
         e_t = bload(rT, vh, soH);
+        p_dh = bload(rDH, vh, soP);                       // step t-1: its dHout, z and h~ for d[row, col]
+        p_z = bload(rG, vg, soGp);
+        p_hh = bload(rG, vg + 2 * H * 4, soGp);
     }
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(1);
+#ifdef SEQREC_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(2);
+#endif
     if constexpr (PHASE == 0) {
-        const float carry = (r0 + arow < a.bnext) ? 1.f : 0.f;     // dHc rows of sessions that ended here are stale
+        if (!carried) {
 #pragma unroll
-        for (int j = 0; j < K / 16; ++j) av[j] = (dh[j] + (carry != 0.f ? cc[j] : 0.f)) * (1.f - zz[j]) * act_grad<ACT>(hh[j]);
-        if (cb == 0 && aok) gstore_vec(av, a.dPre + q * GH + 2 * H + koff);
+            for (int j = 0; j < K / 16; ++j) av[j] = dh[j] * (1.f - zz[j]) * act_grad<ACT>(hh[j]);
+            if (cb == 0 && aok) gstore_vec(av, a.dPre + q * GH + 2 * H + koff);
+        }
     }
+    STAMP(5);
     float acc = tile_16x16_reg<K>(av, b, red, tid);
+    STAMP(3);
     const int srow = min(r0 + row, a.B - 1);
     if (PHASE == 0) {
         if (a.rmask) acc *= a.rmask[((long)2 * a.B + srow) * H + col];          // d(r*h*m2) -> d(r*h)
@@ -319,8 +385,15 @@ __global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a_in) {
             acc = (red[tid] + red[256 + tid]) * a.rmask[((long)0 * a.B + srow) * H + col] +
                   (red[512 + tid] + red[768 + tid]) * a.rmask[((long)1 * a.B + srow) * H + col];
         }
-        bstore(rC, vh, soP, e_t + acc);
+        const float dcar = e_t + acc;
+        bstore(rC, vh, soP, dcar);
+        bstore(rDP, vg + 2 * H * 4, soGp, (p_dh + dcar) * (1.f - p_z) * act_grad<ACT>(p_hh));      // d of step t-1, ready for its PHASE 0
     }
+#ifdef SEQREC_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    STAMP(4);
+    STAMP_REAL(7);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -394,11 +467,14 @@ __global__ __launch_bounds__(256) void gru_step_bwd0_wide(StepArgs a_in) {
     const int drow = tid >> 4, dk0 = (tid & 15) * KT;
     const bool dok = drow < nact;
     const long dq = pt + min(drow, nact - 1);
-    float dh[KT], cc[KT], zz[KT], hh[KT];
-    gload_vec(dh, a.dHout + dq * H + dk0);
-    gload_vec(cc, a.dHc + dq * H + dk0);
-    gload_vec(zz, a.gates + dq * GH + dk0);
-    gload_vec(hh, a.gates + dq * GH + 2 * H + dk0);
+    const bool carried = (r0 + min(drow, nact - 1)) < a.bnext;      // d of a carried row was finished by PHASE 1 of step t+1
+    float dv[KT], dh[KT], zz[KT], hh[KT];
+    gload_vec(dv, a.dPre + dq * GH + 2 * H + dk0);                  // every thread (see gru_step_bwd)
+    if (!carried) {
+        gload_vec(dh, a.dHout + dq * H + dk0);
+        gload_vec(zz, a.gates + dq * GH + dk0);
+        gload_vec(hh, a.gates + dq * GH + 2 * H + dk0);
+    }
     // epilogue operands of this lane's 4 output elements: rows 4q + r, column col
     const int q = lane >> 4, col = 64 * cbw + 16 * w + (lane & 15);
     const rsrc_t rDH = mk_rsrc(a.dHout), rH = mk_rsrc(a.Hout), rG = mk_rsrc(a.gates), rDP = mk_rsrc(a.dPre),
@@ -420,11 +496,11 @@ __global__ __launch_bounds__(256) void gru_step_bwd0_wide(StepArgs a_in) {
     }
     __builtin_amdgcn_sched_barrier(0);
     {
-        const float carry = (r0 + drow < a.bnext) ? 1.f : 0.f;
-        float dv[KT];
+        if (!carried) {
 #pragma unroll
-        for (int j = 0; j < KT; ++j) dv[j] = (dh[j] + (carry != 0.f ? cc[j] : 0.f)) * (1.f - zz[j]) * act_grad<ACT>(hh[j]);
-        if (cbw == 0 && dok) gstore_vec(dv, a.dPre + (pt + drow) * GH + 2 * H + dk0);
+            for (int j = 0; j < KT; ++j) dv[j] = dh[j] * (1.f - zz[j]) * act_grad<ACT>(hh[j]);
+            if (cbw == 0 && dok) gstore_vec(dv, a.dPre + (pt + drow) * GH + 2 * H + dk0);
+        }
         float* o = ab + drow * LDA + dk0;
 #pragma unroll
         for (int j = 0; j < KT / 4; ++j) reinterpret_cast<float4*>(o)[j] = make_float4(dv[4 * j], dv[4 * j + 1], dv[4 * j + 2], dv[4 * j + 3]);
@@ -876,6 +952,18 @@ int issue_graph(Plan& pl, hipStream_t st) {
     return e == hipSuccess ? 0 : (int)e;
 }
 }  // namespace
+
+#ifdef SEQREC_STAMP
+extern "C" int seqrec_debug_stamps(unsigned long long* host_out, int clear) {
+    hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 256 * 8);
+    if (e != hipSuccess) return (int)e;
+    if (clear) {
+        static unsigned long long zero[256 * 8] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), zero, sizeof(zero));
+    }
+    return e == hipSuccess ? 0 : (int)e;
+}
+#endif
 
 extern "C" int seqrec_graph_cache_clear(void) {
     std::lock_guard<std::mutex> lk(g_graph_mu);
