@@ -95,6 +95,10 @@ typedef struct seqrec_gemm_desc {
 } seqrec_gemm_desc;
 int seqrec_gemm_f32_grouped(int count, int a_kcontig, int b_kcontig, const seqrec_gemm_desc* descs_host,
                             int splitk, float* workspace, void* stream);
+/*      diagnostics (tests): force the workgroup tile of the LDS-DMA GEMM kernels -- tile 1 = 64x64, 2 = 128x64,
+ *      3 = 128x128 (grouped form: 1 or 2); <= 0 restores the built-in choice.  Results never depend on it beyond
+ *      the order of the split-K partial sums. */
+void seqrec_debug_gemm_tile(int tile, int grouped_tile);
 
 /* ---- recurrent scan over the ragged batch (Keras K.rnn under Masking).
  *      H must be 64, 128, 256 or 512 (callers zero-pad); H_real <= H are the live units.

@@ -279,6 +279,489 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int tile
         }
 }
 
+
+// ===================================================================================================
+// v2 tile body: both operand tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR staging,
+// no ds_write pass) into a 3-stage ring, TWO K tiles in flight across each barrier (counted vmcnt, raw
+// s_barrier).  The LDS images are lane-linear per DMA (1 KB per wave-instruction), so every swizzle is
+// applied on the per-lane SOURCE address and undone by the reading lane:
+//   K-contiguous operand  [r][16 k], 16-B chunk q of row r stored at chunk q ^ ((r >> 2) & 3): the MFMA operand of
+//       lane (row, kh) = 8 consecutive k = two conflict-free ds_read_b128;
+//   r-contiguous operand  [16 k][R r]: R = 128 -> rows of the wave's two 32-row MFMA tiles interleaved (row 2l + i),
+//       one ds_read_b64 per k feeds both tiles; R = 64 -> chunk ^ 8 on k rows 8..15, one ds_read_b32 per k.
+// K order inside a 16-deep tile: MFMA step j multiplies k = j (lanes 0-31) and k = 8 + j (lanes 32-63) -- the same for A
+// and B, so the sum is the exact fp32 sum in that fixed order.  Rows / K slices outside the matrix, null (negative)
+// gather indices and the K tail read 16 zero bytes (g_zero16) instead of being predicated.
+// LDS reads are inline asm: hipcc would otherwise put s_waitcnt vmcnt(0) in front of every ds_read that follows an
+// LDS-DMA (it cannot see that the stages differ) and drain the ring every K tile.
+__device__ __attribute__((aligned(16))) float g_zero16[4];
+
+typedef __attribute__((address_space(3))) float lds_float;
+__device__ __forceinline__ unsigned lds_addr(const float* p) { return (unsigned)(uintptr_t)(const lds_float*)p; }
+template <int OFF> __device__ __forceinline__ f32x4 lds_read_b128(unsigned addr) {
+    f32x4 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF)); return v;
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int OFF> __device__ __forceinline__ f32x2 lds_read_b64(unsigned addr) {
+    f32x2 v; asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF)); return v;
+}
+template <int OFF> __device__ __forceinline__ float lds_read_b32(unsigned addr) {
+    float v; asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF)); return v;
+}
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+__device__ __forceinline__ void glds16(const float* src, float* lds_dst_wave_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, 0, 0);
+}
+
+#ifdef SEQREC_GEMM_ABLATE      // timing-only diagnostic build (tools/bench_gemm2.py): 1 no MFMA, 2 no in-loop DMA, 4 no C stores, 8 no LDS reads
+__device__ int g_ablate;
+__device__ unsigned long long g_gemm_stamps[4096 * 8];     // per workgroup: s_memrealtime (100 MHz) at 6 points + HW_ID
+#define ABL(bit) (g_ablate_s & (bit))
+#define GSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_gemm_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ unsigned long long g_gemm_phase[4096 * 8];      // per workgroup (wave 0): shader cycles summed per loop section + iterations
+#define PH(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); ph[i] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define PH(i) do {} while (0)
+#define ABL(bit) false
+#define GSTAMP(i) do {} while (0)
+#endif
+constexpr int V2_STAGES = 3;
+constexpr int V2_IDX_CAP = 1024;      // K range per workgroup of a K-slice-gathered A operand (ids parked in LDS)
+template <int BM, int BN, bool AIDX_K> constexpr int v2_lds_floats() { return V2_STAGES * (BM + BN) * 16 + (AIDX_K ? V2_IDX_CAP : 0); }
+
+// one operand's per-lane DMA source state: NI wave-instructions per K tile
+template <int R> struct V2Src {
+    static constexpr int NI = R / 64;
+    const float* p[NI];     // source of the NEXT K tile (or g_zero16)
+    long step[NI];          // floats per K tile (0: stays on the zero chunk)
+    int koff[NI];           // first k (within the tile) this lane's chunk covers: tail validity
+    int roff[NI];           // r-contiguous gathered operand: column offset of the lane's chunk (else unused)
+};
+
+template <int R, bool KC>
+__device__ __forceinline__ void v2_src_setup(V2Src<R>& s, const float* X, long ld, long r0, long Rtot, long kbeg,
+                                             const int* row_idx, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < R / 64; ++i) {
+        const int p = wave + 4 * i;
+        if (KC) {
+            const int r = 16 * p + (lane >> 2);
+            const int sc = (lane & 3) ^ ((r >> 2) & 3);
+            const long gr = r0 + r;
+            long rowid = gr;
+            bool ok = gr < Rtot;
+            if (row_idx) { const int id = ok ? row_idx[gr] : -1; ok = id >= 0; rowid = id; }
+            s.koff[i] = 4 * sc; s.roff[i] = 0;
+            s.p[i] = ok ? X + rowid * ld + kbeg + 4 * sc : g_zero16;
+            s.step[i] = ok ? 16 : 0;
+        } else {
+            const int k = R == 64 ? 4 * p + (lane >> 4) : 2 * p + (lane >> 5);
+            const int c = lane & (R / 4 - 1);
+            const int sc = R == 64 ? c ^ ((k & 8) ? 8 : 0) : c;
+            const bool ok = r0 + 4 * sc < Rtot;
+            s.koff[i] = k; s.roff[i] = ok ? 4 * sc : -1;
+            s.p[i] = ok ? X + (kbeg + k) * ld + r0 + 4 * sc : g_zero16;
+            s.step[i] = ok ? 16 * ld : 0;
+        }
+    }
+}
+
+// bijective XCD remap: workgroups are dealt round-robin to the 8 XCDs, so give XCD x a CONTIGUOUS run of work items
+// (neighbouring tiles share their A rows / B columns through one L2)
+__device__ __forceinline__ int xcd_tile(int b, int n) {
+    const int x = b & 7, q = n >> 3, r = n & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+// work item (= workgroup) -> (problem, tile, K split)
+struct GemmGroup { GemmArgs g[4]; int ntiles[4]; };
+struct PlainMap {
+    const GemmArgs* g; int ntiles, nsplits;
+    __device__ int count() const { return ntiles * nsplits; }
+    __device__ void get(int item, int& p, int& tile, int& z, int& ns) const {
+        const int l = xcd_tile(item, ntiles * nsplits);
+        z = l / ntiles; tile = l - z * ntiles; p = 0; ns = nsplits;
+    }
+    __device__ GemmArgs load(int) const { return *g; }
+};
+struct GroupMap {          // the descriptors stay in the kernel-argument segment: problem p is picked by scalar selects
+    const GemmGroup* gg; int nprob, nsplits, total;
+    __device__ int count() const { return total; }
+    __device__ void get(int item, int& p, int& tile, int& z, int& ns) const {
+        int l = xcd_tile(item, total);
+        const int c0 = gg->ntiles[0] * nsplits, c1 = gg->ntiles[1] * nsplits, c2 = gg->ntiles[2] * nsplits;
+        int nt = gg->ntiles[0];
+        p = 0;
+        if (nprob > 1 && l >= c0) { l -= c0; p = 1; nt = gg->ntiles[1];
+            if (nprob > 2 && l >= c1) { l -= c1; p = 2; nt = gg->ntiles[2];
+                if (nprob > 3 && l >= c2) { l -= c2; p = 3; nt = gg->ntiles[3]; } } }
+        z = l / nt; tile = l - z * nt; ns = nsplits;
+    }
+    __device__ GemmArgs load(int p) const {
+        GemmArgs r = gg->g[0];
+        if (p == 1) r = gg->g[1];
+        if (p == 2) r = gg->g[2];
+        if (p == 3) r = gg->g[3];
+        return r;
+    }
+};
+
+__device__ __forceinline__ void glds16_to(const float* src, unsigned lds_byte_addr_wave_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(uintptr_t)lds_byte_addr_wave_uniform, 16, 0, 0);
+}
+
+// One work item (tile x K split of one problem) per workgroup.  K loop: a 3-stage LDS ring filled by LDS-DMA three K tiles
+// ahead of the MFMAs; the operand fragments of tile kt+1 are read into the second register set while the MFMAs of tile kt
+// run from the first, and every non-MFMA instruction of a step (wait, barrier, DMA issue, fragment reads, bookkeeping) sits
+// in the shadow of one of that step's MFMAs -- the order is pinned with sched_barriers.  The loop is split by what a step
+// still has to do (FULL: wait + barrier + DMA + reads; the last three steps drop the DMA, then the partial wait, then
+// everything), so the steady state carries no per-step conditions.
+enum { STEP_FULL = 0, STEP_NOISSUE = 1, STEP_NOISSUE0 = 2, STEP_LAST = 3 };
+
+template <int BM, int BN, bool A_KC, bool B_KC, bool AIDX, class Map>
+__device__ __forceinline__ void gemm2_body(const Map& map, float* smem) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int STAGE = (BM + BN) * 16;           // floats per ring stage: A image then B image
+    constexpr unsigned SB = STAGE * 4;              // bytes per stage
+    constexpr bool AIDX_K = AIDX && !A_KC;           // the index (if the item has one) runs along K
+    constexpr int NLD = BM / 64 + BN / 64;           // LDS-DMA instructions per wave per K tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, kh = lane >> 5;
+#ifdef SEQREC_GEMM_ABLATE
+    const int g_ablate_s = __builtin_amdgcn_readfirstlane(g_ablate);
+#endif
+    GSTAMP(0);
+#ifdef SEQREC_GEMM_ABLATE
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_gemm_stamps[blockIdx.x * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);   // HW_ID, XCC_ID
+#endif
+    int p, tile, zsplit, nsplits;
+    map.get(blockIdx.x, p, tile, zsplit, nsplits);
+    const GemmArgs g = map.load(p);
+    const long m0 = (long)(tile / g.tiles_n) * BM, n0 = (long)(tile % g.tiles_n) * BN;
+    const long kbeg = (long)zsplit * g.k_per_split;
+    const long kend = min(g.K, kbeg + g.k_per_split);
+    const int nk = (int)((kend - kbeg + 15) / 16);
+    const bool ktail = ((kend - kbeg) & 15) != 0;
+    const bool gather = AIDX_K && g.a_idx != nullptr;
+
+    // per-lane LDS read addresses (bytes) inside a stage
+    unsigned ra0, ra1 = 0, rb0, rb1 = 0;
+    const unsigned sm = lds_addr(smem);
+    if (A_KC) {
+        const int r = wm * (BM / 2) + lr, f = (lr >> 2) & 3;
+        ra0 = sm + (unsigned)(r * 64 + (((2 * kh) ^ f) * 16));
+        ra1 = sm + (unsigned)(r * 64 + (((2 * kh + 1) ^ f) * 16));
+    } else if (TM == 2) {
+        ra0 = sm + (unsigned)((8 * kh) * (BM * 4) + (wm * 64 + 2 * lr) * 4);
+    } else {
+        ra0 = sm + (unsigned)((8 * kh) * (BM * 4) + (((wm * 32 + lr) ^ (kh ? 32 : 0)) * 4));
+    }
+    if (B_KC) {
+        const int r = wn * (BN / 2) + lr, f = (lr >> 2) & 3;
+        rb0 = sm + (unsigned)(BM * 64 + r * 64 + (((2 * kh) ^ f) * 16));
+        rb1 = sm + (unsigned)(BM * 64 + r * 64 + (((2 * kh + 1) ^ f) * 16));
+    } else if (TN == 2) {
+        rb0 = sm + (unsigned)(BM * 64 + (8 * kh) * (BN * 4) + (wn * 64 + 2 * lr) * 4);
+    } else {
+        rb0 = sm + (unsigned)(BM * 64 + (8 * kh) * (BN * 4) + (((wn * 32 + lr) ^ (kh ? 32 : 0)) * 4));
+    }
+
+    // ---------------- DMA side
+    V2Src<BM> sa; V2Src<BN> sb;
+    v2_src_setup<BM, A_KC>(sa, g.A, g.lda, m0, g.M, kbeg, (AIDX && A_KC) ? g.a_idx : nullptr, wave, lane);
+    v2_src_setup<BN, B_KC>(sb, g.B, g.ldb, n0, g.N, kbeg, nullptr, wave, lane);
+    // K-slice gather: the item's K range of the index is parked in LDS; the ids of the NEXT tile to issue are read one
+    // issue ahead (nid), behind the step's closing lgkmcnt(0)
+    int* ids_s = reinterpret_cast<int*>(smem + V2_STAGES * STAGE);
+    const unsigned ids_a = lds_addr(smem + V2_STAGES * STAGE);
+    int nid[BM / 64];
+    auto read_ids = [&](int kt) {
+        const int t = kt < nk ? kt : nk - 1;
+#pragma unroll
+        for (int i = 0; i < BM / 64; ++i) nid[i] = __float_as_int(lds_read_b32<0>(ids_a + (unsigned)((t * 16 + sa.koff[i]) * 4)));
+    };
+    auto lgkm0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); };
+    if (gather) {
+        for (int i = tid; i < nk * 16; i += 256) ids_s[i] = kbeg + i < kend ? g.a_idx[kbeg + i] : -1;
+        __syncthreads();
+        read_ids(0);
+        lgkm0();
+    }
+    const unsigned dmaA = sm + (unsigned)wave * 1024u, dmaB = sm + (unsigned)(BM * 64) + (unsigned)wave * 1024u;   // + stage + 4096 i
+    int kt_i = 0;                 // next K tile to issue
+    unsigned sw = 0;              // byte offset of the ring stage it goes to
+    const float* zero16 = g_zero16;
+    asm volatile("" : "+v"(zero16));                   // keep the address in registers (else: a GOT load + wait in every step)
+    auto issue = [&]() {
+        if (__builtin_expect(ktail && kt_i == nk - 1, 0)) {   // workgroup-uniform, last tile only: k past the end reads zeros
+            asm volatile("" ::: "memory");             // a real branch, not 8 selects per step
+            const long k0 = kbeg + (long)kt_i * 16;
+#pragma unroll
+            for (int i = 0; i < BM / 64; ++i)
+                if (k0 + sa.koff[i] >= kend) sa.p[i] = zero16;
+#pragma unroll
+            for (int i = 0; i < BN / 64; ++i)
+                if (k0 + sb.koff[i] >= kend) sb.p[i] = zero16;
+        }
+        const bool dma = !(ABL(2) && kt_i >= 3);
+#pragma unroll
+        for (int i = 0; i < BM / 64; ++i) {
+            const float* src = sa.p[i];
+            sa.p[i] += sa.step[i];
+            if (gather) src = (nid[i] >= 0 && sa.roff[i] >= 0) ? g.A + (long)nid[i] * g.lda + m0 + sa.roff[i] : zero16;
+            if (dma) glds16_to(src, dmaA + sw + 4096u * i);
+        }
+#pragma unroll
+        for (int i = 0; i < BN / 64; ++i) {
+            if (dma) glds16_to(sb.p[i], dmaB + sw + 4096u * i);
+            sb.p[i] += sb.step[i];
+        }
+        if (gather) read_ids(kt_i + 1);
+        ++kt_i;
+        sw = sw == 2 * SB ? 0u : sw + SB;
+    };
+
+    // ---------------- operand fragments: two register sets (static indices: steps are instantiated per parity)
+    float a[2][TM][8], b[2][TN][8];
+    auto read_a = [&](auto Pc, unsigned so) {
+        constexpr int P = decltype(Pc)::value;
+#ifdef SEQREC_GEMM_ABLATE
+        if (ABL(8)) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[P][i][j] = 1.0f;
+            return;
+        }
+#endif
+        if constexpr (A_KC) {
+            static_for<0, TM>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                const f32x4 v0 = lds_read_b128<i * 2048>(ra0 + so), v1 = lds_read_b128<i * 2048>(ra1 + so);
+                a[P][i][0] = v0[0]; a[P][i][1] = v0[1]; a[P][i][2] = v0[2]; a[P][i][3] = v0[3];
+                a[P][i][4] = v1[0]; a[P][i][5] = v1[1]; a[P][i][6] = v1[2]; a[P][i][7] = v1[3];
+            });
+        } else {
+            static_for<0, 8>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                if constexpr (TM == 2) { const f32x2 v = lds_read_b64<j * BM * 4>(ra0 + so); a[P][0][j] = v[0]; a[P][TM - 1][j] = v[1]; }
+                else a[P][0][j] = lds_read_b32<j * BM * 4>(ra0 + so);
+            });
+        }
+    };
+    auto read_b = [&](auto Pc, unsigned so) {
+        constexpr int P = decltype(Pc)::value;
+#ifdef SEQREC_GEMM_ABLATE
+        if (ABL(8)) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int i = 0; i < TN; ++i) b[P][i][j] = 0.5f;
+            return;
+        }
+#endif
+        if constexpr (B_KC) {
+            static_for<0, TN>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                const f32x4 v0 = lds_read_b128<i * 2048>(rb0 + so), v1 = lds_read_b128<i * 2048>(rb1 + so);
+                b[P][i][0] = v0[0]; b[P][i][1] = v0[1]; b[P][i][2] = v0[2]; b[P][i][3] = v0[3];
+                b[P][i][4] = v1[0]; b[P][i][5] = v1[1]; b[P][i][6] = v1[2]; b[P][i][7] = v1[3];
+            });
+        } else {
+            static_for<0, 8>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                if constexpr (TN == 2) { const f32x2 v = lds_read_b64<j * BN * 4>(rb0 + so); b[P][0][j] = v[0]; b[P][TN - 1][j] = v[1]; }
+                else b[P][0][j] = lds_read_b32<j * BN * 4>(rb0 + so);
+            });
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto mfma_j = [&](auto Pc, auto Jc) {
+        constexpr int P = decltype(Pc)::value, j = decltype(Jc)::value;
+#ifdef SEQREC_GEMM_ABLATE
+        if (ABL(1)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) asm volatile("" :: "v"(a[P][i][j]));
+#pragma unroll
+            for (int i = 0; i < TN; ++i) asm volatile("" :: "v"(b[P][i][j]));
+            return;
+        }
+#endif
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj)
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[P][i][j], b[P][jj][j], acc[i][jj], 0, 0, 0);
+    };
+
+    // ---------------- prologue: three tiles in flight, tile 0 into fragment set 0
+    issue();
+    if (AIDX_K) lgkm0();
+    if (nk > 1) issue();
+    if (AIDX_K) lgkm0();
+    if (nk > 2) issue();
+    if (AIDX_K) lgkm0();
+    GSTAMP(1);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NLD) : "memory");
+    else if (nk == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    GSTAMP(2);
+    read_a(std::integral_constant<int, 0>{}, 0u);
+    read_b(std::integral_constant<int, 0>{}, 0u);
+    lgkm0();
+    unsigned sr = SB;             // byte offset of the ring stage the next fragment reads come from
+
+    // step kt: MFMAs of tile kt from set P.  Under them: wait for tile kt+1 (this wave's DMAs), barrier (every wave's
+    // DMAs of tile kt+1 have landed; everyone finished reading tile kt in the previous step, so its stage may be refilled),
+    // DMA of tile kt+3 into that stage, fragment reads of tile kt+1 into set P^1.
+    auto step = [&](auto Pc, auto Kc) {
+        constexpr int KIND = decltype(Kc)::value;
+        using Q = std::integral_constant<int, decltype(Pc)::value ^ 1>;
+        using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
+        using J2 = std::integral_constant<int, 2>; using J3 = std::integral_constant<int, 3>;
+        using J4 = std::integral_constant<int, 4>; using J5 = std::integral_constant<int, 5>;
+        using J6 = std::integral_constant<int, 6>; using J7 = std::integral_constant<int, 7>;
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_j(Pc, J0{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (KIND == STEP_FULL || KIND == STEP_NOISSUE) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD) : "memory");
+        if (KIND == STEP_NOISSUE0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_j(Pc, J1{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (KIND != STEP_LAST) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_j(Pc, J2{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (KIND == STEP_FULL) issue();
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_j(Pc, J3{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (KIND != STEP_LAST) read_a(Q{}, sr);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_j(Pc, J4{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (KIND != STEP_LAST) read_b(Q{}, sr);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_j(Pc, J5{});
+        __builtin_amdgcn_sched_barrier(0);
+        sr = sr == 2 * SB ? 0u : sr + SB;
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_j(Pc, J6{});
+        mfma_j(Pc, J7{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (KIND != STEP_LAST) lgkm0();
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using KF = std::integral_constant<int, STEP_FULL>;
+    using KN = std::integral_constant<int, STEP_NOISSUE>;
+    using KZ = std::integral_constant<int, STEP_NOISSUE0>;
+    using KL = std::integral_constant<int, STEP_LAST>;
+    auto tail = [&](auto Pc, int rem) {          // the last rem <= 3 steps, starting on set P
+        using Q = std::integral_constant<int, decltype(Pc)::value ^ 1>;
+        if (rem == 3) { step(Pc, KN{}); step(Q{}, KZ{}); step(Pc, KL{}); }
+        else if (rem == 2) { step(Pc, KZ{}); step(Q{}, KL{}); }
+        else step(Pc, KL{});
+    };
+    int kt = 0;
+    for (; kt + 4 < nk; kt += 2) { step(P0{}, KF{}); step(P1{}, KF{}); }
+    if (kt + 3 < nk) { step(P0{}, KF{}); ++kt; tail(P1{}, nk - kt); }
+    else tail(P0{}, nk - kt);
+    GSTAMP(3);
+
+    // ---------------- epilogue.  C/D map of the 32x32 MFMA: column lane = lane&31, row lane = (r&3) + 8*(r>>2) + 4*(lane>>5);
+    // tile (i, jj) covers rows 32 i + row lane (K-contiguous A, or one tile) or 2 row lane + i (interleaved), same for columns
+    float* Cb = g.C + (long)zsplit * g.M * g.ldc;   // split-K slabs use ldc = N
+    const bool splits = nsplits > 1;
+    constexpr bool ROW_IL = !A_KC && TM == 2, COL_IL = !B_KC && TN == 2;
+    const bool pair_ok = COL_IL && ((g.ldc & 1) == 0) && ((reinterpret_cast<uintptr_t>(Cb) & 7) == 0);
+    // fast path (interior tile, nothing to add): one per-lane base pointer + workgroup-uniform byte offsets
+    const bool plain = (splits || (!g.bias && !g.add_table && !g.accumulate)) && m0 + BM <= g.M && n0 + BN <= g.N &&
+                       g.ldc < (1l << 22) && (!COL_IL || pair_ok) && !ABL(4);
+    if (plain) {
+        const unsigned ld4 = (unsigned)g.ldc * 4u;
+        char* base = reinterpret_cast<char*>(Cb + (m0 + wm * (BM / 2) + (ROW_IL ? 8 * kh : 4 * kh)) * g.ldc + n0 + wn * (BN / 2) + (COL_IL ? 2 * lr : lr));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (r & 3) + 8 * (r >> 2);
+                const unsigned ro = (unsigned)(ROW_IL ? 2 * rl + i : 32 * i + rl) * ld4;
+                if (COL_IL) {
+                    *reinterpret_cast<f32x2*>(base + ro) = f32x2{acc[i][0][r], acc[i][TN - 1][r]};
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < TN; ++jj) *reinterpret_cast<float*>(base + ro + 128u * jj) = acc[i][jj][r];
+                }
+            }
+        GSTAMP(4);
+        GSTAMP(5);
+#ifdef SEQREC_GEMM_ABLATE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GSTAMP(6);
+#endif
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const long row = m0 + wm * (BM / 2) + (ROW_IL ? 2 * rl + i : 32 * i + rl);
+            if (row >= g.M) continue;
+            if (ABL(4) && acc[i][0][r] != 12345.678f) continue;
+            float v[TN];
+            long col[TN];
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) {
+                col[jj] = n0 + wn * (BN / 2) + (COL_IL ? 2 * lr + jj : 32 * jj + lr);
+                v[jj] = acc[i][jj][r];
+                if (col[jj] < g.N && !splits) {
+                    if (g.bias) v[jj] += g.bias[col[jj]];
+                    v[jj] += row_add(g, row, col[jj]);
+                    if (g.accumulate) v[jj] += Cb[row * g.ldc + col[jj]];
+                }
+            }
+            if (COL_IL && pair_ok && col[TN - 1] < g.N) {
+                *reinterpret_cast<f32x2*>(Cb + row * g.ldc + col[0]) = f32x2{v[0], v[TN - 1]};
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj)
+                    if (col[jj] < g.N) Cb[row * g.ldc + col[jj]] = v[jj];
+            }
+        }
+    GSTAMP(4);
+    GSTAMP(5);
+#ifdef SEQREC_GEMM_ABLATE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GSTAMP(6);
+#endif
+}
+
+// register budget: the 64x64 tile must keep 5 workgroups on a CU (c3: 1 280 tiles = 5 per CU; at 4 a fifth of them
+// runs as a second round), the larger tiles 3 / 2
+#define GEMM2_WAVES(BM, BN) __attribute__((amdgpu_waves_per_eu((BM) * (BN) <= 4096 ? 5 : (BM) * (BN) <= 8192 ? 3 : 2)))
+template <int BM, int BN, bool A_KC, bool B_KC, bool AIDX>
+__global__ __launch_bounds__(256) GEMM2_WAVES(BM, BN) void gemm2_f32_kernel(GemmArgs g, int ntiles, int nsplits) {
+    __shared__ __attribute__((aligned(16))) float smem[v2_lds_floats<BM, BN, AIDX && !A_KC>()];
+    const PlainMap map{&g, ntiles, nsplits};
+    gemm2_body<BM, BN, A_KC, B_KC, AIDX>(map, smem);
+}
+
 template <int BM, int BN, int BKT, bool A_KC, bool B_KC, bool AIDX = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #ifdef SEQREC_PROBE_XCD_SKIP       // timing probe only (tools/overlap_probe.py): workgroups dealt to the first N XCDs do nothing
@@ -288,13 +771,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 }
 
 // grouped launch: blockIdx.y picks one of up to 4 independent problems of the same layout
-struct GemmGroup { GemmArgs g[4]; int ntiles[4]; };
 template <int BM, int BN, int BKT, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(GemmGroup gg) {
     const int p = blockIdx.y;
     if ((int)blockIdx.x >= gg.ntiles[p]) return;
     if (gg.g[p].a_idx) gemm_tile_body<BM, BN, BKT, A_KC, B_KC, true>(gg.g[p], blockIdx.x, blockIdx.z, gridDim.z);
     else gemm_tile_body<BM, BN, BKT, A_KC, B_KC, false>(gg.g[p], blockIdx.x, blockIdx.z, gridDim.z);
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) GEMM2_WAVES(BM, BN) void gemm2_f32_grouped_kernel(GemmGroup gg, int nprob, int nsplits, int total) {   // layout (A, B both r-contiguous) only
+    __shared__ __attribute__((aligned(16))) float smem[v2_lds_floats<BM, BN, true>()];
+    const GroupMap map{&gg, nprob, nsplits, total};
+    gemm2_body<BM, BN, false, false, true>(map, smem);
 }
 
 struct ReduceGroup { const float* ws[4]; float* C[4]; const float* bias[4]; long M[4], N[4], ldc[4]; int accumulate[4]; };
@@ -352,6 +841,55 @@ int launch_gemm_bk(int a_kc, int b_kc, GemmArgs& g, int splits, hipStream_t st) 
     SEQREC_LAUNCH_CHECK();
     return 0;
 }
+int g_v2_tile = -1, g_v2_gtile = -1;      // seqrec_debug_gemm_tile(): tests force every tile shape through every layout
+// v2 (LDS-DMA ring) launcher.  Eligible: 16-byte loads legal on both operands, K % 4 == 0 for a K-contiguous operand
+// (its 16-byte chunks run along K), a K-slice-gathered A with at most V2_IDX_CAP k per workgroup, plain epilogue.
+inline bool gemm2_eligible(int a_kc, int b_kc, const GemmArgs& g) {
+    static const bool on = !(getenv("SEQREC_GEMM_V2") && atoi(getenv("SEQREC_GEMM_V2")) == 0);      // tuning switch
+    if (!on || !g.a_vec || !g.b_vec || g.epi != 0 || g.K <= 0) return false;
+    if ((a_kc || b_kc) && (g.K % 4 != 0)) return false;
+    if (g.a_idx && !a_kc && g.k_per_split > V2_IDX_CAP) return false;
+    if (g.a_idx && a_kc && b_kc) return false;               // not instantiated (no caller)
+    if (g.a_idx && !a_kc && b_kc) return false;
+    return true;
+}
+inline int gemm2_grid(long nitems) { return (int)nitems; }      // one work item per workgroup
+template <int BM, int BN>
+int launch_gemm2(int a_kc, int b_kc, GemmArgs& g, int splits, hipStream_t st) {
+    const long tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    g.tiles_n = (int)tiles_n;
+    const int ntiles = (int)(tiles_m * tiles_n);
+    dim3 grid((unsigned)gemm2_grid((long)ntiles * splits)), block(256);
+    if (g.a_idx) {
+        if (a_kc) hipLaunchKernelGGL((gemm2_f32_kernel<BM, BN, true, false, true>), grid, block, 0, st, g, ntiles, splits);
+        else hipLaunchKernelGGL((gemm2_f32_kernel<BM, BN, false, false, true>), grid, block, 0, st, g, ntiles, splits);
+    } else if (a_kc && b_kc) hipLaunchKernelGGL((gemm2_f32_kernel<BM, BN, true, true, false>), grid, block, 0, st, g, ntiles, splits);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm2_f32_kernel<BM, BN, true, false, false>), grid, block, 0, st, g, ntiles, splits);
+    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm2_f32_kernel<BM, BN, false, true, false>), grid, block, 0, st, g, ntiles, splits);
+    else hipLaunchKernelGGL((gemm2_f32_kernel<BM, BN, false, false, false>), grid, block, 0, st, g, ntiles, splits);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+// tile choice of v2 (measured at the c3 shapes, a 25 088-row batch and 4096^3, tools/bench_gemm2.py): the per-workgroup
+// prologue + epilogue favour MANY small workgroups until there are enough tiles for several rounds per CU
+inline int gemm2_tile(long M, long N, int splits) {
+    static const int forced = getenv("SEQREC_GEMM_V2_TILE") ? atoi(getenv("SEQREC_GEMM_V2_TILE")) : 0;      // tuning switch
+    if (g_v2_tile > 0) return g_v2_tile;
+    if (forced) return forced;
+    const long t128 = ((M + 127) / 128) * ((N + 127) / 128) * splits;
+    const long t12864 = ((M + 127) / 128) * ((N + 63) / 64) * splits;
+    if (t128 >= 1024) return 3;
+    if (t12864 >= 2048) return 2;
+    return 1;
+}
+int launch_gemm2_auto(int a_kc, int b_kc, GemmArgs& g, int splits, hipStream_t st) {
+    switch (gemm2_tile(g.M, g.N, splits)) {
+        case 3: return launch_gemm2<128, 128>(a_kc, b_kc, g, splits, st);
+        case 2: return launch_gemm2<128, 64>(a_kc, b_kc, g, splits, st);
+        default: return launch_gemm2<64, 64>(a_kc, b_kc, g, splits, st);
+    }
+}
+
 // one barrier per 32-deep K tile when the per-split K is long enough (halves the barrier count);
 // 128x128 stays at 16 (LDS: 2 x 2 x 32 x 130 x 4 B would cost occupancy)
 template <int BM, int BN>
@@ -363,6 +901,23 @@ int launch_gemm(int a_kc, int b_kc, GemmArgs& g, int splits, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef SEQREC_GEMM_ABLATE
+extern "C" void seqrec_debug_gemm_stamps(unsigned long long* out, int clear) {      // diagnostic build only
+    if (clear) { (void)hipMemset((void*)nullptr, 0, 0); static unsigned long long z[4096 * 8]; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), z, sizeof(z)); }
+    else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps), sizeof(unsigned long long) * 4096 * 8);
+}
+extern "C" void seqrec_debug_gemm_phases(unsigned long long* out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_phase), sizeof(unsigned long long) * 4096 * 8);
+}
+#endif
+extern "C" void seqrec_debug_gemm_tile(int tile, int grouped_tile) {
+    g_v2_tile = tile; g_v2_gtile = grouped_tile;
+#ifdef SEQREC_GEMM_ABLATE
+    const int m = getenv("SEQREC_GEMM_ABLATE") ? atoi(getenv("SEQREC_GEMM_ABLATE")) : 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ablate), &m, sizeof(int));
+#endif
+}
 
 extern "C" int64_t seqrec_gemm_workspace_floats(int64_t M, int64_t N, int splitk) {
     return splitk > 1 ? (int64_t)splitk * M * N : 0;
@@ -410,7 +965,8 @@ extern "C" int seqrec_gemm_f32_fused(int a_kcontig, int b_kcontig, int64_t M, in
     const long t12864 = ((M + 127) / 128) * ((N + 63) / 64) * splits;
     static const long thr = getenv("SEQREC_GEMM_TILE_THR") ? atol(getenv("SEQREC_GEMM_TILE_THR")) : 1024;   // tuning switch
     int rc;
-    if (g.a_idx) rc = launch_gemm<64, 64>(a_kcontig, b_kcontig, g, splits, st);
+    if (gemm2_eligible(a_kcontig, b_kcontig, g)) rc = launch_gemm2_auto(a_kcontig, b_kcontig, g, splits, st);
+    else if (g.a_idx) rc = launch_gemm<64, 64>(a_kcontig, b_kcontig, g, splits, st);
     else if (t128 >= thr) rc = launch_gemm<128, 128>(a_kcontig, b_kcontig, g, splits, st);
     else if (t12864 >= thr) rc = launch_gemm<128, 64>(a_kcontig, b_kcontig, g, splits, st);
     else rc = launch_gemm<64, 64>(a_kcontig, b_kcontig, g, splits, st);
@@ -528,8 +1084,27 @@ extern "C" int seqrec_gemm_f32_grouped(int count, int a_kcontig, int b_kcontig, 
         rg.ldc[i] = d[i].ldc; rg.accumulate[i] = d[i].accumulate;
         wsoff += (long)splits * g.M * g.N;
     }
+    bool v2 = !a_kcontig && !b_kcontig;
+    for (int i = 0; i < count && v2; ++i) v2 = gemm2_eligible(0, 0, gg.g[i]);
+    static const int gtile_env = getenv("SEQREC_GEMM_V2_GTILE") ? atoi(getenv("SEQREC_GEMM_V2_GTILE")) : 1;      // tuning switch
+    const int gtile = g_v2_gtile > 0 ? g_v2_gtile : gtile_env;
+    if (v2 && gtile == 2) {
+        maxtiles = 0;
+        for (int i = 0; i < count; ++i) {
+            const long tm = (gg.g[i].M + 127) / 128, tn = (gg.g[i].N + 63) / 64;
+            gg.g[i].tiles_n = (int)tn; gg.ntiles[i] = (int)(tm * tn);
+            if (tm * tn > maxtiles) maxtiles = tm * tn;
+        }
+    }
     dim3 grid((unsigned)maxtiles, (unsigned)count, (unsigned)splits), block(256);
-    if (a_kcontig && b_kcontig) hipLaunchKernelGGL((gemm_f32_grouped_kernel<64, 64, 16, true, true>), grid, block, 0, st, gg);
+    if (v2) {
+        long total = 0;
+        for (int i = 0; i < count; ++i) total += (long)gg.ntiles[i] * splits;
+        dim3 pgrid((unsigned)gemm2_grid(total));
+        if (gtile == 2) hipLaunchKernelGGL((gemm2_f32_grouped_kernel<128, 64>), pgrid, block, 0, st, gg, count, splits, (int)total);
+        else hipLaunchKernelGGL((gemm2_f32_grouped_kernel<64, 64>), pgrid, block, 0, st, gg, count, splits, (int)total);
+    }
+    else if (a_kcontig && b_kcontig) hipLaunchKernelGGL((gemm_f32_grouped_kernel<64, 64, 16, true, true>), grid, block, 0, st, gg);
     else if (a_kcontig && !b_kcontig) hipLaunchKernelGGL((gemm_f32_grouped_kernel<64, 64, 16, true, false>), grid, block, 0, st, gg);
     else if (!a_kcontig && b_kcontig) hipLaunchKernelGGL((gemm_f32_grouped_kernel<64, 64, 16, false, true>), grid, block, 0, st, gg);
     else hipLaunchKernelGGL((gemm_f32_grouped_kernel<64, 64, 16, false, false>), grid, block, 0, st, gg);

@@ -545,9 +545,9 @@ class ShardedEngine(Engine):
             wgrad = [(Hp, GHp, n, Hout, Hp, dPre, GHp, Gd["U"], GHp, d["prev"])]
         wgrad.append((Dp, GHp, n, X, Dp, dPre, GHp, Gd["W"], GHp))
         if c.use_bias:                       # db = ones^T . dPre in the same grouped launch (M = 1)
-            wgrad.append((1, GHp, n, self._ones(n), 1, dPre, GHp, Gd["b"], GHp))
+            wgrad.append((1, GHp, n, self._ones(n), self.ONES_LD, dPre, GHp, Gd["b"], GHp))
         tiles = sum(((w_[0] + 63) // 64) * ((w_[1] + 63) // 64) for w_ in wgrad)
-        sk = int(max(1, min(32, -(-SPLITK_TARGET_WGS // max(tiles, 1)), n // 128)))
+        sk = self._splitk_tiles(tiles, n)
         wsp = self.buf("gemm_ws", sum(sk * w_[0] * w_[1] for w_ in wgrad)) if sk > 1 else None
         call("seqrec_gemm_f32_grouped", len(wgrad), 0, 0, _lib.gemm_descs(wgrad), sk, ptr(wsp), st, tag="dW+dU")
         if self.unified and reduce_dense:

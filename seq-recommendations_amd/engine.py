@@ -32,7 +32,8 @@ INT32_MAX = 2 ** 31 - 1
 import os as _os
 # split-K is raised until about this many workgroups are in flight (4 per CU; measured on the c3
 # backward shapes: 512 -> 1024 takes dEneg from 53 to 45 us and dH from 46 to 43 us)
-SPLITK_TARGET_WGS = int(_os.environ.get("SEQREC_SPLITK_WGS", "1024"))
+SPLITK_TARGET_WGS = int(_os.environ.get("SEQREC_SPLITK_WGS", "512"))
+SPLITK_MIN_K = int(_os.environ.get("SEQREC_SPLITK_MIN_K", "512"))
 
 # Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg):
 # _PROF = {"events": [(name, tag, start_event, end_event), ...]} while enabled, else None.
@@ -309,7 +310,7 @@ class Engine:
                 use.append(self._splitk(m, kin, GHp) * m * kin)                                          # dX
             shapes = [(Hp, GHp), (kin, GHp), (1, GHp)]                                                   # grouped dU, dW, db
             tiles = sum(((a + 63) // 64) * ((b + 63) // 64) for a, b in shapes if a)
-            sk = int(max(1, min(32, -(-SPLITK_TARGET_WGS // max(tiles, 1)), m // 128)))
+            sk = self._splitk_tiles(tiles, m)
             use.append(sk * sum(a * b for a, b in shapes))
             ws = max(ws, max(use))
         need["gemm_ws"] = ws
@@ -317,12 +318,16 @@ class Engine:
             self.buf(name, int(max(sz, 1)))
         self.buf("neg", c.K if c.output == "sampled" else 1, dtype=torch.int32)
 
+    ONES_LD = 4
+
     def _ones(self, n):
+        """[n, 4] ones, used as the K x 1 operand of db = ones^T . dPre with lda = 4: 16-byte rows keep the grouped
+        weight-gradient launch on the LDS-DMA GEMM kernels (columns 1-3 are rows >= M, never stored)."""
         t = self.ws.get("_ones")
-        if t is None or t.numel() < n:
-            t = torch.ones(max(n, 4096), dtype=torch.float32, device=self.dev)
+        if t is None or t.numel() < n * self.ONES_LD:
+            t = torch.ones(max(n, 4096) * self.ONES_LD, dtype=torch.float32, device=self.dev)
             self.ws["_ones"] = t
-        return t[:n]
+        return t[:n * self.ONES_LD]
 
     def gemm(self, a_kc, b_kc, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, accumulate=0, splitk=1, tag=None,
              ws_name="gemm_ws", fuse=None):
@@ -341,9 +346,13 @@ class Engine:
 
     @staticmethod
     def _splitk(M, N, K):
-        """Split K until ~SPLITK_TARGET_WGS workgroups are in flight; slabs are reduced deterministically."""
-        tiles = ((M + 63) // 64) * ((N + 63) // 64)
-        return int(max(1, min(32, -(-SPLITK_TARGET_WGS // max(tiles, 1)), K // 128)))
+        """Split K until about SPLITK_TARGET_WGS workgroups are in flight, never below SPLITK_MIN_K per slab: every split
+        costs a slab round trip + a share of the reduce launch (tools/bench_gemm2.py: dH 3, dEneg 4, dX 1, dW+dU 5 at c3)."""
+        return Engine._splitk_tiles(((M + 63) // 64) * ((N + 63) // 64), K)
+
+    @staticmethod
+    def _splitk_tiles(tiles, K):
+        return int(max(1, min(32, SPLITK_TARGET_WGS // max(tiles, 1), K // SPLITK_MIN_K)))
 
     # ------------------------------------------------------------------ parameters (Keras layouts)
     def _gate_pad(self, w, rows_p):
@@ -828,13 +837,13 @@ class Engine:
         if bias_in_group:
             if 0 < len(wgrad) < 4:
                 # db = ones^T . dPre rides in the same launch as the other token reductions (M = 1)
-                wgrad.append((1, GHp, n, self._ones(n), 1, dPre, GHp, Gd["b"], GHp))
+                wgrad.append((1, GHp, n, self._ones(n), self.ONES_LD, dPre, GHp, Gd["b"], GHp))
             else:
                 call("seqrec_colsum", ptr(dPre), n, GHp, GHp, ptr(Gd["b"]), 0, ptr(cs_ws), st)
         if wgrad:
             # the weight gradients A^T . dPre all reduce over the tokens: one grouped split-K launch
             tiles = sum(((w_[0] + 63) // 64) * ((w_[1] + 63) // 64) for w_ in wgrad)
-            sk = int(max(1, min(32, -(-SPLITK_TARGET_WGS // max(tiles, 1)), n // 128)))
+            sk = self._splitk_tiles(tiles, n)
             wsz = sum(sk * w_[0] * w_[1] for w_ in wgrad)
             wsp = self.buf("gemm_ws", wsz) if sk > 1 else None
             call("seqrec_gemm_f32_grouped", len(wgrad), 0, 0, _lib.gemm_descs(wgrad), sk, ptr(wsp), st, tag="dW+dU")

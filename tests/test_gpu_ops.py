@@ -60,6 +60,30 @@ def test_gemm_layouts(M, N, K, a_kc, b_kc):
     assert err <= 2e-5 * max(1.0, np.sqrt(K)), err
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 0), (1, 1), (0, 0), (0, 1)])
+def test_gemm_lds_dma_kernels_every_tile_every_layout(tile, a_kc, b_kc):
+    """The LDS-DMA GEMM (gemm.hip v2): every workgroup tile x every operand layout on shapes with ragged M / N edges,
+    a K tail (K % 16 != 0), split-K, bias and accumulate, against float64 numpy; integer operands make it bit-exact."""
+    lib = L.load()
+    try:
+        lib.seqrec_debug_gemm_tile(tile, 0)
+        for (M, N, K, splitk) in [(64, 64, 16, 1), (130, 68, 100, 1), (300, 200, 72, 1), (516, 260, 132, 3), (2604, 768, 256, 1),
+                                  (1500, 2000, 256, 1), (384, 256, 2604, 5)]:
+            rng = np.random.default_rng(M + N + K + tile)
+            A = rng.integers(-4, 5, size=(M, K)).astype(np.float32)
+            Bm = rng.integers(-4, 5, size=(K, N)).astype(np.float32)
+            bias = rng.integers(-3, 4, size=N).astype(np.float32)
+            C0 = rng.integers(-9, 10, size=(M, N)).astype(np.float32)
+            C = dev(C0)
+            gemm(a_kc, b_kc, M, N, K, dev(A if a_kc else A.T.copy()), K if a_kc else M, dev(Bm.T.copy() if b_kc else Bm), K if b_kc else N,
+                 C, N, bias=dev(bias), acc=1, splitk=splitk)
+            ref = (A.astype(np.float64) @ Bm.astype(np.float64) + bias + C0).astype(np.float32)
+            np.testing.assert_array_equal(C.cpu().numpy(), ref, err_msg=str((M, N, K, splitk)))
+    finally:
+        lib.seqrec_debug_gemm_tile(0, 0)
+
+
 def test_gemm_is_exact_fp32_fma_chain_on_integers():
     # small integers: every product and partial sum is exact -> bit-exact result; asymmetric B
     # catches a transposed C write, A = I catches a wrong operand map.
@@ -629,8 +653,17 @@ def test_ordered_norm_equals_the_atomic_norm_and_is_reproducible():
     assert torch.equal(lo, lo2)                                                                     # same fixed order
 
 
+@pytest.fixture(params=[0, 2, 3])
+def forced_gemm_tile(request):
+    """0 = the library's own tile choice; 2 / 3 force the 128x64 / 128x128 LDS-DMA tiles (grouped form: 128x64)."""
+    lib = L.load()
+    lib.seqrec_debug_gemm_tile(request.param, min(request.param, 2))
+    yield request.param
+    lib.seqrec_debug_gemm_tile(0, 0)
+
+
 @pytest.mark.parametrize("splitk", [1, 5])
-def test_gemm_fused_gathered_a_operand_and_row_add(splitk):
+def test_gemm_fused_gathered_a_operand_and_row_add(splitk, forced_gemm_tile):
     """seqrec_gemm_f32_fused against numpy: (1) A rows read through an index (x.W with x = E[ids], -1 = zero row),
     bit-identical to the GEMM on the materialised gather; (2) the index along K for the stored-KxM form
     (Hout[prev]^T . dPre, ragged sizes); (3) the row add of the final write (dH += dlt * Eout[tgt]) with and

@@ -25,7 +25,7 @@ def test_library_exports_every_symbol_in_the_header():
     assert lib.seqrec_build_arch() == b"gfx950"
     # argument validation happens on the host, before any launch: callable without a GPU
     assert lib.seqrec_gather_rows(None, None, None, -1, 8, None, None, 0, None) == -1
-    assert lib.seqrec_rnn_upack_floats(2, 256) == 2 * 3 * 256 * 256
+    assert lib.seqrec_rnn_upack_floats(2, 256) == 2 * 3 * 256 * 256 + 256 * 256      # + the wide BPTT form of U_h^T
 
 
 def test_engine_refuses_to_run_without_gpu_or_library():
