@@ -99,6 +99,10 @@ int seqrec_gemm_f32_grouped(int count, int a_kcontig, int b_kcontig, const seqre
  *      3 = 128x128 (grouped form: 1 or 2); <= 0 restores the built-in choice.  Results never depend on it beyond
  *      the order of the split-K partial sums. */
 void seqrec_debug_gemm_tile(int tile, int grouped_tile);
+/*      diagnostics (tests): GRU scan form of seqrec_rnn_fwd_stepwise / _bwd_stepwise -- 1 cluster (one launch, in-kernel
+ *      exchange between the column-slice workgroups of a row block), 0 step-wise (one launch per recurrent product),
+ *      -1 the built-in choice (cluster whenever the call qualifies; SEQREC_SCAN_CLUSTER=0 disables it). */
+void seqrec_debug_scan_cluster(int mode);
 
 /* ---- recurrent scan over the ragged batch (Keras K.rnn under Masking).
  *      H must be 64, 128, 256 or 512 (callers zero-pad); H_real <= H are the live units.

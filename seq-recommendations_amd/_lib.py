@@ -41,6 +41,7 @@ _SIGS = {
     "seqrec_gemm_workspace_floats": [L, L, I],
     "seqrec_gemm_f32_grouped": [I, I, I, P, I, P, P],
     "seqrec_debug_gemm_tile": [I, I],
+    "seqrec_debug_scan_cluster": [I],
     "seqrec_rnn_upack_floats": [I, I],
     "seqrec_rnn_pack_u": [I, I, P, P, P],
     "seqrec_rnn_fwd": [I, I, I, I, I, I, P, P, P, P, P, P, P],
@@ -90,6 +91,7 @@ _SIGS = {
 }
 _RESTYPES = {
     "seqrec_debug_gemm_tile": None,
+    "seqrec_debug_scan_cluster": None,
     "seqrec_build_arch": C.c_char_p,
     "seqrec_gemm_workspace_floats": L,
     "seqrec_rnn_upack_floats": L,

@@ -530,6 +530,7 @@ __device__ __forceinline__ void gemm2_body(const Map& map, float* smem) {
     float a[2][TM][8], b[2][TN][8];
     auto read_a = [&](auto Pc, unsigned so) {
         constexpr int P = decltype(Pc)::value;
+        const unsigned ra0s = ra0 + so, ra1s = ra1 + so;      // one address add per operand half, immediates for the rest
 #ifdef SEQREC_GEMM_ABLATE
         if (ABL(8)) {
 #pragma unroll
@@ -542,20 +543,21 @@ __device__ __forceinline__ void gemm2_body(const Map& map, float* smem) {
         if constexpr (A_KC) {
             static_for<0, TM>([&](auto I) {
                 constexpr int i = decltype(I)::value;
-                const f32x4 v0 = lds_read_b128<i * 2048>(ra0 + so), v1 = lds_read_b128<i * 2048>(ra1 + so);
+                const f32x4 v0 = lds_read_b128<i * 2048>(ra0s), v1 = lds_read_b128<i * 2048>(ra1s);
                 a[P][i][0] = v0[0]; a[P][i][1] = v0[1]; a[P][i][2] = v0[2]; a[P][i][3] = v0[3];
                 a[P][i][4] = v1[0]; a[P][i][5] = v1[1]; a[P][i][6] = v1[2]; a[P][i][7] = v1[3];
             });
         } else {
             static_for<0, 8>([&](auto J) {
                 constexpr int j = decltype(J)::value;
-                if constexpr (TM == 2) { const f32x2 v = lds_read_b64<j * BM * 4>(ra0 + so); a[P][0][j] = v[0]; a[P][TM - 1][j] = v[1]; }
-                else a[P][0][j] = lds_read_b32<j * BM * 4>(ra0 + so);
+                if constexpr (TM == 2) { const f32x2 v = lds_read_b64<j * BM * 4>(ra0s); a[P][0][j] = v[0]; a[P][TM - 1][j] = v[1]; }
+                else a[P][0][j] = lds_read_b32<j * BM * 4>(ra0s);
             });
         }
     };
     auto read_b = [&](auto Pc, unsigned so) {
         constexpr int P = decltype(Pc)::value;
+        const unsigned rb0s = rb0 + so, rb1s = rb1 + so;
 #ifdef SEQREC_GEMM_ABLATE
         if (ABL(8)) {
 #pragma unroll
@@ -568,15 +570,15 @@ __device__ __forceinline__ void gemm2_body(const Map& map, float* smem) {
         if constexpr (B_KC) {
             static_for<0, TN>([&](auto I) {
                 constexpr int i = decltype(I)::value;
-                const f32x4 v0 = lds_read_b128<i * 2048>(rb0 + so), v1 = lds_read_b128<i * 2048>(rb1 + so);
+                const f32x4 v0 = lds_read_b128<i * 2048>(rb0s), v1 = lds_read_b128<i * 2048>(rb1s);
                 b[P][i][0] = v0[0]; b[P][i][1] = v0[1]; b[P][i][2] = v0[2]; b[P][i][3] = v0[3];
                 b[P][i][4] = v1[0]; b[P][i][5] = v1[1]; b[P][i][6] = v1[2]; b[P][i][7] = v1[3];
             });
         } else {
             static_for<0, 8>([&](auto J) {
                 constexpr int j = decltype(J)::value;
-                if constexpr (TN == 2) { const f32x2 v = lds_read_b64<j * BN * 4>(rb0 + so); b[P][0][j] = v[0]; b[P][TN - 1][j] = v[1]; }
-                else b[P][0][j] = lds_read_b32<j * BN * 4>(rb0 + so);
+                if constexpr (TN == 2) { const f32x2 v = lds_read_b64<j * BN * 4>(rb0s); b[P][0][j] = v[0]; b[P][TN - 1][j] = v[1]; }
+                else b[P][0][j] = lds_read_b32<j * BN * 4>(rb0s);
             });
         }
     };

@@ -18,6 +18,7 @@
 // stages h_prev in LDS.  Exact fp32 (v_mfma_f32_16x16x4_f32).  Needs the step offsets on the HOST to size
 // the launches.
 #include "common.h"
+#include "rnn_cluster.h"
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -985,6 +986,10 @@ extern "C" int seqrec_rnn_fwd_stepwise(int cell, int act, int H, int H_real, int
     const int J = H / 64;
     const long HH = (long)H * H;
     const int32_t* soh = step_off_host;
+    if (cell == SEQREC_CELL_GRU && !rmask) {          // cluster form: one launch, in-kernel exchange (rnn_cluster.hip)
+        int rc = 0;
+        if (seqrec_cluster_gru_fwd(act, H, H_real, T, soh, XW, Hout, gates, aux, upack, st, &rc)) return rc;
+    }
     Plan pl;
     pl.reserve(2 * (size_t)T);
     StepArgs a = {};

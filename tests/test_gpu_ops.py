@@ -556,6 +556,46 @@ def test_stepwise_scan_vs_oracle_and_persistent(cell, H, B, maxlen, act, graph):
         assert L.load().seqrec_graph_cache_clear() == 0
 
 
+@pytest.mark.parametrize("H,B,maxlen,act", [(256, 512, 40, "tanh"), (256, 700, 9, "relu"), (128, 333, 25, "tanh"), (64, 40, 12, "linear"),
+                                            (512, 100, 17, "tanh"), (256, 5, 60, "tanh"), (256, 16, 1, "tanh")])
+def test_cluster_scan_equals_stepwise_scan(H, B, maxlen, act):
+    """The one-launch cluster form of the GRU scan (rnn_cluster.hip: in-kernel exchange between the column-slice
+    workgroups of a row block) against the launch-per-product form on the same inputs: same arithmetic element for
+    element, so Hout / gates / r*h_prev (and dPre) agree bit for bit; run twice (flag epochs advance between calls)."""
+    lib = L.load()
+    rng = np.random.default_rng(H + B + maxlen)
+    rb, XW, U = packed_scan_inputs(rng, "gru", H, B, maxlen)
+    n = rb.n_tok
+    ci = L.CELL["gru"]
+    up = torch.empty(int(lib.seqrec_rnn_upack_floats(ci, H)), device="cuda")
+    XWd, Ud = dev(XW), dev(U)
+    call("seqrec_rnn_pack_u_stepwise", ci, H, ptr(Ud), ptr(up), st())
+    so = rb.step_off
+    dHd = dev((rng.normal(size=(n, H)) * 0.5).astype(np.float32))
+    out = {}
+    try:
+        for mode in (0, 1, 1):
+            lib.seqrec_debug_scan_cluster(mode)
+            Hout = torch.full((n, H), float("nan"), device="cuda"); gates = torch.full((n, 3 * H), float("nan"), device="cuda")
+            aux = torch.full((n, H), float("nan"), device="cuda")
+            call("seqrec_rnn_fwd_stepwise", ci, L.ACT[act], H, H - 3, rb.T, rb.B, None, so.ctypes.data, ptr(XWd), ptr(Hout), ptr(gates),
+                 ptr(aux), ptr(up), None, 0, st())
+            dPre = torch.full((n, 3 * H), float("nan"), device="cuda")
+            ws = torch.full((2 * n * H,), float("nan"), device="cuda")
+            call("seqrec_rnn_bwd_stepwise", ci, L.ACT[act], H, H - 3, rb.T, rb.B, None, so.ctypes.data, n, ptr(dHd), ptr(Hout), ptr(gates),
+                 ptr(aux), ptr(dPre), ptr(up), ptr(ws), None, 0, st())
+            torch.cuda.synchronize()
+            got = (Hout.cpu().numpy(), gates.cpu().numpy(), aux.cpu().numpy(), dPre.cpu().numpy())
+            if mode == 0:
+                out = got
+            else:
+                for name, x, y in zip(("Hout", "gates", "aux", "dPre"), out, got):
+                    assert np.isfinite(y).all(), name
+                    np.testing.assert_array_equal(x, y, err_msg=name)
+    finally:
+        lib.seqrec_debug_scan_cluster(-1)
+
+
 @pytest.mark.parametrize("width,V,sizes", [(256, 5000, (2603, 2000, 2603)), (1, 300, (700, 50)), (100, 64, (900,)),
                                            (512, 2000, (4000, 4000)), (2048, 40, (300, 17)), (64, 7, (5000, 3, 129))])
 def test_sorted_merge_is_bitwise_reproducible_and_equals_the_atomic_scatter(width, V, sizes):
