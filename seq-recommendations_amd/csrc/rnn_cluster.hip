@@ -194,6 +194,88 @@ __global__ __launch_bounds__(256) void gru_cluster_fwd(ClusterArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// BPTT: per step (descending)  d = dh (1-z) act'(h~)  (exchange A)  ->  drh = d.U_h^T;  dpre_z, dpre_r  (exchange B)  ->
+//       dh_prev = dh z + drh r + [dpre_z|dpre_r].U_zr^T, carried to step t-1 in a register of thread (row, col).
+// Step 0 has no recurrent product and no exchange (h_prev = 0).
+// ------------------------------------------------------------------------------------------------------------------
+template <int J, int ACT>
+__global__ __launch_bounds__(256) void gru_cluster_bwd(ClusterArgs a) {
+    constexpr int H = 64 * J, GH = 3 * H, CB = H / 16, NB = H / 64;
+    const int L = blockIdx.x, x = L & 7, s = L >> 3, jj = s / CB, c = s - jj * CB;
+    const int gl = x + 8 * jj;
+    const int r0 = 16 * (a.g_base + gl);
+    if (gl >= a.n_groups || r0 >= a.so[1] - a.so[0]) return;
+    __shared__ float red[1024];
+    __shared__ int ok_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int row = tid >> 4, col = 16 * c + (tid & 15);
+    float4 bh[NB], bzr[2 * NB];
+    {
+        const float4* pa = reinterpret_cast<const float4*>(a.pk_a);      // U_h^T, K = H
+        const float4* pb = reinterpret_cast<const float4*>(a.pk_b);      // [U_z U_r]^T, K = 2H
+#pragma unroll
+        for (int i = 0; i < NB; ++i) bh[i] = pa[((size_t)(c * 4 + w) * NB + i) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 2 * NB; ++i) bzr[i] = pb[((size_t)(c * 4 + w) * (2 * NB) + i) * 64 + lane];
+    }
+    unsigned* fl = a.flags + (size_t)gl * 64;
+    unsigned count = a.epoch;                         // this workgroup's published exchanges so far (same sequence in every member)
+    if (tid == 0) st_u32(fl + 32 + c, (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xF) + 1u, true);
+    bool wt = true, first_x = true;
+    int tg = 0;                                       // steps this row block is alive
+    while (tg < a.T && a.so[tg + 1] - a.so[tg] > r0) ++tg;
+    float carry = 0.f;
+    const int koff1 = cl_koff<H>(lane, w), koff2 = cl_koff<2 * H>(lane, w);
+    for (int t = tg - 1; t >= 0; --t) {
+        const int p0 = a.so[t], bt = a.so[t + 1] - p0;
+        const int bnext = t + 1 < a.T ? a.so[t + 2] - a.so[t + 1] : 0;
+        const int nact = min(16, bt - r0);
+        const bool ok = row < nact;
+        const long q = (long)p0 + r0 + (ok ? row : 0);
+        const int arow = min(lane & 15, nact - 1);
+        float dh = a.dHout[q * H + col];
+        if (r0 + row < bnext) dh += carry;
+        const float z = a.gates[q * GH + col], r = a.gates[q * GH + H + col], hh = a.gates[q * GH + 2 * H + col];
+        const float d = dh * (1.f - z) * act_grad<ACT>(hh);
+        if (t == 0) {
+            if (ok) {
+                a.dPre[q * GH + col] = dh * (0.f - hh) * hard_sigmoid_grad(z);
+                a.dPre[q * GH + H + col] = 0.f;
+                a.dPre[q * GH + 2 * H + col] = d;
+            }
+            break;
+        }
+        const float h0 = a.Hout[((long)a.so[t - 1] + r0 + (ok ? row : 0)) * H + col];
+        if (ok) st_f32(a.dPre + q * GH + 2 * H + col, d, wt);
+        cl_publish(fl + c, ++count, wt);
+        if (!cl_wait<CB>(fl, count, &ok_s, a.error)) return;
+        if (first_x) { wt = !cl_same_xcd<CB>(fl); first_x = false; }
+        float acc = 0.f, dummy;
+        {
+            float av[H / 16];
+            ld_vec_dev(av, a.dPre + ((long)p0 + r0 + arow) * GH + 2 * H + koff1);
+            cl_wait_loads();
+            cl_tiles<H, 1>(av, bh, bh, red, tid, acc, dummy);
+        }
+        const float dcar = dh * z + acc * r;
+        if (ok) {
+            st_f32(a.dPre + q * GH + col, dh * (h0 - hh) * hard_sigmoid_grad(z), wt);
+            st_f32(a.dPre + q * GH + H + col, acc * h0 * hard_sigmoid_grad(r), wt);
+        }
+        cl_publish(fl + c, ++count, wt);
+        if (!cl_wait<CB>(fl, count, &ok_s, a.error)) return;
+        float acc2 = 0.f;
+        {
+            float av2[2 * H / 16];
+            ld_vec_dev(av2, a.dPre + ((long)p0 + r0 + arow) * GH + koff2);
+            cl_wait_loads();
+            cl_tiles<2 * H, 1>(av2, bzr, bzr, red, tid, acc2, dummy);
+        }
+        carry = dcar + acc2;
+    }
+}
+
 // per-stream flag buffers + epochs
 struct FlagBuf { unsigned* flags; unsigned* error; unsigned epoch; };
 std::map<hipStream_t, FlagBuf> g_flagbufs;
@@ -276,7 +358,45 @@ bool seqrec_cluster_gru_fwd(int act, int H, int H_real, int T, const int32_t* so
     return true;
 }
 
-bool seqrec_cluster_gru_bwd(int, int, int, int, const int32_t*, const float*, const float*, const float*, const float*, float*,
-                            const float*, hipStream_t, int*) {
-    return false;
+namespace {
+template <int ACT> const void* bwd_kernel(int J) {
+    switch (J) {
+        case 1: return reinterpret_cast<const void*>(gru_cluster_bwd<1, ACT>);
+        case 2: return reinterpret_cast<const void*>(gru_cluster_bwd<2, ACT>);
+        case 4: return reinterpret_cast<const void*>(gru_cluster_bwd<4, ACT>);
+        case 8: return reinterpret_cast<const void*>(gru_cluster_bwd<8, ACT>);
+    }
+    return nullptr;
+}
+}  // namespace
+
+bool seqrec_cluster_gru_bwd(int act, int H, int H_real, int T, const int32_t* soh, const float* dHout, const float* Hout,
+                            const float* gates, const float* aux, float* dPre, const float* upack, hipStream_t st, int* rc) {
+    (void)aux;
+    if (!cluster_enabled() || T > CL_TMAX || T < 1) return false;
+    const int J = H / 64, CB = H / 16;
+    const void* fn = act == 0 ? bwd_kernel<0>(J) : act == 1 ? bwd_kernel<1>(J) : bwd_kernel<2>(J);
+    if (!fn) return false;
+    const int B0 = soh[1] - soh[0];
+    if (B0 <= 0) { *rc = 0; return true; }
+    const int G = (B0 + 15) / 16;
+    int gcap = (512 / CB) & ~7;
+    if (gcap < 8) gcap = 8;
+    if (gcap > CL_MAX_GROUPS) gcap = CL_MAX_GROUPS;
+    ClusterArgs a = {};
+    a.H_real = H_real; a.T = T; a.dHout = dHout; a.Hout = const_cast<float*>(Hout); a.gates = const_cast<float*>(gates); a.dPre = dPre;
+    a.pk_a = upack + 3l * H * H; a.pk_b = upack + 4l * H * H;
+    for (int t = 0; t <= T; ++t) a.so[t] = soh[t];
+    for (int g0 = 0; g0 < G; g0 += gcap) {
+        FlagBuf fb;
+        if ((*rc = get_flagbuf(st, T, fb))) return true;
+        a.flags = fb.flags; a.error = fb.error; a.epoch = fb.epoch;
+        a.g_base = g0; a.n_groups = G - g0 < gcap ? G - g0 : gcap;
+        const unsigned grid = 8u * CB * ((a.n_groups + 7) / 8);
+        void* argv[1] = {&a};
+        const hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(256), argv, 0, st);
+        if (e != hipSuccess) { *rc = (int)e; return true; }
+    }
+    *rc = 0;
+    return true;
 }

@@ -1033,6 +1033,10 @@ extern "C" int seqrec_rnn_bwd_stepwise(int cell, int act, int H, int H_real, int
     const int J = H / 64;
     const long HH = (long)H * H;
     const int32_t* soh = step_off_host;
+    if (cell == SEQREC_CELL_GRU && !rmask) {          // cluster form: one launch, in-kernel exchange (rnn_cluster.hip)
+        int rc = 0;
+        if (seqrec_cluster_gru_bwd(act, H, H_real, T, soh, dHout, Hout, gates, aux, dPre, upack, st, &rc)) return rc;
+    }
     Plan pl;
     pl.reserve(2 * (size_t)T);
     StepArgs a = {};

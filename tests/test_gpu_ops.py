@@ -561,7 +561,8 @@ def test_stepwise_scan_vs_oracle_and_persistent(cell, H, B, maxlen, act, graph):
 def test_cluster_scan_equals_stepwise_scan(H, B, maxlen, act):
     """The one-launch cluster form of the GRU scan (rnn_cluster.hip: in-kernel exchange between the column-slice
     workgroups of a row block) against the launch-per-product form on the same inputs: same arithmetic element for
-    element, so Hout / gates / r*h_prev (and dPre) agree bit for bit; run twice (flag epochs advance between calls)."""
+    element, so Hout / gates / r*h_prev agree bit for bit and dPre to the last bits; run twice (flag epochs advance
+    between calls)."""
     lib = L.load()
     rng = np.random.default_rng(H + B + maxlen)
     rb, XW, U = packed_scan_inputs(rng, "gru", H, B, maxlen)
@@ -591,7 +592,13 @@ def test_cluster_scan_equals_stepwise_scan(H, B, maxlen, act):
             else:
                 for name, x, y in zip(("Hout", "gates", "aux", "dPre"), out, got):
                     assert np.isfinite(y).all(), name
-                    np.testing.assert_array_equal(x, y, err_msg=name)
+                    if name == "dPre":
+                        # same products and sums, but the element-wise epilogues are separate code (FMA contraction may
+                        # differ), and steps with more than 8 row blocks use the wide tile in the step-wise BPTT (one K
+                        # chain per wave instead of four partial chains): last-bit differences
+                        assert np.abs(x - y).max() <= 2e-5 * max(1.0, np.abs(x).max()), name
+                    else:
+                        np.testing.assert_array_equal(x, y, err_msg=name)
     finally:
         lib.seqrec_debug_scan_cluster(-1)
 
