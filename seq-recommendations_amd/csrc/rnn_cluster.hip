@@ -227,6 +227,17 @@ __global__ __launch_bounds__(256) void gru_cluster_bwd(ClusterArgs a) {
     while (tg < a.T && a.so[tg + 1] - a.so[tg] > r0) ++tg;
     float carry = 0.f;
     const int koff1 = cl_koff<H>(lane, w), koff2 = cl_koff<2 * H>(lane, w);
+    // the element-wise operands of a step (dHout, z, r, h~, h_prev) are requested one step ahead: they do not depend on
+    // the exchange, so their latency hides under the previous step's waits
+    float n_dh = 0.f, n_z = 0.f, n_r = 0.f, n_hh = 0.f, n_h0 = 0.f;
+    auto prefetch = [&](int t) {
+        const int p0 = a.so[t], nact = min(16, a.so[t + 1] - p0 - r0);
+        const long q = (long)p0 + r0 + (row < nact ? row : 0);
+        n_dh = a.dHout[q * H + col];
+        n_z = a.gates[q * GH + col]; n_r = a.gates[q * GH + H + col]; n_hh = a.gates[q * GH + 2 * H + col];
+        n_h0 = t > 0 ? a.Hout[((long)a.so[t - 1] + r0 + (row < nact ? row : 0)) * H + col] : 0.f;
+    };
+    if (tg > 0) prefetch(tg - 1);
     for (int t = tg - 1; t >= 0; --t) {
         const int p0 = a.so[t], bt = a.so[t + 1] - p0;
         const int bnext = t + 1 < a.T ? a.so[t + 2] - a.so[t + 1] : 0;
@@ -234,9 +245,9 @@ __global__ __launch_bounds__(256) void gru_cluster_bwd(ClusterArgs a) {
         const bool ok = row < nact;
         const long q = (long)p0 + r0 + (ok ? row : 0);
         const int arow = min(lane & 15, nact - 1);
-        float dh = a.dHout[q * H + col];
+        float dh = n_dh;
         if (r0 + row < bnext) dh += carry;
-        const float z = a.gates[q * GH + col], r = a.gates[q * GH + H + col], hh = a.gates[q * GH + 2 * H + col];
+        const float z = n_z, r = n_r, hh = n_hh, h0 = n_h0;
         const float d = dh * (1.f - z) * act_grad<ACT>(hh);
         if (t == 0) {
             if (ok) {
@@ -246,8 +257,8 @@ __global__ __launch_bounds__(256) void gru_cluster_bwd(ClusterArgs a) {
             }
             break;
         }
-        const float h0 = a.Hout[((long)a.so[t - 1] + r0 + (ok ? row : 0)) * H + col];
         if (ok) st_f32(a.dPre + q * GH + 2 * H + col, d, wt);
+        prefetch(t - 1);
         cl_publish(fl + c, ++count, wt);
         if (!cl_wait<CB>(fl, count, &ok_s, a.error)) return;
         if (first_x) { wt = !cl_same_xcd<CB>(fl); first_x = false; }

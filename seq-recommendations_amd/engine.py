@@ -202,6 +202,8 @@ class Engine:
         self._merge_ws = {}
         self._views = {}
         self._cur_st = None
+        self._side_stream = None
+        self._overlap = _os.environ.get("SEQREC_OVERLAP", "1") != "0"      # A/B switch: dEneg GEMM under the BPTT
         self.sq1 = z(1)                 # squared gradient norm (multi-launch path)
         self.sq2 = z(2)                 # two alternating slots of the fused optimizer launches
         self._sq_slots = (self.sq2[0:1], self.sq2[1:2])
@@ -223,6 +225,14 @@ class Engine:
         self.step_count = 0
 
     # ------------------------------------------------------------------ utilities
+    def _side(self):
+        """Side stream (+ fork / join events) for work that is independent of the scan it runs under."""
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.dev)
+            self._ev_fork = torch.cuda.Event()
+            self._ev_join = torch.cuda.Event()
+        return self._side_stream
+
     def _stream(self):
         """HIP stream handle of torch's current stream; remembered so that the helpers called later in
         the same operation (gemm) need not ask torch again."""
@@ -744,6 +754,7 @@ class Engine:
         Gd, Gt = self.Gd, self.Gt
         tr = self.trainable
         sparse_jobs = []     # scatter lists of this step (see _job)
+        join_side = False    # a side-stream GEMM has to be joined before its consumer
         wgrad = []           # deferred weight-gradient GEMMs (M, N, K, A, lda, B, ldb, C, ldc), launched grouped
         dHd = self.buf("dHd", n, Hp)
         cs_ws = self.buf("colsum_ws", 64 * max(GHp, self.Vp, c.K if c.output == "sampled" else 1))
@@ -777,7 +788,20 @@ class Engine:
                       fuse=_lib.gemm_fuse(add_table=Et, add_index=d["tgt"], add_scale=dlt, add_ld=Hp))
             if tr[tname]:
                 dEneg = self.buf("dEneg", K, Hp)
-                self.gemm(0, 0, K, Hp, n, dln, K, Hd, Hp, dEneg, Hp, splitk=self._splitk(K, Hp, n), tag="dEneg")
+                if self._overlap and _PROF is None:      # (the per-call profile times calls on the main stream)
+                    # dEneg = dlogits^T . H needs nothing from the BPTT: it runs on a side stream UNDER the (latency-bound,
+                    # one-launch) BPTT and is joined in front of the scatter that consumes it
+                    side = self._side()
+                    self._ev_fork.record(torch.cuda.current_stream(self.dev))
+                    side.wait_event(self._ev_fork)
+                    self._cur_st = side.cuda_stream
+                    self.gemm(0, 0, K, Hp, n, dln, K, Hd, Hp, dEneg, Hp, splitk=self._splitk(K, Hp, n), tag="dEneg",
+                              ws_name="gemm_ws_side")
+                    self._cur_st = st
+                    self._ev_join.record(side)
+                    join_side = True
+                else:
+                    self.gemm(0, 0, K, Hp, n, dln, K, Hd, Hp, dEneg, Hp, splitk=self._splitk(K, Hp, n), tag="dEneg")
                 sparse_jobs.append(self._job(tname, d["tgt"], Hd, Hp, dlt, n, Hp, 0))
                 sparse_jobs.append(self._job(tname, neg, dEneg, Hp, None, K, Hp, n))
             if c.out_bias and tr["bout"]:
@@ -847,6 +871,8 @@ class Engine:
             wsz = sum(sk * w_[0] * w_[1] for w_ in wgrad)
             wsp = self.buf("gemm_ws", wsz) if sk > 1 else None
             call("seqrec_gemm_f32_grouped", len(wgrad), 0, 0, _lib.gemm_descs(wgrad), sk, ptr(wsp), st, tag="dW+dU")
+        if join_side:
+            torch.cuda.current_stream(self.dev).wait_event(self._ev_join)
         # ---- row-sparse contributions: one launch for (up to 4) scatter lists
         groups = [sparse_jobs[i:i + 4] for i in range(0, len(sparse_jobs), 4)]
         packed = [_lib.rows_jobs(g) for g in groups]
