@@ -203,6 +203,12 @@ def pmc_traffic(kernel, t_mean, a):
     if a.config != "c3" or a.saturated or not path:
         return None
     pm = json.load(open(path))
+    src = os.path.relpath(path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+    # cluster form of the scan: the call IS one launch
+    one = {"seqrec_rnn_fwd_stepwise": "gru_cluster_fwd<4, 0>", "seqrec_rnn_bwd_stepwise": "gru_cluster_bwd<4, 0>"}.get(kernel)
+    ent = next((v for k, v in pm.items() if one and one in k), None)
+    if ent is not None and os.environ.get("SEQREC_SCAN_CLUSTER", "1") != "0":
+        return {"bytes_per_call": round((ent["fetch_kib_x2"] + ent["write_kib"]) * 1024.0), "source": src}
     pick = {"seqrec_rnn_fwd_stepwise": ("gru_step_fwd<4, 0, 0>", "gru_step_fwd<4, 0, 1>"),
             "seqrec_rnn_bwd_stepwise": ("gru_step_bwd<4, 0, 0>", "gru_step_bwd<4, 0, 1>")}.get(kernel)
     if not pick:
@@ -214,8 +220,7 @@ def pmc_traffic(kernel, t_mean, a):
             return None
         launches = t_mean - (1 if (i == 1 and "bwd" in kernel) else 0)     # bwd phase 1 is skipped at t = 0
         tot += launches * (ent["fetch_kib_x2"] + ent["write_kib"]) * 1024.0
-    return {"bytes_per_call": round(tot), "source": os.path.relpath(path, ROOT) +
-            " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+    return {"bytes_per_call": round(tot), "source": src}
 
 
 def pmc_mfma_util(kernel, a):
@@ -224,11 +229,13 @@ def pmc_mfma_util(kernel, a):
     path = _latest_profile("r*_c3%s_pmc_mfma.json" % ("_saturated" if a.saturated else ""))
     if a.config != "c3" or not path:
         return None
-    frag = {"seqrec_rnn_fwd_stepwise": "gru_step_fwd<4, 0, ", "seqrec_rnn_bwd_stepwise": "gru_step_bwd<4, 0, "}.get(kernel)
+    cluster = os.environ.get("SEQREC_SCAN_CLUSTER", "1") != "0"
+    frag = ({"seqrec_rnn_fwd_stepwise": "gru_cluster_fwd<4, 0", "seqrec_rnn_bwd_stepwise": "gru_cluster_bwd<4, 0"} if cluster else
+            {"seqrec_rnn_fwd_stepwise": "gru_step_fwd<4, 0, ", "seqrec_rnn_bwd_stepwise": "gru_step_bwd<4, 0, "}).get(kernel)
     if not frag:
         return None
     pm = json.load(open(path))
-    out = {k[k.index("gru_step"):k.index(">") + 1]: v["mfma_util"] for k, v in pm.items() if frag in k}
+    out = {k[k.index("gru_"):k.index(">") + 1]: v["mfma_util"] for k, v in pm.items() if frag in k}
     if not out:
         return None
     out["source"] = os.path.relpath(path, ROOT) + " (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE)"
@@ -568,7 +575,7 @@ def main(argv=None):
                 tr = pmc_traffic(dom, t_prof, a)
                 roof = {"kernel": dom, "bound": e["bound"], "achieved": e["achieved"], "peak": e["peak"], "unit": e["unit"],
                         "frac": e["frac"], "traffic": tr["bytes_per_call"] if tr else None,
-                        "traffic_unit": "HBM-side bytes per call (FETCH_SIZE x2 + WRITE_SIZE, isolated dispatches)" if tr else None,
+                        "traffic_unit": "HBM-side bytes per call (FETCH_SIZE x2 + WRITE_SIZE)" if tr else None,
                         "traffic_source": tr["source"] if tr else None, "pmc_mfma_util": pmc_mfma_util(dom, a),
                         "avg_us": e["avg_us"], "share_of_step": e["share"], "tokens_per_call": round(n_prof, 1)}
         except Exception as e:                                   # noqa: BLE001
