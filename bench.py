@@ -675,6 +675,11 @@ def main(argv=None):
             "recall_after_steps": step if recall is not None else None,
             "roofline": roof, "cpu_baseline": cpu, "parity": parity, "kernels": kern,
         }
+        # the cluster scan kernels wait in bounded spins; a healthy run has none that ran out
+        out["config"]["scan"] = dict(scan_issue or {}, form="cluster (one launch, in-kernel exchange)" if
+                                     os.environ.get("SEQREC_SCAN_CLUSTER", "1") != "0" and cd.get("cell", "gru") == "gru" else "step-wise",
+                                     exchange_timeouts=int(importlib.import_module("seq-recommendations_amd._lib").load().seqrec_cluster_scan_errors(
+                                         torch.cuda.current_stream().cuda_stream)))
         if notes:
             out["notes"] = notes
         sys.stdout.flush()

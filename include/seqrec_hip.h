@@ -103,6 +103,9 @@ void seqrec_debug_gemm_tile(int tile, int grouped_tile);
  *      exchange between the column-slice workgroups of a row block), 0 step-wise (one launch per recurrent product),
  *      -1 the built-in choice (cluster whenever the call qualifies; SEQREC_SCAN_CLUSTER=0 disables it). */
 void seqrec_debug_scan_cluster(int mode);
+/*      every wait inside the cluster kernels is a BOUNDED spin; this returns how many ran out on `stream` since its first
+ *      cluster scan (0 in a healthy run; synchronises the stream; -1 on a HIP error). */
+int seqrec_cluster_scan_errors(void* stream);
 
 /* ---- recurrent scan over the ragged batch (Keras K.rnn under Masking).
  *      H must be 64, 128, 256 or 512 (callers zero-pad); H_real <= H are the live units.

@@ -42,6 +42,7 @@ _SIGS = {
     "seqrec_gemm_f32_grouped": [I, I, I, P, I, P, P],
     "seqrec_debug_gemm_tile": [I, I],
     "seqrec_debug_scan_cluster": [I],
+    "seqrec_cluster_scan_errors": [P],
     "seqrec_rnn_upack_floats": [I, I],
     "seqrec_rnn_pack_u": [I, I, P, P, P],
     "seqrec_rnn_fwd": [I, I, I, I, I, I, P, P, P, P, P, P, P],

@@ -617,7 +617,7 @@ __device__ __forceinline__ void sampled_softmax_ce_reg_row(float* __restrict__ l
     for (int i = 0; i < NC; ++i) {
         const int k0 = 256 * i + 4 * lane;
         float4 q = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-        if (vec && k0 + 3 < K) {
+        if ((vec & 1) && k0 + 3 < K) {
             q = *reinterpret_cast<const float4*>(x + k0);
         } else {
             if (k0 + 0 < K) q.x = x[k0 + 0];
@@ -626,6 +626,29 @@ __device__ __forceinline__ void sampled_softmax_ce_reg_row(float* __restrict__ l
             if (k0 + 3 < K) q.w = x[k0 + 3];
         }
         const float qq[4] = {q.x, q.y, q.z, q.w};
+        if ((vec & 2) && k0 + 3 < K) {
+            // candidate ids (and their log-Q) as ONE 16-byte load each: the element-wise form costs 64 dword loads with a
+            // predicated branch and a wait apiece per row -- the kernel spent its time there, not in the 32 exps
+            const int4 ng = *reinterpret_cast<const int4*>(neg + k0);
+            float4 lq = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lq_n) lq = *reinterpret_cast<const float4*>(lq_n + k0);
+            const int ids[4] = {ng.x, ng.y, ng.z, ng.w};
+            const float lqs[4] = {lq.x, lq.y, lq.z, lq.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float l = qq[e];
+                if (ROWS) {
+                    l -= lqs[e];
+                } else {
+                    if (bout) l += bout[ids[e]];
+                    if (lq_n) l -= lqs[e];
+                    else if (logq) l -= logq[ids[e]];
+                }
+                if (ids[e] == t) l = -INFINITY;
+                v[4 * i + e] = l;
+            }
+            continue;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int k = k0 + e;
@@ -675,7 +698,7 @@ __device__ __forceinline__ void sampled_softmax_ce_reg_row(float* __restrict__ l
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         const int k0 = 256 * i + 4 * lane;
-        if (vec && k0 + 3 < K) {
+        if ((vec & 1) && k0 + 3 < K) {
             *reinterpret_cast<float4*>(x + k0) = make_float4(v[4 * i] * sc, v[4 * i + 1] * sc, v[4 * i + 2] * sc, v[4 * i + 3] * sc);
         } else {
 #pragma unroll
@@ -706,7 +729,9 @@ int launch_sampled(float* ln, long ld, const float* hd, int H, const float* Eout
     static const int ce_block = getenv("SEQREC_CE_BLOCK") ? atoi(getenv("SEQREC_CE_BLOCK")) : 64;
     const int wpb = (ce_block == 256 || n > 16384) ? 4 : 1;
     const dim3 grid((unsigned)((n + wpb - 1) / wpb)), block(64 * wpb);
-    const int vec = ((reinterpret_cast<uintptr_t>(ln) & 15) == 0) && (ld % 4 == 0);
+    // bit 0: 16-byte accesses to the logit rows are legal; bit 1: to the candidate id / log-Q vectors
+    const int vec = ((((reinterpret_cast<uintptr_t>(ln) & 15) == 0) && (ld % 4 == 0)) ? 1 : 0) |
+                    ((((reinterpret_cast<uintptr_t>(neg) & 15) == 0) && (!lq_n || (reinterpret_cast<uintptr_t>(lq_n) & 15) == 0)) ? 2 : 0);
 #define SS_ARGS ln, ld, hd, H, Eout, bout, logq, lq_n, tgt, neg, n, K, inv_denom, loss_rows, dlt
 #define SS_ARGSV SS_ARGS, vec
     if (K <= 64 * 8) hipLaunchKernelGGL((sampled_softmax_ce_reg_kernel<ROWS, 8>), grid, block, 0, st, SS_ARGSV);

@@ -337,6 +337,22 @@ template <int ACT> const void* fwd_kernel(int J) {
 
 extern "C" void seqrec_debug_scan_cluster(int mode) { g_cluster_override = mode; }
 
+// Bounded spins that ran out since the stream's first cluster scan (0 in a healthy run): synchronises the stream.
+extern "C" int seqrec_cluster_scan_errors(void* stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    unsigned* dev = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_flag_mu);
+        auto it = g_flagbufs.find(st);
+        if (it == g_flagbufs.end()) return 0;
+        dev = it->second.error;
+    }
+    unsigned h = 0;
+    if (hipStreamSynchronize(st) != hipSuccess) return -1;
+    if (hipMemcpy(&h, dev, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)(h > 0x7FFFFFFFu ? 0x7FFFFFFFu : h);
+}
+
 bool seqrec_cluster_gru_fwd(int act, int H, int H_real, int T, const int32_t* soh, const float* XW, float* Hout, float* gates,
                             float* aux, const float* upack, hipStream_t st, int* rc) {
     if (!cluster_enabled() || T > CL_TMAX || T < 1) return false;

@@ -599,6 +599,7 @@ def test_cluster_scan_equals_stepwise_scan(H, B, maxlen, act):
                         assert np.abs(x - y).max() <= 2e-5 * max(1.0, np.abs(x).max()), name
                     else:
                         np.testing.assert_array_equal(x, y, err_msg=name)
+        assert lib.seqrec_cluster_scan_errors(st()) == 0          # no bounded spin ran out
     finally:
         lib.seqrec_debug_scan_cluster(-1)
 
