@@ -495,7 +495,10 @@ def main(argv=None):
     # how the scan's launches are issued is decided per box (fast host core: eager; slow one: rewritten hipGraph) on
     # untimed training steps -- Engine.autotune_scan; SEQREC_SCAN_GRAPH=0/1 pins it
     scan_issue = None
-    if not sharded and "SEQREC_SCAN_GRAPH" not in os.environ and a.tune_steps > 0:
+    cluster = cd["cell"] == "gru" and os.environ.get("SEQREC_SCAN_CLUSTER", "1") != "0"      # one launch per scan call: nothing to tune
+    if cluster:
+        scan_issue = {"scan_issue": "one launch per call"}
+    elif not sharded and "SEQREC_SCAN_GRAPH" not in os.environ and a.tune_steps > 0:
         def _one():
             nonlocal step
             train(step)

@@ -31,6 +31,18 @@ struct ClusterArgs {
     int so[CL_TMAX + 1];
 };
 
+// Diagnostic build only (-DSEQREC_CLUSTER_STAMP, tools/cluster_stamps.py): workgroup (group 0, column block 1) sums the
+// s_memrealtime (100 MHz) spent between marked points of a step; no stamp exists in the product build.
+#ifdef SEQREC_CLUSTER_STAMP
+__device__ unsigned long long g_cl_stamp[32];
+#define CS_DECL unsigned long long cs_prev = __builtin_amdgcn_s_memrealtime(); unsigned long long cs_acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; int cs_steps = 0
+#define CS(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); cs_acc[i] += t_ - cs_prev; cs_prev = t_; } while (0)
+#define CS_FLUSH(base_) do { if (gl == 0 && c == 1 && threadIdx.x == 0) { for (int i_ = 0; i_ < 12; ++i_) g_cl_stamp[(base_) + i_] = cs_acc[i_]; g_cl_stamp[(base_) + 12] = cs_steps; } } while (0)
+#else
+#define CS_DECL
+#define CS(i)
+#define CS_FLUSH(base_)
+#endif
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_f32(float* p, float v, bool wt) {          // wt: write-through (device scope)
     if (wt) asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
@@ -54,11 +66,84 @@ template <int N> __device__ __forceinline__ void ld_vec_dev(float (&a)[N], const
         a[4 * i + 0] = v[0]; a[4 * i + 1] = v[1]; a[4 * i + 2] = v[2]; a[4 * i + 3] = v[3];
     }
 }
+// The A rows of a product, coalesced: a wave needs rows 0..15 x its K slice [w*K/4, +K/4) -- 16 pieces of K bytes.  In MFMA
+// operand order lane (row, q) reads K/16 consecutive floats of its row: every dwordx4 instruction then touches 16 rows x 4
+// separate 16-byte pieces (64 requests, 32 half-used lines; the stamped build: 0.55-0.67 us per row load).  Here each row's
+// slice is read by CONSECUTIVE lanes (full lines) straight into LDS by LDS-DMA (device scope), 16-byte chunk c of row m
+// landing at chunk c ^ (m mod chunks) (the swizzle is applied on the source address: an LDS-DMA image is lane-linear), and
+// the wave re-reads its own image in operand order, conflict-free.  Same values in the same registers as the direct form.
+template <int K> __device__ __forceinline__ void ld_rows_dma(float (&a)[K / 16], const float* base, long row_stride, int nact,
+                                                              int kslice0, float* lds_wave, int lane) {
+    constexpr int SL = K / 4;                      // floats of a row's slice (64 at K = 256)
+    constexpr int LPR = SL / 4;                    // 16-byte chunks per row slice = lanes per row: 16 at K = 256
+    constexpr int RPI = 64 / LPR;                  // rows per DMA instruction: 4 at K = 256
+    constexpr int NI = 16 / RPI;                   // DMA instructions: 4 at K = 256
+    static_assert(LPR <= 64 && LPR >= 4, "slice fits a wave instruction");
+    const int wl = __builtin_amdgcn_readfirstlane(0);
+    (void)wl;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int rl = RPI * i + lane / LPR;                       // image row
+        const int ch = (lane % LPR) ^ (rl % LPR);                  // source chunk that lands at position lane % LPR
+        const float* p = base + (long)min(rl, nact - 1) * row_stride + kslice0 + 4 * ch;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                         (__attribute__((address_space(3))) void*)(lds_wave + i * (RPI * SL)), 16, 0, 16 /* sc1 */);
+    }
+    const int m = lane & 15, q = lane >> 4;
+    const float* src = lds_wave + m * SL;
+#pragma unroll
+    for (int j = 0; j < K / 64; ++j) {
+        const int pos = (q * (K / 64) + j) ^ (m % LPR);
+        const float4 t = *reinterpret_cast<const float4*>(src + 4 * pos);
+        a[4 * j] = t.x; a[4 * j + 1] = t.y; a[4 * j + 2] = t.z; a[4 * j + 3] = t.w;
+    }
+}
 __device__ __forceinline__ void cl_wait_loads() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
 template <int K> __device__ __forceinline__ int cl_koff(int lane, int w) { return w * (K / 4) + (lane >> 4) * (K / 16); }
+
+// consumer side, scalar form (NOT used: measured 2.6-3.0 us per wait against 0.4 us for the vector poll -- a glc scalar
+// load does not see a same-XCD store for microseconds; kept for the record, tools/cluster_stamps.py).  The idea: a poll
+// that never touches the vector-memory counter, so stash stores and operand prefetches could stay in flight under it.
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+typedef unsigned u32x8s __attribute__((ext_vector_type(8)));
+typedef unsigned u32x16s __attribute__((ext_vector_type(16)));
+template <int CB> __device__ __forceinline__ bool cl_flags_ready(const unsigned* fl, unsigned target) {
+    bool ok = true;
+    if constexpr (CB == 4) {
+        u32x4s f; asm volatile("s_load_dwordx4 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(f) : "s"(fl) : "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ok = ok && (int)(f[i] - target) >= 0;
+    } else if constexpr (CB == 8) {
+        u32x8s f; asm volatile("s_load_dwordx8 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(f) : "s"(fl) : "memory");
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ok = ok && (int)(f[i] - target) >= 0;
+    } else {
+#pragma unroll
+        for (int h = 0; h < CB / 16; ++h) {
+            u32x16s f; asm volatile("s_load_dwordx16 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(f) : "s"(fl + 16 * h) : "memory");
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ok = ok && (int)(f[i] - target) >= 0;
+        }
+    }
+    return ok;
+}
+template <int CB> __device__ __forceinline__ bool cl_wait_s(const unsigned* fl, unsigned target, unsigned* error) {
+    int spins = 0;
+    while (!cl_flags_ready<CB>(fl, target)) {
+        if (++spins > (1 << 22)) { if ((threadIdx.x & 63) == 0) atomicAdd(error, 1u); return false; }
+    }
+    return true;
+}
+// producer side with NB younger inline-asm stores allowed to stay in flight (they were issued AFTER the exchange stores;
+// the counter is in order, so vmcnt(NB) says the exchange stores -- and everything older -- are done)
+template <int NB> __device__ __forceinline__ void cl_publish_n(unsigned* myflag, unsigned value, bool wt) {
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NB) : "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) st_u32(myflag, value, wt);
+}
 
 // producer side of an exchange: my stores are in L2 / memory, then the flag
 __device__ __forceinline__ void cl_publish(unsigned* myflag, unsigned value, bool wt) {
@@ -129,7 +214,9 @@ __global__ __launch_bounds__(256) void gru_cluster_fwd(ClusterArgs a) {
     const int gl = x + 8 * jj;                       // group index inside this launch
     const int r0 = 16 * (a.g_base + gl);
     if (gl >= a.n_groups || r0 >= a.so[1] - a.so[0]) return;
-    __shared__ float red[2 * 1024];
+    __shared__ float smem[1024 + 4 * 16 * (H / 4)];       // partial tiles of a product + the 4 waves' A-row images
+    float* red = smem;
+    float* stage = smem + 1024;
     __shared__ int ok_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int row = tid >> 4, col = 16 * c + (tid & 15);
@@ -150,6 +237,15 @@ __global__ __launch_bounds__(256) void gru_cluster_fwd(ClusterArgs a) {
     bool wt = true;                                   // write-through exchange stores until the group is known to share an XCD
     float hprev = 0.f;
     const int koff = cl_koff<H>(lane, w);
+    CS_DECL;
+    // input projections of a step are requested one step ahead (after the flag store of the step before: nothing on the
+    // exchange path waits for them)
+    float n_xz = 0.f, n_xr = 0.f, n_xh = 0.f;
+    auto prefetch_xw = [&](int t) {
+        const int p0 = a.so[t], nact = min(16, a.so[t + 1] - p0 - r0);
+        if (row < nact) { const float* xw = a.XW + ((long)p0 + r0 + row) * GH + col; n_xz = xw[0]; n_xr = xw[H]; n_xh = xw[2 * H]; }
+    };
+    prefetch_xw(0);
     for (int t = 0; t < a.T; ++t) {
         const int p0 = a.so[t], bt = a.so[t + 1] - p0;
         if (bt <= r0) break;
@@ -157,41 +253,59 @@ __global__ __launch_bounds__(256) void gru_cluster_fwd(ClusterArgs a) {
         const bool ok = row < nact;
         const long q = (long)p0 + r0 + row;
         const int arow = min(lane & 15, nact - 1);
-        float xz = 0.f, xr = 0.f, xh = 0.f;
-        if (ok) { const float* xw = a.XW + q * GH + col; xz = xw[0]; xr = xw[H]; xh = xw[2 * H]; }
-        float accz = 0.f, accr = 0.f, acch = 0.f;
+        const bool more = t + 1 < a.T && a.so[t + 2] - a.so[t + 1] > r0;
+        const float xz = n_xz, xr = n_xr, xh = n_xh;
+        float accz = 0.f, accr = 0.f, acch = 0.f, dummy;
         float av[H / 16];
+        CS(0);
         if (t > 0) {
             if (!cl_wait<CB>(fl, base + 2u * t, &ok_s, a.error)) return;
+            CS(1);
             if (t == 1) wt = !cl_same_xcd<CB>(fl);
-            ld_vec_dev(av, a.Hout + ((long)a.so[t - 1] + r0 + arow) * H + koff);
-            cl_wait_loads();
-            cl_tiles<H, 2>(av, bz, br, red, tid, accz, accr);
+            ld_rows_dma<H>(av, a.Hout + ((long)a.so[t - 1] + r0) * H, H, nact, w * (H / 4), stage + w * (16 * H / 4), lane);
+            CS(2);
+            cl_tiles<H, 1>(av, br, br, red, tid, accr, dummy);        // r first: r * h_prev is what the others wait for
+            CS(3);
         }
-        const float z = hard_sigmoid(accz + xz), r = hard_sigmoid(accr + xr);
-        if (ok) {
-            a.gates[q * GH + col] = z;
-            a.gates[q * GH + H + col] = r;
-            st_f32(a.aux + q * H + col, r * hprev, wt);
-        }
+        const float r = hard_sigmoid(accr + xr);
+        if (ok) st_f32(a.aux + q * H + col, r * hprev, wt);
         if (t > 0) {
-            cl_publish(fl + c, base + 2u * t + 1u, wt);
+            cl_publish_n<0>(fl + c, base + 2u * t + 1u, wt);
+            CS(4);
+            cl_tiles<H, 1>(av, bz, bz, red, tid, accz, dummy);        // z under the exchange (only the h update needs it)
+            CS(5);
+        }
+        const float z = hard_sigmoid(accz + xz);
+        if (t > 0) {
             if (!cl_wait<CB>(fl, base + 2u * t + 1u, &ok_s, a.error)) return;
-            ld_vec_dev(av, a.aux + ((long)p0 + r0 + arow) * H + koff);
-            cl_wait_loads();
-            float dummy;
+            CS(6);
+            ld_rows_dma<H>(av, a.aux + ((long)p0 + r0) * H, H, nact, w * (H / 4), stage + w * (16 * H / 4), lane);
+            CS(7);
+            __syncthreads();                                          // red: slower waves may still read the z product
             cl_tiles<H, 1>(av, bh, bh, red, tid, acch, dummy);
+            CS(8);
         }
         const float hh = act_fwd<ACT>(acch + xh);
         float hn = z * hprev + (1.f - z) * hh;
         if (col >= a.H_real) hn = 0.f;
         if (ok) {
             st_f32(a.Hout + q * H + col, hn, wt);
-            a.gates[q * GH + 2 * H + col] = hh;
+            // the stash (z, r, h~ for the BPTT) rides behind the exchange store: in flight under the flag and the next poll
+            st_f32(a.gates + q * GH + col, z, false);
+            st_f32(a.gates + q * GH + H + col, r, false);
+            st_f32(a.gates + q * GH + 2 * H + col, hh, false);
         }
         hprev = hn;
-        if (t + 1 < a.T && a.so[t + 2] - a.so[t + 1] > r0) cl_publish(fl + c, base + 2u * t + 2u, wt);
+        if (more) {
+            cl_publish_n<3>(fl + c, base + 2u * t + 2u, wt);
+            prefetch_xw(t + 1);
+        }
+        CS(9);
+#ifdef SEQREC_CLUSTER_STAMP
+        if (t > 0) ++cs_steps;
+#endif
     }
+    CS_FLUSH(0);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -206,7 +320,9 @@ __global__ __launch_bounds__(256) void gru_cluster_bwd(ClusterArgs a) {
     const int gl = x + 8 * jj;
     const int r0 = 16 * (a.g_base + gl);
     if (gl >= a.n_groups || r0 >= a.so[1] - a.so[0]) return;
-    __shared__ float red[1024];
+    __shared__ float smem[1024 + 4 * 16 * (2 * H / 4)];   // partial tiles of a product + the 4 waves' A-row images (K up to 2H)
+    float* red = smem;
+    float* stage = smem + 1024;
     __shared__ int ok_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int row = tid >> 4, col = 16 * c + (tid & 15);
@@ -258,15 +374,14 @@ __global__ __launch_bounds__(256) void gru_cluster_bwd(ClusterArgs a) {
             break;
         }
         if (ok) st_f32(a.dPre + q * GH + 2 * H + col, d, wt);
-        prefetch(t - 1);
-        cl_publish(fl + c, ++count, wt);
+        cl_publish_n<0>(fl + c, ++count, wt);
+        prefetch(t - 1);                              // behind the flag store: nothing on the exchange path is issued after it
         if (!cl_wait<CB>(fl, count, &ok_s, a.error)) return;
         if (first_x) { wt = !cl_same_xcd<CB>(fl); first_x = false; }
         float acc = 0.f, dummy;
         {
             float av[H / 16];
-            ld_vec_dev(av, a.dPre + ((long)p0 + r0 + arow) * GH + 2 * H + koff1);
-            cl_wait_loads();
+            ld_rows_dma<H>(av, a.dPre + ((long)p0 + r0) * GH + 2 * H, GH, nact, w * (H / 4), stage + w * (16 * 2 * H / 4), lane);
             cl_tiles<H, 1>(av, bh, bh, red, tid, acc, dummy);
         }
         const float dcar = dh * z + acc * r;
@@ -274,13 +389,12 @@ __global__ __launch_bounds__(256) void gru_cluster_bwd(ClusterArgs a) {
             st_f32(a.dPre + q * GH + col, dh * (h0 - hh) * hard_sigmoid_grad(z), wt);
             st_f32(a.dPre + q * GH + H + col, acc * h0 * hard_sigmoid_grad(r), wt);
         }
-        cl_publish(fl + c, ++count, wt);
+        cl_publish_n<0>(fl + c, ++count, wt);
         if (!cl_wait<CB>(fl, count, &ok_s, a.error)) return;
         float acc2 = 0.f;
         {
             float av2[2 * H / 16];
-            ld_vec_dev(av2, a.dPre + ((long)p0 + r0 + arow) * GH + koff2);
-            cl_wait_loads();
+            ld_rows_dma<2 * H>(av2, a.dPre + ((long)p0 + r0) * GH, GH, nact, w * (2 * H / 4), stage + w * (16 * 2 * H / 4), lane);
             cl_tiles<2 * H, 1>(av2, bzr, bzr, red, tid, acc2, dummy);
         }
         carry = dcar + acc2;
@@ -336,6 +450,11 @@ template <int ACT> const void* fwd_kernel(int J) {
 }  // namespace
 
 extern "C" void seqrec_debug_scan_cluster(int mode) { g_cluster_override = mode; }
+#ifdef SEQREC_CLUSTER_STAMP
+extern "C" void seqrec_debug_cluster_stamps(unsigned long long* out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cl_stamp), sizeof(unsigned long long) * 32);
+}
+#endif
 
 // Bounded spins that ran out since the stream's first cluster scan (0 in a healthy run): synchronises the stream.
 extern "C" int seqrec_cluster_scan_errors(void* stream) {
