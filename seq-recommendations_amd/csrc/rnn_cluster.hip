@@ -57,15 +57,6 @@ __device__ __forceinline__ unsigned ld_u32_dev(const unsigned* p) {            /
     asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
-// N consecutive floats with device-scope loads; the caller waits (cl_wait_loads) before the first use
-template <int N> __device__ __forceinline__ void ld_vec_dev(float (&a)[N], const float* p) {
-#pragma unroll
-    for (int i = 0; i < N / 4; ++i) {
-        f32x4v v;
-        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p + 4 * i) : "memory");
-        a[4 * i + 0] = v[0]; a[4 * i + 1] = v[1]; a[4 * i + 2] = v[2]; a[4 * i + 3] = v[3];
-    }
-}
 // The A rows of a product, coalesced: a wave needs rows 0..15 x its K slice [w*K/4, +K/4) -- 16 pieces of K bytes.  In MFMA
 // operand order lane (row, q) reads K/16 consecutive floats of its row: every dwordx4 instruction then touches 16 rows x 4
 // separate 16-byte pieces (64 requests, 32 half-used lines; the stamped build: 0.55-0.67 us per row load).  Here each row's
@@ -98,45 +89,8 @@ template <int K> __device__ __forceinline__ void ld_rows_dma(float (&a)[K / 16],
         a[4 * j] = t.x; a[4 * j + 1] = t.y; a[4 * j + 2] = t.z; a[4 * j + 3] = t.w;
     }
 }
-__device__ __forceinline__ void cl_wait_loads() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
-template <int K> __device__ __forceinline__ int cl_koff(int lane, int w) { return w * (K / 4) + (lane >> 4) * (K / 16); }
-
-// consumer side, scalar form (NOT used: measured 2.6-3.0 us per wait against 0.4 us for the vector poll -- a glc scalar
-// load does not see a same-XCD store for microseconds; kept for the record, tools/cluster_stamps.py).  The idea: a poll
-// that never touches the vector-memory counter, so stash stores and operand prefetches could stay in flight under it.
-typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
-typedef unsigned u32x8s __attribute__((ext_vector_type(8)));
-typedef unsigned u32x16s __attribute__((ext_vector_type(16)));
-template <int CB> __device__ __forceinline__ bool cl_flags_ready(const unsigned* fl, unsigned target) {
-    bool ok = true;
-    if constexpr (CB == 4) {
-        u32x4s f; asm volatile("s_load_dwordx4 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(f) : "s"(fl) : "memory");
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ok = ok && (int)(f[i] - target) >= 0;
-    } else if constexpr (CB == 8) {
-        u32x8s f; asm volatile("s_load_dwordx8 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(f) : "s"(fl) : "memory");
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ok = ok && (int)(f[i] - target) >= 0;
-    } else {
-#pragma unroll
-        for (int h = 0; h < CB / 16; ++h) {
-            u32x16s f; asm volatile("s_load_dwordx16 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(f) : "s"(fl + 16 * h) : "memory");
-#pragma unroll
-            for (int i = 0; i < 16; ++i) ok = ok && (int)(f[i] - target) >= 0;
-        }
-    }
-    return ok;
-}
-template <int CB> __device__ __forceinline__ bool cl_wait_s(const unsigned* fl, unsigned target, unsigned* error) {
-    int spins = 0;
-    while (!cl_flags_ready<CB>(fl, target)) {
-        if (++spins > (1 << 22)) { if ((threadIdx.x & 63) == 0) atomicAdd(error, 1u); return false; }
-    }
-    return true;
-}
+// (A scalar-load poll -- s_load_dwordx16 glc, so that the poll leaves the vector-memory counter alone -- was measured at
+// 2.6-3.0 us per wait against 0.35 us for the vector poll below: profiles/r02_v3_cluster_step_stamps.txt.)
 // producer side with NB younger inline-asm stores allowed to stay in flight (they were issued AFTER the exchange stores;
 // the counter is in order, so vmcnt(NB) says the exchange stores -- and everything older -- are done)
 template <int NB> __device__ __forceinline__ void cl_publish_n(unsigned* myflag, unsigned value, bool wt) {
@@ -236,7 +190,6 @@ __global__ __launch_bounds__(256) void gru_cluster_fwd(ClusterArgs a) {
     if (tid == 0) st_u32(fl + 32 + c, (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xF) + 1u, true);
     bool wt = true;                                   // write-through exchange stores until the group is known to share an XCD
     float hprev = 0.f;
-    const int koff = cl_koff<H>(lane, w);
     CS_DECL;
     // input projections of a step are requested one step ahead (after the flag store of the step before: nothing on the
     // exchange path waits for them)
@@ -252,7 +205,6 @@ __global__ __launch_bounds__(256) void gru_cluster_fwd(ClusterArgs a) {
         const int nact = min(16, bt - r0);
         const bool ok = row < nact;
         const long q = (long)p0 + r0 + row;
-        const int arow = min(lane & 15, nact - 1);
         const bool more = t + 1 < a.T && a.so[t + 2] - a.so[t + 1] > r0;
         const float xz = n_xz, xr = n_xr, xh = n_xh;
         float accz = 0.f, accr = 0.f, acch = 0.f, dummy;
@@ -342,7 +294,6 @@ __global__ __launch_bounds__(256) void gru_cluster_bwd(ClusterArgs a) {
     int tg = 0;                                       // steps this row block is alive
     while (tg < a.T && a.so[tg + 1] - a.so[tg] > r0) ++tg;
     float carry = 0.f;
-    const int koff1 = cl_koff<H>(lane, w), koff2 = cl_koff<2 * H>(lane, w);
     // the element-wise operands of a step (dHout, z, r, h~, h_prev) are requested one step ahead: they do not depend on
     // the exchange, so their latency hides under the previous step's waits
     float n_dh = 0.f, n_z = 0.f, n_r = 0.f, n_hh = 0.f, n_h0 = 0.f;
@@ -360,7 +311,6 @@ __global__ __launch_bounds__(256) void gru_cluster_bwd(ClusterArgs a) {
         const int nact = min(16, bt - r0);
         const bool ok = row < nact;
         const long q = (long)p0 + r0 + (ok ? row : 0);
-        const int arow = min(lane & 15, nact - 1);
         float dh = n_dh;
         if (r0 + row < bnext) dh += carry;
         const float z = n_z, r = n_r, hh = n_hh, h0 = n_h0;
