@@ -314,17 +314,47 @@ __global__ void adagrad_multi_kernel(DenseMulti m, float lr, float eps, const fl
 
 struct RowsMulti { seqrec_rows_job j[4]; };
 __global__ void rows_scatter_add_multi_kernel(RowsMulti m) {
+    // every wave owns RPW consecutive contributions and issues their loads together (row ids, then all value pieces)
+    // before the first atomic: one contribution per wave was a chain of dependent round trips (id -> 4 x (load -> atomic))
+    // and four times as many workgroups to dispatch
+    constexpr int RPW = 4;
     const seqrec_rows_job& J = m.j[blockIdx.y];
     const int lane = threadIdx.x & 63;
-    const long i = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (i >= J.n) return;
-    const int r = J.rows[i];
-    if (r < 0) return;
-    const float s = J.row_scale ? J.row_scale[i] : 1.f;
-    float* g = J.gtab + (long)r * J.width;
-    const float* v = J.vals + i * J.ldv;
-    for (int c = lane; c < J.width; c += 64) atomicAdd(g + c, v[c] * s);
-    if (lane == 0) atomicMin(J.slot + r, J.base + (int)i);
+    const long i0 = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW;
+    if (i0 >= J.n) return;
+    int r[RPW];
+    float s[RPW];
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) r[k] = (i0 + k < J.n) ? J.rows[i0 + k] : -1;
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) s[k] = (J.row_scale && r[k] >= 0) ? J.row_scale[i0 + k] : 1.f;
+    if (J.width == 256) {
+        float x[RPW][4];
+#pragma unroll
+        for (int k = 0; k < RPW; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[k][j] = r[k] >= 0 ? J.vals[(i0 + k) * J.ldv + lane + 64 * j] : 0.f;
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            if (r[k] < 0) continue;
+            float* g = J.gtab + (long)r[k] * 256;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(g + lane + 64 * j, x[k][j] * s[k]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            if (r[k] < 0) continue;
+            float* g = J.gtab + (long)r[k] * J.width;
+            const float* v = J.vals + (i0 + k) * J.ldv;
+            for (int c = lane; c < J.width; c += 64) atomicAdd(g + c, v[c] * s[k]);
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < RPW; ++k)
+            if (r[k] >= 0) atomicMin(J.slot + r[k], J.base + (int)(i0 + k));
+    }
 }
 __global__ void rows_sqnorm_multi_kernel(RowsMulti m, float* __restrict__ sq) {
     // every wave owns RPW consecutive contributions and issues their (random, HBM-latency-bound)
@@ -1139,7 +1169,7 @@ extern "C" int seqrec_rows_scatter_add_multi(const seqrec_rows_job* jobs, int co
     int rc = fill_rows_multi(jobs, count, m, maxn);
     if (rc || maxn == 0) return rc;
     for (int i = 0; i < count; ++i) if (jobs[i].n > 0 && !jobs[i].vals) return SEQREC_E_ARG;
-    hipLaunchKernelGGL(rows_scatter_add_multi_kernel, dim3((unsigned)((maxn + 3) / 4), count), dim3(256), 0, as_stream(stream), m);
+    hipLaunchKernelGGL(rows_scatter_add_multi_kernel, dim3((unsigned)((maxn + 15) / 16), count), dim3(256), 0, as_stream(stream), m);
     SEQREC_LAUNCH_CHECK();
     return 0;
 }
