@@ -2,7 +2,7 @@
 // H/16 workgroups, one per 16 hidden columns, that stay resident for the whole scan with their slices of the recurrent
 // kernel in registers and exchange h / r*h (forward) and d / [dpre_z|dpre_r] (BPTT) INSIDE the kernel:
 //   producer: stores its 16 x 16 slice, drains the stores (vmcnt 0), workgroup barrier, one flag store;
-//   consumer: wave 0 polls the group's H/16 flags with device-scope loads, workgroup barrier, device-scope loads of the rows.
+//   consumer: every wave polls the group's H/16 flags with device-scope loads, then reads the rows (device scope).
 // tools/xcd_l2_exchange_probe.hip prices one such exchange at ~1.1 us among 16 workgroups of one XCD (plain stores: the
 // XCD's L2 is the meeting point) and ~1.8 us with write-through stores (correct at device scope wherever the workgroups
 // sit), against ~2.9 us per dependent LAUNCH of the step-wise form (rnn_step.hip), which pays one per recurrent product.
@@ -105,19 +105,16 @@ __device__ __forceinline__ void cl_publish(unsigned* myflag, unsigned value, boo
     __syncthreads();
     if (threadIdx.x == 0) st_u32(myflag, value, wt);
 }
-// consumer side: every member's counter has reached `target` (wrap-safe); false = the bounded spin ran out
-template <int CB> __device__ __forceinline__ bool cl_wait(const unsigned* fl, unsigned target, int* ok_s, unsigned* error) {
-    if (threadIdx.x < 64) {
-        int good = 1, spins = 0;
-        while (true) {
-            const unsigned f = (int)threadIdx.x < CB ? ld_u32_dev(fl + threadIdx.x) : target;
-            if (__all((int)(f - target) >= 0)) break;
-            if (++spins > (1 << 22)) { good = 0; break; }
-        }
-        if (threadIdx.x == 0) { *ok_s = good; if (!good) atomicAdd(error, 1u); }
+// consumer side: every member's counter has reached `target` (wrap-safe); false = the bounded spin ran out.  Every wave
+// polls for itself: no workgroup barrier between the flags and the wave's own row loads
+template <int CB> __device__ __forceinline__ bool cl_wait_w(const unsigned* fl, unsigned target, unsigned* error) {
+    const int lane = threadIdx.x & 63;
+    int spins = 0;
+    while (true) {
+        const unsigned f = lane < CB ? ld_u32_dev(fl + lane) : target;
+        if (__all((int)(f - target) >= 0)) return true;
+        if (++spins > (1 << 22)) { if (lane == 0) atomicAdd(error, 1u); return false; }
     }
-    __syncthreads();
-    return *ok_s != 0;
 }
 template <int CB> __device__ __forceinline__ bool cl_same_xcd(const unsigned* fl) {
     const unsigned mine = ld_u32_dev(fl + 32);
@@ -171,7 +168,6 @@ __global__ __launch_bounds__(256) void gru_cluster_fwd(ClusterArgs a) {
     __shared__ float smem[1024 + 4 * 16 * (H / 4)];       // partial tiles of a product + the 4 waves' A-row images
     float* red = smem;
     float* stage = smem + 1024;
-    __shared__ int ok_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int row = tid >> 4, col = 16 * c + (tid & 15);
     float4 bz[NB], br[NB], bh[NB];
@@ -211,7 +207,7 @@ __global__ __launch_bounds__(256) void gru_cluster_fwd(ClusterArgs a) {
         float av[H / 16];
         CS(0);
         if (t > 0) {
-            if (!cl_wait<CB>(fl, base + 2u * t, &ok_s, a.error)) return;
+            if (!cl_wait_w<CB>(fl, base + 2u * t, a.error)) return;
             CS(1);
             if (t == 1) wt = !cl_same_xcd<CB>(fl);
             ld_rows_dma<H>(av, a.Hout + ((long)a.so[t - 1] + r0) * H, H, nact, w * (H / 4), stage + w * (16 * H / 4), lane);
@@ -229,7 +225,7 @@ __global__ __launch_bounds__(256) void gru_cluster_fwd(ClusterArgs a) {
         }
         const float z = hard_sigmoid(accz + xz);
         if (t > 0) {
-            if (!cl_wait<CB>(fl, base + 2u * t + 1u, &ok_s, a.error)) return;
+            if (!cl_wait_w<CB>(fl, base + 2u * t + 1u, a.error)) return;
             CS(6);
             ld_rows_dma<H>(av, a.aux + ((long)p0 + r0) * H, H, nact, w * (H / 4), stage + w * (16 * H / 4), lane);
             CS(7);
@@ -275,7 +271,6 @@ __global__ __launch_bounds__(256) void gru_cluster_bwd(ClusterArgs a) {
     __shared__ float smem[1024 + 4 * 16 * (2 * H / 4)];   // partial tiles of a product + the 4 waves' A-row images (K up to 2H)
     float* red = smem;
     float* stage = smem + 1024;
-    __shared__ int ok_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int row = tid >> 4, col = 16 * c + (tid & 15);
     float4 bh[NB], bzr[2 * NB];
@@ -326,7 +321,7 @@ __global__ __launch_bounds__(256) void gru_cluster_bwd(ClusterArgs a) {
         if (ok) st_f32(a.dPre + q * GH + 2 * H + col, d, wt);
         cl_publish_n<0>(fl + c, ++count, wt);
         prefetch(t - 1);                              // behind the flag store: nothing on the exchange path is issued after it
-        if (!cl_wait<CB>(fl, count, &ok_s, a.error)) return;
+        if (!cl_wait_w<CB>(fl, count, a.error)) return;
         if (first_x) { wt = !cl_same_xcd<CB>(fl); first_x = false; }
         float acc = 0.f, dummy;
         {
@@ -340,7 +335,7 @@ __global__ __launch_bounds__(256) void gru_cluster_bwd(ClusterArgs a) {
             st_f32(a.dPre + q * GH + H + col, acc * h0 * hard_sigmoid_grad(r), wt);
         }
         cl_publish_n<0>(fl + c, ++count, wt);
-        if (!cl_wait<CB>(fl, count, &ok_s, a.error)) return;
+        if (!cl_wait_w<CB>(fl, count, a.error)) return;
         float acc2 = 0.f;
         {
             float av2[2 * H / 16];
