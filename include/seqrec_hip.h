@@ -315,6 +315,13 @@ int seqrec_prior_grad(const float* w, const float* means, int64_t n, float stren
  *      history_features:  xs[p, v] = [v in s[0..t]]  (freq != 0: number of occurrences), row stride ld >= x_dim */
 int seqrec_pack_batch(const int32_t* flat, const int64_t* starts, const int32_t* sess, const int32_t* step_off,
                       int B, int T, int32_t* ids, int32_t* tgt, int32_t* prev, void* stream);
+/*      pack_batch_host: the same with `sess_host` / `step_off_host` read on the HOST and carried in the launch's
+ *      kernel arguments (B + T + 1 <= SEQREC_PACK_HOST_MAX, else SEQREC_E_SHAPE): no host -> device copy precedes the
+ *      launch.  The launch also writes both arrays to sess_out[B] / step_off_out[T+1] in HBM for later readers. */
+#define SEQREC_PACK_HOST_MAX 960
+int seqrec_pack_batch_host(const int32_t* flat, const int64_t* starts, const int32_t* sess_host,
+                           const int32_t* step_off_host, int B, int T, int32_t* sess_out, int32_t* step_off_out,
+                           int32_t* ids, int32_t* tgt, int32_t* prev, void* stream);
 int seqrec_history_features(const int32_t* flat, const int64_t* starts, const int32_t* sess, const int32_t* step_off,
                             int B, int T, int x_dim, int64_t ld, int freq, float* xs, void* stream);
 

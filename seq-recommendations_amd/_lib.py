@@ -66,6 +66,7 @@ _SIGS = {
     "seqrec_opt_apply": [I, P, P, P, P, P, I, P, F, F, F, P, P, P, P],
     "seqrec_prior_grad": [P, P, L, C.c_float, P, P, P],
     "seqrec_pack_batch": [P, P, P, P, I, I, P, P, P, P],
+    "seqrec_pack_batch_host": [P, P, P, P, I, I, P, P, P, P, P, P],
     "seqrec_history_features": [P, P, P, P, I, I, I, L, I, P, P],
     "seqrec_index_affine_i32": [P, P, P, P, L, I, I, P],
     "seqrec_rows_scatter_add": [P, P, P, P, L, P, L, I, I, P],
@@ -118,6 +119,9 @@ def rows_jobs(jobs):
             setattr(arr[i], k, None if t is None else t.data_ptr())
         arr[i].ldv, arr[i].n, arr[i].width, arr[i].base = int(j["ldv"]), int(j["n"]), int(j["width"]), int(j["base"])
     return arr, len(jobs)
+
+
+PACK_HOST_MAX = 960      # SEQREC_PACK_HOST_MAX (include/seqrec_hip.h)
 
 
 class GemmDesc(C.Structure):

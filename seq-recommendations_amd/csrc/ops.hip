@@ -413,10 +413,12 @@ struct OptPlan { DenseMulti d; RowsMulti r; int nd, nr; const float* loss_rows; 
 // batch loss in the same launch as the gradient norm (one spare workgroup): loss_out[0] = sum of the per-token CE in a
 // fixed order, loss_out[1] = its token mean -- no separate reduction launch, no host-side division
 __device__ __forceinline__ void block_loss_reduce(const float* __restrict__ x, long n, float* __restrict__ out) {
-    __shared__ float red[256];
-    float s = 0.f;
-    for (long i = threadIdx.x; i < n; i += 256) s += x[i];
-    red[threadIdx.x] = s;
+    __shared__ float red[256];             // the first 256 threads of the workgroup add, whatever its size: one summation order
+    if (threadIdx.x < 256) {
+        float s = 0.f;
+        for (long i = threadIdx.x; i < n; i += 256) s += x[i];
+        red[threadIdx.x] = s;
+    }
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
@@ -425,12 +427,14 @@ __device__ __forceinline__ void block_loss_reduce(const float* __restrict__ x, l
     if (threadIdx.x == 0) { out[0] = red[0]; out[1] = red[0] / (float)n; }
 }
 __global__ void loss_reduce_kernel(const float* __restrict__ x, long n, float* __restrict__ out) { block_loss_reduce(x, n, out); }
-__global__ void opt_sqnorm_kernel(OptPlan pl, float* __restrict__ sq) {
+// 1024-thread workgroups: every workgroup ends in ONE atomic on the same address, and those serialise at ~10 ns each
+// (tools/rows_probe.py: the launch took 15 us whatever the rows were, with ~940 workgroups of 256)
+__global__ void __launch_bounds__(1024) opt_sqnorm_kernel(OptPlan pl, float* __restrict__ sq) {
     if ((int)blockIdx.y == pl.nd + pl.nr) {                 // spare row: the batch loss
         if (blockIdx.x == 0) block_loss_reduce(pl.loss_rows, pl.n_loss, pl.loss_out);
         return;
     }
-    __shared__ float part[4];
+    __shared__ float part[16];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float s = 0.f;
     if ((int)blockIdx.y < pl.nd) {
@@ -459,7 +463,8 @@ __global__ void opt_sqnorm_kernel(OptPlan pl, float* __restrict__ sq) {
     if (lane == 0) part[wv] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float t = part[0] + part[1] + part[2] + part[3];
+        float t = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += part[w];
         if (t != 0.f) atomicAdd(sq, t);
     }
 }
@@ -963,6 +968,27 @@ __global__ void pack_batch_kernel(const int* __restrict__ flat, const long* __re
     tgt[p] = flat[base + 1];
     prev[p] = t > 0 ? step_off[t - 1] + r : -1;
 }
+// the same with the batch's step offsets and session indices handed over IN THE KERNEL ARGUMENTS (<= 3840 bytes): no
+// host -> device copy in front of the launch (a ~5 us blit on the stream).  The launch also leaves both arrays in HBM
+// for later readers (history features, evaluation).
+struct PackHost { int v[SEQREC_PACK_HOST_MAX]; };
+__global__ void pack_batch_host_kernel(const int* __restrict__ flat, const long* __restrict__ starts, const PackHost h, int B,
+                                       int T, int* __restrict__ sess_out, int* __restrict__ step_off_out,
+                                       int* __restrict__ ids, int* __restrict__ tgt, int* __restrict__ prev) {
+    const int t = blockIdx.y;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) {
+        if (r < B) sess_out[r] = h.v[T + 1 + r];
+        if (r <= T) step_off_out[r] = h.v[r];
+    }
+    const int p0 = h.v[t];
+    if (r >= h.v[t + 1] - p0) return;
+    const long base = starts[h.v[T + 1 + r]] + t;
+    const int p = p0 + r;
+    ids[p] = flat[base];
+    tgt[p] = flat[base + 1];
+    prev[p] = t > 0 ? h.v[t - 1] + r : -1;
+}
 // xs[p, v] = 1 (or the count, freq != 0) for every item v among the session's items 0..t  (datasets.py:97-113)
 __global__ void history_features_kernel(const int* __restrict__ flat, const long* __restrict__ starts,
                                         const int* __restrict__ sess, const int* __restrict__ step_off, int x_dim, long ld,
@@ -992,6 +1018,24 @@ extern "C" int seqrec_pack_batch(const int32_t* flat, const int64_t* starts, con
     if (!flat || !starts || !sess || !step_off || !ids || !tgt || !prev) return SEQREC_E_ARG;
     hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)((B + 255) / 256), (unsigned)T), dim3(256), 0, as_stream(stream), flat,
                        reinterpret_cast<const long*>(starts), sess, step_off, ids, tgt, prev);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int seqrec_pack_batch_host(const int32_t* flat, const int64_t* starts, const int32_t* sess_host,
+                                      const int32_t* step_off_host, int B, int T, int32_t* sess_out, int32_t* step_off_out,
+                                      int32_t* ids, int32_t* tgt, int32_t* prev, void* stream) {
+    if (B < 0 || T < 0) return SEQREC_E_ARG;
+    if ((long)B + T + 1 > SEQREC_PACK_HOST_MAX) return SEQREC_E_SHAPE;
+    if (!sess_host || !step_off_host || !sess_out || !step_off_out) return SEQREC_E_ARG;
+    if (B == 0 || T == 0) return 0;
+    if (!flat || !starts || !ids || !tgt || !prev) return SEQREC_E_ARG;
+    if (step_off_host[T] < 0 || step_off_host[0] != 0) return SEQREC_E_ARG;
+    PackHost h;
+    for (int i = 0; i <= T; ++i) h.v[i] = step_off_host[i];
+    for (int i = 0; i < B; ++i) h.v[T + 1 + i] = sess_host[i];
+    const unsigned gx = (unsigned)((std::max(B, T + 1) + 255) / 256);
+    hipLaunchKernelGGL(pack_batch_host_kernel, dim3(gx, (unsigned)T), dim3(256), 0, as_stream(stream), flat,
+                       reinterpret_cast<const long*>(starts), h, B, T, sess_out, step_off_out, ids, tgt, prev);
     SEQREC_LAUNCH_CHECK();
     return 0;
 }
@@ -1235,8 +1279,8 @@ extern "C" int seqrec_opt_sqnorm(int n_dense, const float* const* grads, const i
     if (rc) return rc;
     if (!sq_accum || (loss_out && (!loss_rows || n_loss <= 0))) return SEQREC_E_ARG;
     pl.loss_rows = loss_rows; pl.n_loss = (long)n_loss; pl.loss_out = loss_out;
-    const unsigned gx = (unsigned)std::max<long>(32, (maxn + 15) / 16);
-    hipLaunchKernelGGL(opt_sqnorm_kernel, dim3(gx, n_dense + n_jobs + (loss_out ? 1 : 0)), dim3(256), 0, as_stream(stream), pl, sq_accum);
+    const unsigned gx = (unsigned)std::max<long>(8, (maxn + 63) / 64);
+    hipLaunchKernelGGL(opt_sqnorm_kernel, dim3(gx, n_dense + n_jobs + (loss_out ? 1 : 0)), dim3(1024), 0, as_stream(stream), pl, sq_accum);
     SEQREC_LAUNCH_CHECK();
     return 0;
 }

@@ -515,13 +515,22 @@ class Engine:
         rb = index_flat(ds["starts_host"], sel, lean=True)
         n, T, B = rb.n_tok, rb.T, rb.B
         sess = np.asarray(sel, dtype=np.int64)[rb.order].astype(np.int32)
-        blob = torch.from_numpy(np.concatenate([rb.step_off.astype(np.int32), sess])).to(self.dev, non_blocking=True)
         out = torch.empty(3 * max(n, 1), dtype=torch.int32, device=self.dev)
-        d = {"n": n, "T": T, "B": B, "rb": rb, "blob": blob, "step_off": blob[: T + 1], "sess": blob[T + 1:],
-             "ids": out[:n], "tgt": out[n:2 * n], "prev": out[2 * n:3 * n], "_out": out}
         st = self._stream()
-        call("seqrec_pack_batch", ptr(ds["flat"]), ptr(ds["starts"]), ptr(d["sess"]), ptr(d["step_off"]), B, T, ptr(d["ids"]),
-             ptr(d["tgt"]), ptr(d["prev"]), st)
+        so32 = np.ascontiguousarray(rb.step_off, dtype=np.int32)
+        if B + T + 1 <= _lib.PACK_HOST_MAX:
+            # offsets and session indices ride in the launch's kernel arguments: no copy in front of the launch
+            blob = torch.empty(T + 1 + B, dtype=torch.int32, device=self.dev)
+            d = {"n": n, "T": T, "B": B, "rb": rb, "blob": blob, "step_off": blob[: T + 1], "sess": blob[T + 1:],
+                 "ids": out[:n], "tgt": out[n:2 * n], "prev": out[2 * n:3 * n], "_out": out}
+            call("seqrec_pack_batch_host", ptr(ds["flat"]), ptr(ds["starts"]), sess.ctypes.data, so32.ctypes.data, B, T,
+                 ptr(d["sess"]), ptr(d["step_off"]), ptr(d["ids"]), ptr(d["tgt"]), ptr(d["prev"]), st)
+        else:
+            blob = torch.from_numpy(np.concatenate([so32, sess])).to(self.dev, non_blocking=True)
+            d = {"n": n, "T": T, "B": B, "rb": rb, "blob": blob, "step_off": blob[: T + 1], "sess": blob[T + 1:],
+                 "ids": out[:n], "tgt": out[n:2 * n], "prev": out[2 * n:3 * n], "_out": out}
+            call("seqrec_pack_batch", ptr(ds["flat"]), ptr(ds["starts"]), ptr(d["sess"]), ptr(d["step_off"]), B, T, ptr(d["ids"]),
+                 ptr(d["tgt"]), ptr(d["prev"]), st)
         if history:
             if not c.x_to_y:
                 raise ValueError("history features feed the x_to_y branch (NetConfig.x_to_y)")

@@ -202,6 +202,16 @@ def test_device_batcher_equals_host_packing():
             assert (dd["n"], dd["T"], dd["B"]) == (dh["n"], dh["T"], dh["B"])
             for k in ("ids", "tgt", "prev", "step_off"):
                 assert torch.equal(dd[k], dh[k]), k
+            # upload_device took the kernel-argument form (seqrec_pack_batch_host); the form that reads both index
+            # arrays from HBM must give the same three arrays from what that launch left there
+            L = importlib.import_module("seq-recommendations_amd._lib")
+            assert dd["B"] + dd["T"] + 1 <= L.PACK_HOST_MAX
+            assert dd["sess"].cpu().tolist() == [int(sel[i]) for i in rb.order]
+            out = torch.full((3 * max(dd["n"], 1),), -7, dtype=torch.int32, device="cuda")
+            n_ = dd["n"]
+            L.call("seqrec_pack_batch", L.ptr(ds["flat"]), L.ptr(ds["starts"]), L.ptr(dd["sess"]), L.ptr(dd["step_off"]), dd["B"],
+                   dd["T"], L.ptr(out[:n_]), L.ptr(out[n_:2 * n_]), L.ptr(out[2 * n_:]), torch.cuda.current_stream().cuda_stream)
+            assert torch.equal(out[:3 * n_], dd["_out"][:3 * n_])
             ref = np.zeros((rb.n_tok, V), np.float32)
             for p in range(rb.n_tok):
                 ref[p] = xs_all[int(sel[rb.tok_b[p]])][int(rb.tok_s[p])]

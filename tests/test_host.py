@@ -162,6 +162,8 @@ def test_c_abi_rejects_bad_arguments_before_any_launch():
     assert lib.seqrec_dropout_mask(1, 2, one, 4, 8, 4, 0.5, one, None) == E_ARG                                   # ld < width
     assert lib.seqrec_dropout_mask(1, 2, one, 4, 8, 8, 1.0, one, None) == E_ARG                                   # rate == 1
     assert lib.seqrec_pack_batch(None, one, one, one, 4, 3, one, one, one, None) == E_ARG
+    assert lib.seqrec_pack_batch_host(one, one, one, one, 957, 3, one, one, one, one, one, None) == E_SHAPE      # B + T + 1 > 960
+    assert lib.seqrec_pack_batch_host(one, one, None, one, 4, 3, one, one, one, one, one, None) == E_ARG
     assert lib.seqrec_history_features(one, one, one, one, 4, 3, 8, 4, 0, one, None) == E_ARG                     # ld < x_dim
     assert lib.seqrec_topk_finish(one, one, 4, 65, one, one, None) == E_ARG                                       # k > 64
     assert lib.seqrec_topk_merge(one, 4, 4, 8, 0, None, one, one, None) == E_ARG                                  # ld < width
