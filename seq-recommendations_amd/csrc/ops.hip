@@ -356,6 +356,66 @@ __global__ void rows_scatter_add_multi_kernel(RowsMulti m) {
             if (r[k] >= 0) atomicMin(J.slot + r[k], J.base + (int)(i0 + k));
     }
 }
+// The same with the contributions of a workgroup (12 waves x RPW = 48) COMBINED per row before the atomics.  Item ids are
+// Zipf: in a c3 batch ~2 500 input contributions hit ~950 rows and the most popular row takes ~250 of them; float atomics
+// on one address serialise (~20 ns each: tools/rows_probe.py, 18.8 us with the batch's rows against 13.8 us with as many
+// distinct rows).  Every wave parks its scaled rows in LDS; the FIRST contribution of a row inside the workgroup (ballot
+// over the 48 ids) adds the others' rows in index order and issues the only atomics for that row.
+template <int NC>
+__global__ void __launch_bounds__(768) rows_scatter_combine_kernel(RowsMulti m) {
+    constexpr int RPW = 4, NW = 12, CPB = RPW * NW, W = 64 * NC;
+    __shared__ float vals[CPB * W];
+    __shared__ int rid[64];
+    const seqrec_rows_job& J = m.j[blockIdx.y];
+    const long b0 = (long)blockIdx.x * CPB;
+    if (b0 >= J.n) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long i0 = b0 + wv * RPW;
+    int r[RPW];
+    float s[RPW], x[RPW][NC];
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) r[k] = (i0 + k < J.n) ? J.rows[i0 + k] : -1;
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) s[k] = (J.row_scale && r[k] >= 0) ? J.row_scale[i0 + k] : 1.f;
+#pragma unroll
+    for (int k = 0; k < RPW; ++k)
+#pragma unroll
+        for (int j = 0; j < NC; ++j) x[k][j] = r[k] >= 0 ? J.vals[(i0 + k) * J.ldv + lane + 64 * j] * s[k] : 0.f;
+    if (threadIdx.x >= CPB && threadIdx.x < 64) rid[threadIdx.x] = -1;
+    if (lane < RPW) {
+        int mine = r[0];
+#pragma unroll
+        for (int k = 1; k < RPW; ++k) if (lane == k) mine = r[k];
+        rid[wv * RPW + lane] = mine;
+    }
+#pragma unroll
+    for (int k = 0; k < RPW; ++k)
+#pragma unroll
+        for (int j = 0; j < NC; ++j) vals[(wv * RPW + k) * W + lane + 64 * j] = x[k][j];
+    __syncthreads();
+    const int other = rid[lane];
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+        if (r[k] < 0) continue;                                          // wave-uniform
+        const int c = wv * RPW + k;
+        unsigned long long same = __ballot(other == r[k]);
+        if (__ffsll((long long)same) - 1 != c) continue;                 // an earlier contribution of the workgroup leads this row
+        same &= same - 1;                                                // the others, in index order
+        float acc[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) acc[j] = x[k][j];
+        while (same) {
+            const int o = __ffsll((long long)same) - 1;
+            same &= same - 1;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) acc[j] += vals[o * W + lane + 64 * j];
+        }
+        float* g = J.gtab + (long)r[k] * W;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) atomicAdd(g + lane + 64 * j, acc[j]);
+        if (lane == 0) atomicMin(J.slot + r[k], J.base + (int)(i0 + k));   // the leader is the smallest index of its row here
+    }
+}
 __global__ void rows_sqnorm_multi_kernel(RowsMulti m, float* __restrict__ sq) {
     // every wave owns RPW consecutive contributions and issues their (random, HBM-latency-bound)
     // accesses together: RPW slot reads, then RPW predicated row reads -- instead of RPW dependent
@@ -1213,6 +1273,17 @@ extern "C" int seqrec_rows_scatter_add_multi(const seqrec_rows_job* jobs, int co
     int rc = fill_rows_multi(jobs, count, m, maxn);
     if (rc || maxn == 0) return rc;
     for (int i = 0; i < count; ++i) if (jobs[i].n > 0 && !jobs[i].vals) return SEQREC_E_ARG;
+    int w0 = jobs[0].width;
+    for (int i = 0; i < count; ++i) if (jobs[i].n > 0 && (jobs[i].width != w0 || jobs[i].ldv < w0)) w0 = 0;
+    static const bool combine = !(getenv("SEQREC_SCATTER_COMBINE") && atoi(getenv("SEQREC_SCATTER_COMBINE")) == 0);
+    if (combine && (w0 == 64 || w0 == 128 || w0 == 256)) {
+        const dim3 grid((unsigned)((maxn + 47) / 48), count);
+        if (w0 == 64) hipLaunchKernelGGL(rows_scatter_combine_kernel<1>, grid, dim3(768), 0, as_stream(stream), m);
+        else if (w0 == 128) hipLaunchKernelGGL(rows_scatter_combine_kernel<2>, grid, dim3(768), 0, as_stream(stream), m);
+        else hipLaunchKernelGGL(rows_scatter_combine_kernel<4>, grid, dim3(768), 0, as_stream(stream), m);
+        SEQREC_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(rows_scatter_add_multi_kernel, dim3((unsigned)((maxn + 15) / 16), count), dim3(256), 0, as_stream(stream), m);
     SEQREC_LAUNCH_CHECK();
     return 0;

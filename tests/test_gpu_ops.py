@@ -395,6 +395,42 @@ def test_index_affine_and_filler_rows():
         assert torch.all(gt == 0) and torch.all(slot == 2 ** 31 - 1)
 
 
+@pytest.mark.parametrize("W", [64, 128, 256, 192])
+def test_scatter_add_multi_with_hot_rows(W):
+    """seqrec_rows_scatter_add_multi on Zipf-like rows (one row takes a tenth of the contributions, as the most popular
+    item of a c3 batch does): widths 64 / 128 / 256 take the form that combines a workgroup's contributions per row in
+    LDS before the atomics, 192 the plain form; two lists share one table (bases 0 and n1), the first has row scales, a
+    wider value stride and filler rows.  Gradient table against a float64 sum, owner slots exactly."""
+    rng = np.random.default_rng(77 + W)
+    V, n1, n2, ldv = 3000, 2501, 1999, W + 8
+    def zipf(n):
+        r = np.minimum((V * rng.random(n) ** 6).astype(np.int64), V - 1)
+        r[rng.random(n) < 0.1] = 7
+        return r.astype(np.int32)
+    r1, r2 = zipf(n1), zipf(n2)
+    r1[::11] = -1
+    v1 = rng.normal(size=(n1, ldv)).astype(np.float32); v2 = rng.normal(size=(n2, W)).astype(np.float32)
+    s1 = rng.normal(size=n1).astype(np.float32)
+    gref = np.zeros((V, W), np.float64)
+    k1 = r1 >= 0
+    np.add.at(gref, r1[k1], v1[k1, :W].astype(np.float64) * s1[k1, None].astype(np.float64))
+    np.add.at(gref, r2, v2.astype(np.float64))
+    sref = np.full(V, 2 ** 31 - 1, np.int64)
+    np.minimum.at(sref, r1[k1], np.nonzero(k1)[0])
+    np.minimum.at(sref, r2, n1 + np.arange(n2))
+    gt = torch.zeros((V, W), device="cuda")
+    slot = torch.full((V,), 2 ** 31 - 1, dtype=torch.int32, device="cuda")
+    keep = [dev(r1), dev(v1), dev(s1), dev(r2), dev(v2)]
+    arr, cnt = L.rows_jobs([dict(table=gt, accum=gt, gtab=gt, slot=slot, rows=keep[0], vals=keep[1], ldv=ldv, row_scale=keep[2],
+                                 n=n1, width=W, base=0),
+                            dict(table=gt, accum=gt, gtab=gt, slot=slot, rows=keep[3], vals=keep[4], ldv=W, row_scale=None,
+                                 n=n2, width=W, base=n1)])
+    call("seqrec_rows_scatter_add_multi", arr, cnt, st())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(gt.cpu().numpy(), gref, rtol=2e-5, atol=2e-4)
+    np.testing.assert_array_equal(slot.cpu().numpy().astype(np.int64), sref)
+
+
 def test_fused_optimizer_launches_equal_the_separate_kernels():
     """seqrec_opt_sqnorm / seqrec_opt_apply (two launches for the whole clipnorm + Adagrad step) against
     the five separate kernels on the same data: dense tensors of odd sizes + two scatter lists with
