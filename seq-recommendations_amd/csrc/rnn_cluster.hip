@@ -107,11 +107,17 @@ __device__ __forceinline__ void cl_publish(unsigned* myflag, unsigned value, boo
 }
 // consumer side: every member's counter has reached `target` (wrap-safe); false = the bounded spin ran out.  Every wave
 // polls for itself: no workgroup barrier between the flags and the wave's own row loads
+#ifdef SEQREC_CLUSTER_SPINS          // diagnostic build (tools/cluster_spins.py): [0] waits, [1 + min(polls - 1, 6)] histogram of polls per wait
+__device__ unsigned long long g_cl_spins[8];
+#endif
 template <int CB> __device__ __forceinline__ bool cl_wait_w(const unsigned* fl, unsigned target, unsigned* error) {
     const int lane = threadIdx.x & 63;
     int spins = 0;
     while (true) {
         const unsigned f = lane < CB ? ld_u32_dev(fl + lane) : target;
+#ifdef SEQREC_CLUSTER_SPINS
+        if (lane == 0 && __all((int)(f - target) >= 0)) { atomicAdd(&g_cl_spins[0], 1ull); atomicAdd(&g_cl_spins[1 + min(spins, 6)], 1ull); }
+#endif
         if (__all((int)(f - target) >= 0)) return true;
         if (++spins > (1 << 22)) { if (lane == 0) atomicAdd(error, 1u); return false; }
     }
@@ -395,6 +401,12 @@ template <int ACT> const void* fwd_kernel(int J) {
 }  // namespace
 
 extern "C" void seqrec_debug_scan_cluster(int mode) { g_cluster_override = mode; }
+#ifdef SEQREC_CLUSTER_SPINS
+extern "C" void seqrec_debug_cluster_spins(unsigned long long* out, int reset) {
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cl_spins), z, sizeof(z)); return; }
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cl_spins), sizeof(unsigned long long) * 8);
+}
+#endif
 #ifdef SEQREC_CLUSTER_STAMP
 extern "C" void seqrec_debug_cluster_stamps(unsigned long long* out) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cl_stamp), sizeof(unsigned long long) * 32);
