@@ -66,6 +66,12 @@ int seqrec_gemm_f32(int a_kcontig, int b_kcontig, int64_t M, int64_t N, int64_t 
                     float* C, int64_t ldc, const float* bias, int accumulate,
                     int splitk, float* workspace, void* stream);
 int64_t seqrec_gemm_workspace_floats(int64_t M, int64_t N, int splitk);
+/*      the same product with its split-K partial sums LEFT in `workspace` (seqrec_gemm_workspace_floats floats): slab s
+ *      = workspace + s * M * N, row stride N, *n_slabs of them (<= splitk; 1 = the whole product).  No reduce launch and no
+ *      C: for products whose only reader adds the slabs itself -- the row scatter of dX / dEneg (seqrec_rows_job.n_slabs). */
+int seqrec_gemm_f32_slabs(int a_kcontig, int b_kcontig, int64_t M, int64_t N, int64_t K,
+                          const float* A, int64_t lda, const float* B, int64_t ldb,
+                          int splitk, float* workspace, int* n_slabs, void* stream);
 /*      the same GEMM with the gathers of the hot path fused in (no materialised copy, no extra launch):
  *      a_index  : the A operand is read THROUGH an index -- a_kcontig: row m of A is A[a_index[m]*lda + k]
  *                 (x.W with x = E[ids]: the embedding lookup of model.py:248-255 inside the cell GEMM);
@@ -228,6 +234,10 @@ typedef struct seqrec_rows_job {
     float* table; float* accum; float* gtab; int32_t* slot;
     const int32_t* rows; const float* vals; int64_t ldv; const float* row_scale;
     int64_t n; int32_t width; int32_t base;
+    int32_t n_slabs; int32_t reserved_; int64_t slab_stride;   /* n_slabs > 1: the values are the SUM over s < n_slabs of
+                                                                  (vals + s * slab_stride)[i * ldv + :], added in that order
+                                                                  (seqrec_gemm_f32_slabs); 0 or 1: vals alone.  Read by
+                                                                  seqrec_rows_scatter_add_multi only (merge_sorted refuses > 1) */
 } seqrec_rows_job;
 int seqrec_rows_scatter_add_multi(const seqrec_rows_job* jobs_host, int count, void* stream);
 /*      deterministic alternative to seqrec_rows_scatter_add_multi for the lists of ONE table (same gtab, slot

@@ -37,6 +37,7 @@ _SIGS = {
     "seqrec_build_arch": [],
     "seqrec_gather_rows": [P, P, P, L, I, P, P, I, P],
     "seqrec_gemm_f32": [I, I, L, L, L, P, L, P, L, P, L, P, I, I, P, P],
+    "seqrec_gemm_f32_slabs": [I, I, L, L, L, P, L, P, L, I, P, P, P],
     "seqrec_gemm_f32_fused": [I, I, L, L, L, P, L, P, L, P, L, P, I, I, P, P, P],
     "seqrec_gemm_workspace_floats": [L, L, I],
     "seqrec_gemm_f32_grouped": [I, I, I, P, I, P, P],
@@ -106,7 +107,8 @@ EXPORTS = sorted(_SIGS)
 class RowsJob(C.Structure):
     """seqrec_rows_job (include/seqrec_hip.h)."""
     _fields_ = [("table", P), ("accum", P), ("gtab", P), ("slot", P), ("rows", P), ("vals", P), ("ldv", L),
-                ("row_scale", P), ("n", L), ("width", C.c_int32), ("base", C.c_int32)]
+                ("row_scale", P), ("n", L), ("width", C.c_int32), ("base", C.c_int32),
+                ("n_slabs", C.c_int32), ("reserved_", C.c_int32), ("slab_stride", L)]
 
 
 def rows_jobs(jobs):
@@ -118,6 +120,7 @@ def rows_jobs(jobs):
             t = j.get(k)
             setattr(arr[i], k, None if t is None else t.data_ptr())
         arr[i].ldv, arr[i].n, arr[i].width, arr[i].base = int(j["ldv"]), int(j["n"]), int(j["width"]), int(j["base"])
+        arr[i].n_slabs, arr[i].slab_stride = int(j.get("n_slabs", 0)), int(j.get("slab_stride", 0))
     return arr, len(jobs)
 
 

@@ -933,11 +933,36 @@ extern "C" int seqrec_gemm_f32(int a_kcontig, int b_kcontig, int64_t M, int64_t 
                                  nullptr, stream);
 }
 
+static int gemm_f32_impl(int a_kcontig, int b_kcontig, int64_t M, int64_t N, int64_t K,
+                         const float* A, int64_t lda, const float* B, int64_t ldb,
+                         float* C, int64_t ldc, const float* bias, int accumulate,
+                         int splitk, float* workspace, const seqrec_gemm_fuse* fuse, void* stream, int* slabs_out);
+
 extern "C" int seqrec_gemm_f32_fused(int a_kcontig, int b_kcontig, int64_t M, int64_t N, int64_t K,
                                      const float* A, int64_t lda, const float* B, int64_t ldb,
                                      float* C, int64_t ldc, const float* bias, int accumulate,
                                      int splitk, float* workspace, const seqrec_gemm_fuse* fuse, void* stream) {
-    if (M < 0 || N < 0 || K < 0 || !C) return SEQREC_E_ARG;
+    if (!C) return SEQREC_E_ARG;
+    return gemm_f32_impl(a_kcontig, b_kcontig, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, splitk, workspace, fuse, stream,
+                         nullptr);
+}
+
+// split-K partial products LEFT in the workspace (slab s = workspace + s * M * N, row stride N): no reduce launch, the
+// consumer adds the slabs where it reads them (seqrec_rows_job.n_slabs: the row scatter of dX / dEneg)
+extern "C" int seqrec_gemm_f32_slabs(int a_kcontig, int b_kcontig, int64_t M, int64_t N, int64_t K,
+                                     const float* A, int64_t lda, const float* B, int64_t ldb,
+                                     int splitk, float* workspace, int* n_slabs, void* stream) {
+    if (!workspace || !n_slabs) return SEQREC_E_ARG;
+    *n_slabs = 0;
+    return gemm_f32_impl(a_kcontig, b_kcontig, M, N, K, A, lda, B, ldb, nullptr, N, nullptr, 0, splitk, workspace, nullptr, stream,
+                         n_slabs);
+}
+
+static int gemm_f32_impl(int a_kcontig, int b_kcontig, int64_t M, int64_t N, int64_t K,
+                         const float* A, int64_t lda, const float* B, int64_t ldb,
+                         float* C, int64_t ldc, const float* bias, int accumulate,
+                         int splitk, float* workspace, const seqrec_gemm_fuse* fuse, void* stream, int* slabs_out) {
+    if (M < 0 || N < 0 || K < 0 || (!C && !slabs_out)) return SEQREC_E_ARG;
     if (M == 0 || N == 0) return 0;
     if ((K > 0 && (!A || !B)) || splitk < 1) return SEQREC_E_ARG;
     if (splitk > 1 && !workspace) return SEQREC_E_ARG;
@@ -960,7 +985,8 @@ extern "C" int seqrec_gemm_f32_fused(int a_kcontig, int b_kcontig, int64_t M, in
     int splits = (int)((K + kps - 1) / kps);
     if (splits < 1) splits = 1;
     g.k_per_split = kps;
-    if (splits > 1) { g.C = workspace; g.ldc = N; } else { g.C = C; g.ldc = ldc; }
+    if (splits > 1 || slabs_out) { g.C = workspace; g.ldc = N; } else { g.C = C; g.ldc = ldc; }
+    if (slabs_out) *slabs_out = splits;
     // tile choice: the biggest tile that still puts >= 4 workgroups on every CU (256 CUs); measured on
     // the c3 shapes, 64x64 beats 128x64 below that (K is short: prologue/epilogue dominate)
     const long t128 = ((M + 127) / 128) * ((N + 127) / 128) * splits;
@@ -973,7 +999,7 @@ extern "C" int seqrec_gemm_f32_fused(int a_kcontig, int b_kcontig, int64_t M, in
     else if (t12864 >= thr) rc = launch_gemm<128, 64>(a_kcontig, b_kcontig, g, splits, st);
     else rc = launch_gemm<64, 64>(a_kcontig, b_kcontig, g, splits, st);
     if (rc) return rc;
-    if (splits > 1) {
+    if (splits > 1 && !slabs_out) {
         const long total = M * N;
         int blocks = (int)min((long)2048, (total + 255) / 256);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, splits, (long)M, (long)N,

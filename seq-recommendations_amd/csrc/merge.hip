@@ -218,6 +218,7 @@ extern "C" int seqrec_rows_merge_sorted(const seqrec_rows_job* jobs, int count, 
         if (j.n < 0 || j.width <= 0) return SEQREC_E_ARG;
         if (j.n == 0) continue;
         if (!j.gtab || !j.slot || !j.rows || !j.vals) return SEQREC_E_ARG;
+        if (j.n_slabs > 1) return SEQREC_E_UNSUPPORTED;          // slab sums are read by the atomic scatter only
         if (used && (j.gtab != m.j[0].gtab || j.slot != m.j[0].slot || j.width != m.j[0].width)) return SEQREC_E_ARG;
         if (used && (long)j.base < (long)m.j[used - 1].base + m.j[used - 1].n) return SEQREC_E_ARG;     // overlapping index ranges
         if ((long)j.base + j.n > (long)INT_MAX) return SEQREC_E_ARG;

@@ -334,6 +334,13 @@ __global__ void rows_scatter_add_multi_kernel(RowsMulti m) {
         for (int k = 0; k < RPW; ++k)
 #pragma unroll
             for (int j = 0; j < 4; ++j) x[k][j] = r[k] >= 0 ? J.vals[(i0 + k) * J.ldv + lane + 64 * j] : 0.f;
+        for (int sl = 1; sl < J.n_slabs; ++sl) {
+            const float* v = J.vals + (long)sl * J.slab_stride;
+#pragma unroll
+            for (int k = 0; k < RPW; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[k][j] += r[k] >= 0 ? v[(i0 + k) * J.ldv + lane + 64 * j] : 0.f;
+        }
 #pragma unroll
         for (int k = 0; k < RPW; ++k) {
             if (r[k] < 0) continue;
@@ -347,7 +354,11 @@ __global__ void rows_scatter_add_multi_kernel(RowsMulti m) {
             if (r[k] < 0) continue;
             float* g = J.gtab + (long)r[k] * J.width;
             const float* v = J.vals + (i0 + k) * J.ldv;
-            for (int c = lane; c < J.width; c += 64) atomicAdd(g + c, v[c] * s[k]);
+            for (int c = lane; c < J.width; c += 64) {
+                float xv = v[c];
+                for (int sl = 1; sl < J.n_slabs; ++sl) xv += v[(long)sl * J.slab_stride + c];
+                atomicAdd(g + c, xv * s[k]);
+            }
         }
     }
     if (lane == 0) {
@@ -380,7 +391,18 @@ __global__ void __launch_bounds__(768) rows_scatter_combine_kernel(RowsMulti m) 
 #pragma unroll
     for (int k = 0; k < RPW; ++k)
 #pragma unroll
-        for (int j = 0; j < NC; ++j) x[k][j] = r[k] >= 0 ? J.vals[(i0 + k) * J.ldv + lane + 64 * j] * s[k] : 0.f;
+        for (int j = 0; j < NC; ++j) x[k][j] = r[k] >= 0 ? J.vals[(i0 + k) * J.ldv + lane + 64 * j] : 0.f;
+    for (int sl = 1; sl < J.n_slabs; ++sl) {            // split-K slabs of the producing GEMM, added in slab order
+        const float* v = J.vals + (long)sl * J.slab_stride;
+#pragma unroll
+        for (int k = 0; k < RPW; ++k)
+#pragma unroll
+            for (int j = 0; j < NC; ++j) x[k][j] += r[k] >= 0 ? v[(i0 + k) * J.ldv + lane + 64 * j] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < RPW; ++k)
+#pragma unroll
+        for (int j = 0; j < NC; ++j) x[k][j] *= s[k];
     if (threadIdx.x >= CPB && threadIdx.x < 64) rid[threadIdx.x] = -1;
     if (lane < RPW) {
         int mine = r[0];

@@ -203,6 +203,8 @@ class Engine:
         self._views = {}
         self._cur_st = None
         self._side_stream = None
+        self._slab_scatter = _os.environ.get("SEQREC_SLAB_SCATTER", "1") != "0"   # A/B switch: dX / dEneg reach the scatter as split-K slabs
+        self._slab_min_k = int(_os.environ.get("SEQREC_SLAB_MIN_K", "256"))
         self._overlap = _os.environ.get("SEQREC_OVERLAP", "0") != "0"      # A/B switch: dEneg GEMM on a side stream under the BPTT (measured +-0.5 %: off)
         self.sq1 = z(1)                 # squared gradient norm (multi-launch path)
         self.sq2 = z(2)                 # two alternating slots of the fused optimizer launches
@@ -354,6 +356,17 @@ class Engine:
             call("seqrec_gemm_f32_fused", int(a_kc), int(b_kc), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(Cm), ldc, ptr(bias),
                  accumulate, splitk, ptr(wsp), ctypes.addressof(fuse), st, tag=tag)
 
+    def gemm_slabs(self, a_kc, b_kc, M, N, K, A, lda, B, ldb, name, splitk, tag=None):
+        """The product as split-K slabs left in the buffer `name` (seqrec_gemm_f32_slabs): no reduce launch, no C.
+        Returns (buffer, n_slabs, slab_stride); the row scatter adds the slabs (seqrec_rows_job.n_slabs)."""
+        import ctypes
+        ws = self.buf(name, max(splitk, 1) * M * N)
+        ns = ctypes.c_int(0)
+        st = self._cur_st if self._cur_st is not None else self._stream()
+        call("seqrec_gemm_f32_slabs", int(a_kc), int(b_kc), M, N, K, ptr(A), lda, ptr(B), ldb, int(max(splitk, 1)), ptr(ws),
+             ctypes.addressof(ns), st, tag=tag)
+        return ws, int(ns.value), M * N
+
     @staticmethod
     def _splitk(M, N, K):
         """Split K until about SPLITK_TARGET_WGS workgroups are in flight, never below SPLITK_MIN_K per slab: every split
@@ -361,8 +374,8 @@ class Engine:
         return Engine._splitk_tiles(((M + 63) // 64) * ((N + 63) // 64), K)
 
     @staticmethod
-    def _splitk_tiles(tiles, K):
-        return int(max(1, min(32, SPLITK_TARGET_WGS // max(tiles, 1), K // SPLITK_MIN_K)))
+    def _splitk_tiles(tiles, K, min_k=None):
+        return int(max(1, min(32, SPLITK_TARGET_WGS // max(tiles, 1), K // (min_k or SPLITK_MIN_K))))
 
     # ------------------------------------------------------------------ parameters (Keras layouts)
     def _gate_pad(self, w, rows_p):
@@ -591,10 +604,10 @@ class Engine:
             out["_rk_out"] = rk
         return out
 
-    def _job(self, name, rows, vals, ldv, row_scale, n, width, base):
+    def _job(self, name, rows, vals, ldv, row_scale, n, width, base, n_slabs=0, slab_stride=0):
         """One scatter list of this step for table `name` (see seqrec_rows_job)."""
         return dict(table=self.P[name], accum=self.A[name], gtab=self.Gt[name], slot=self.slot[name], rows=rows, vals=vals,
-                    ldv=ldv, row_scale=row_scale, n=n, width=width, base=base, name=name)
+                    ldv=ldv, row_scale=row_scale, n=n, width=width, base=base, name=name, n_slabs=n_slabs, slab_stride=slab_stride)
 
     def _merge_sorted(self, jobs):
         """Deterministic merge (csrc/merge.hip): the scatter lists of each table are sorted by row (stable) and
@@ -797,6 +810,7 @@ class Engine:
                       fuse=_lib.gemm_fuse(add_table=Et, add_index=d["tgt"], add_scale=dlt, add_ld=Hp))
             if tr[tname]:
                 dEneg = self.buf("dEneg", K, Hp)
+                ns_neg = ss_neg = 0
                 if self._overlap and _PROF is None:      # (the per-call profile times calls on the main stream)
                     # dEneg = dlogits^T . H needs nothing from the BPTT: it runs on a side stream UNDER the (latency-bound,
                     # one-launch) BPTT and is joined in front of the scatter that consumes it
@@ -809,10 +823,13 @@ class Engine:
                     self._cur_st = st
                     self._ev_join.record(side)
                     join_side = True
+                elif self._slab_scatter and c.merge != "sorted":
+                    # dEneg's only reader is the row scatter: the split-K slabs go there as they are (no reduce launch)
+                    dEneg, ns_neg, ss_neg = self.gemm_slabs(0, 0, K, Hp, n, dln, K, Hd, Hp, "dEneg_slabs", self._splitk(K, Hp, n), tag="dEneg")
                 else:
                     self.gemm(0, 0, K, Hp, n, dln, K, Hd, Hp, dEneg, Hp, splitk=self._splitk(K, Hp, n), tag="dEneg")
                 sparse_jobs.append(self._job(tname, d["tgt"], Hd, Hp, dlt, n, Hp, 0))
-                sparse_jobs.append(self._job(tname, neg, dEneg, Hp, None, K, Hp, n))
+                sparse_jobs.append(self._job(tname, neg, dEneg, Hp, None, K, Hp, n, ns_neg, ss_neg))
             if c.out_bias and tr["bout"]:
                 dbn = self.buf("dbn", K)
                 call("seqrec_colsum", ptr(dln), n, K, K, ptr(dbn), 0, ptr(cs_ws), st)
@@ -861,12 +878,19 @@ class Engine:
             if tr[wname]:
                 wgrad.append((Kd, GHp, n, X, Kd, dPre, GHp, Gd[wname], GHp, r["X_index"]))
             if c.input == "embed" and tr["E"]:
-                dX = self.buf("dX", n, self.Dp)
-                self.gemm(1, 1, n, self.Dp, GHp, dPre, GHp, P["W"], GHp, dX, self.Dp, splitk=self._splitk(n, self.Dp, GHp), tag="dX")
-                if "in" in drops:
-                    call("seqrec_mul", ptr(dX), ptr(drops["in"]), ptr(dX), n * self.Dp, st)
+                ns_x = ss_x = 0
+                if self._slab_scatter and c.merge != "sorted" and "in" not in drops:
+                    # dX too is read by the scatter alone: split K until the chip is full (160 tiles of 64x64 at c3: 3 slabs of
+                    # K = 256 measured best of 1 / 2 / 3 / 4 / 6), slabs unreduced
+                    sk_x = self._splitk_tiles(((n + 63) // 64) * ((self.Dp + 63) // 64), GHp, min_k=self._slab_min_k)
+                    dX, ns_x, ss_x = self.gemm_slabs(1, 1, n, self.Dp, GHp, dPre, GHp, P["W"], GHp, "dX_slabs", sk_x, tag="dX")
+                else:
+                    dX = self.buf("dX", n, self.Dp)
+                    self.gemm(1, 1, n, self.Dp, GHp, dPre, GHp, P["W"], GHp, dX, self.Dp, splitk=self._splitk(n, self.Dp, GHp), tag="dX")
+                    if "in" in drops:
+                        call("seqrec_mul", ptr(dX), ptr(drops["in"]), ptr(dX), n * self.Dp, st)
                 base_i = (n + c.K) if c.tied else 0
-                sparse_jobs.append(self._job("E", d["ids"], dX, self.Dp, None, n, self.Dp, base_i))
+                sparse_jobs.append(self._job("E", d["ids"], dX, self.Dp, None, n, self.Dp, base_i, ns_x, ss_x))
         if bias_in_group:
             if 0 < len(wgrad) < 4:
                 # db = ones^T . dPre rides in the same launch as the other token reductions (M = 1)

@@ -431,6 +431,52 @@ def test_scatter_add_multi_with_hot_rows(W):
     np.testing.assert_array_equal(slot.cpu().numpy().astype(np.int64), sref)
 
 
+@pytest.mark.parametrize("W", [256, 192])
+def test_gemm_slabs_feed_the_scatter_like_the_reduced_product(W):
+    """seqrec_gemm_f32_slabs leaves the split-K partial products in the workspace; a scatter list with n_slabs / slab_stride
+    adds them per row in slab order.  Slabs summed in that order == the product seqrec_gemm_f32 writes with the same split
+    (its reduce launch adds in the same order), bit for bit; the scatter of the slabs == the scatter of that product to
+    rounding of the atomics' order only (rows distinct here: exactly)."""
+    import ctypes
+    rng = np.random.default_rng(5 + W)
+    n, K, sk, V = 700, 1000, 4, 5000          # dEneg-shaped: C[n, W] = A^T[n, K] . B[K, W], split over K
+    A = dev(rng.normal(size=(K, n)).astype(np.float32)); B = dev(rng.normal(size=(K, W)).astype(np.float32))
+    Cref = torch.zeros((n, W), device="cuda"); ws = torch.zeros(sk * n * W, device="cuda"); ws2 = torch.zeros(sk * n * W, device="cuda")
+    call("seqrec_gemm_f32", 0, 0, n, W, K, ptr(A), n, ptr(B), W, ptr(Cref), W, None, 0, sk, ptr(ws), st())
+    ns = ctypes.c_int(0)
+    call("seqrec_gemm_f32_slabs", 0, 0, n, W, K, ptr(A), n, ptr(B), W, sk, ptr(ws2), ctypes.addressof(ns), st())
+    torch.cuda.synchronize()
+    assert ns.value == sk
+    slabs = ws2.view(sk, n, W)
+    acc = slabs[0].clone()
+    for z in range(1, sk):
+        acc += slabs[z]
+    assert torch.equal(acc, Cref)
+    rows = dev(rng.permutation(V)[:n].astype(np.int32))
+    out = []
+    for vals, nsl, stride in ((Cref, 0, 0), (ws2, sk, n * W)):
+        gt = torch.zeros((V, W), device="cuda")
+        slot = torch.full((V,), 2 ** 31 - 1, dtype=torch.int32, device="cuda")
+        arr, cnt = L.rows_jobs([dict(table=gt, accum=gt, gtab=gt, slot=slot, rows=rows, vals=vals, ldv=W, row_scale=None, n=n,
+                                     width=W, base=0, n_slabs=nsl, slab_stride=stride)])
+        call("seqrec_rows_scatter_add_multi", arr, cnt, st())
+        torch.cuda.synchronize()
+        out.append((gt, slot))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    # one slab (split 1) is the whole product
+    call("seqrec_gemm_f32_slabs", 0, 0, n, W, K, ptr(A), n, ptr(B), W, 1, ptr(ws2), ctypes.addressof(ns), st())
+    call("seqrec_gemm_f32", 0, 0, n, W, K, ptr(A), n, ptr(B), W, ptr(Cref), W, None, 0, 1, None, st())
+    torch.cuda.synchronize()
+    assert ns.value == 1 and torch.equal(ws2[: n * W].view(n, W), Cref)
+    # the deterministic merge does not read slabs
+    arr, cnt = L.rows_jobs([dict(table=gt, accum=gt, gtab=gt, slot=slot, rows=rows, vals=ws2, ldv=W, row_scale=None, n=n,
+                                 width=W, base=0, n_slabs=2, slab_stride=n * W)])
+    lib = L.load()
+    nbytes = int(lib.seqrec_rows_merge_workspace_bytes(n, W))
+    mws = torch.zeros((nbytes + 3) // 4, device="cuda")
+    assert lib.seqrec_rows_merge_sorted(arr, cnt, ptr(mws), nbytes, None) == -3
+
+
 def test_fused_optimizer_launches_equal_the_separate_kernels():
     """seqrec_opt_sqnorm / seqrec_opt_apply (two launches for the whole clipnorm + Adagrad step) against
     the five separate kernels on the same data: dense tensors of odd sizes + two scatter lists with
