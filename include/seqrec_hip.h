@@ -305,6 +305,11 @@ int seqrec_sample_negatives(uint64_t seed, uint64_t step, int K, const uint32_t*
 int seqrec_sample_gather(uint64_t seed, uint64_t step, int K, const uint32_t* thresh, const int32_t* alias,
                          int V, const float* table, int width, const float* logq, int32_t* neg_out,
                          float* rows_out, float* logq_out, void* stream);
+/*      seqrec_rnn_pack_u_stepwise + seqrec_sample_gather in ONE launch (the two independent openers of a sampled-softmax
+ *      training step): same arguments, same outputs as the two calls */
+int seqrec_rnn_pack_u_sample(int cell, int H, const float* U, float* upack, uint64_t seed, uint64_t step, int K,
+                             const uint32_t* thresh, const int32_t* alias, int V, const float* table, int width,
+                             const float* logq, int32_t* neg_out, float* rows_out, float* logq_out, void* stream);
 int seqrec_dropout_mask(uint64_t seed, uint64_t stream_id, const int64_t* rowkey, int64_t n_rows,
                         int width, int64_t ld, double rate, float* out, void* stream);
 

@@ -87,6 +87,7 @@ _SIGS = {
     "seqrec_adagrad_dense": [P, P, P, L, F, F, P, P],
     "seqrec_sample_negatives": [U64, U64, I, P, P, I, P, P],
     "seqrec_sample_gather": [C.c_uint64, C.c_uint64, I, P, P, I, P, I, P, P, P, P, P],
+    "seqrec_rnn_pack_u_sample": [I, I, P, P, C.c_uint64, C.c_uint64, I, P, P, I, P, I, P, P, P, P, P],
     "seqrec_dropout_mask": [U64, U64, P, L, I, L, D, P, P],
     "seqrec_rank_count": [P, I, P, P, P, L, I, P, P, P],
     "seqrec_rank_count_thr": [P, I, P, P, P, P, L, I, P, P],

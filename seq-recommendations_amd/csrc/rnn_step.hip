@@ -19,6 +19,7 @@
 // the launches.
 #include "common.h"
 #include "rnn_cluster.h"
+#include <algorithm>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -120,7 +121,33 @@ __device__ __forceinline__ bool tile_of(const StepArgs& a, int& r0, int& cb) {
 //   m = 4*i + e of the wave that owns column block cb, k = q*(K/4) + m -- lane (row, q) owns K/4 consecutive k of its A row
 struct PackStepJob { int coff, K, N, mode; long off; int wide; };
 struct PackStepArgs { const float* U; float* out; int ldu; PackStepJob job[5]; };
-__global__ void pack_step_kernel(PackStepArgs pa) {
+// the step's shared negatives ride in the same launch (grid row `njobs`): draw k (oracle/rng.py counter RNG, exactly
+// seqrec_sample_gather), copy of its table row, its log-Q -- two ~5 us launches of a training step become one
+struct SampleJob { uint64_t key, step; int K, V, width, njobs; const uint32_t* thresh; const int* alias; const float* table;
+                   const float* logq; int* neg; float* rows; float* lq; };
+__device__ __forceinline__ void sample_rows(const SampleJob& sj) {
+    const int lane = threadIdx.x & 63;
+    for (int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < sj.K; k += gridDim.x * (blockDim.x >> 6)) {
+        const uint64_t r = rand64(sj.key, sj.step * (uint64_t)sj.K + (uint64_t)k);
+        const uint64_t hi = r >> 32;
+        const uint32_t lo = (uint32_t)(r & 0xFFFFFFFFu);
+        const int j = (int)((hi * (uint64_t)sj.V) >> 32);
+        const int id = lo < sj.thresh[j] ? j : sj.alias[j];
+        const float* src = sj.table + (long)id * sj.width;
+        float* dst = sj.rows + (long)k * sj.width;
+        if ((sj.width & 3) == 0) {
+            for (int c = lane; c < sj.width / 4; c += 64) reinterpret_cast<float4*>(dst)[c] = reinterpret_cast<const float4*>(src)[c];
+        } else {
+            for (int c = lane; c < sj.width; c += 64) dst[c] = src[c];
+        }
+        if (lane == 0) {
+            sj.neg[k] = id;
+            if (sj.lq) sj.lq[k] = sj.logq[id];
+        }
+    }
+}
+__global__ void pack_step_kernel(PackStepArgs pa, SampleJob sj) {
+    if ((int)blockIdx.y == sj.njobs) { sample_rows(sj); return; }      // njobs < 0: no sampling row in this launch
     const PackStepJob jb = pa.job[blockIdx.y];
     const float* __restrict__ U = pa.U;
     float* __restrict__ out = pa.out + jb.off;
@@ -859,41 +886,59 @@ int issue_eager(Plan& pl, hipStream_t st) {
 }  // namespace
 
 // layouts, in this order inside upack: fwd [z|r] (H x 2H), fwd h (H x H), bwd U_h^T (H x H), bwd [U_z U_r]^T (2H x H)
-extern "C" int seqrec_rnn_pack_u_stepwise(int cell, int H, const float* U, float* upack, void* stream) {
+static int pack_u_impl(int cell, int H, const float* U, float* upack, const SampleJob* sample, hipStream_t st) {
     if (cell < 0 || cell > 2) return SEQREC_E_UNSUPPORTED;
     if (!(H == 64 || H == 128 || H == 256 || H == 512)) return SEQREC_E_SHAPE;
     if (!U || !upack) return SEQREC_E_ARG;
-    hipStream_t st = as_stream(stream);
     const long HH = (long)H * H;
+    SampleJob sj = {};
+    sj.njobs = -1;
+    if (sample) sj = *sample;
+    const unsigned gx = sample ? (unsigned)std::max(128, std::min(1024, (sample->K + 3) / 4)) : 128u;
+    const unsigned extra = sample ? 1u : 0u;
+    PackStepArgs pa = {};
+    pa.U = U; pa.out = upack;
+    int nj;
     if (cell == SEQREC_CELL_LSTM) {
         // fwd: [cb][gate][K/16 groups][lane] -- wave g streams gate g's 16 columns over the whole K
         hipLaunchKernelGGL(pack_lstm_fwd_kernel, dim3(256), dim3(256), 0, st, U, H, upack);
-        PackStepArgs pl = {};
-        pl.U = U; pl.out = upack; pl.ldu = 4 * H;
-        pl.job[0] = PackStepJob{0, 4 * H, H, 1, 4 * HH};          // bwd: U^T, K = 4H
-        hipLaunchKernelGGL(pack_step_kernel, dim3(128, 1), dim3(256), 0, st, pl);
-        SEQREC_LAUNCH_CHECK();
-        return 0;
+        pa.ldu = 4 * H;
+        pa.job[0] = PackStepJob{0, 4 * H, H, 1, 4 * HH};          // bwd: U^T, K = 4H
+        nj = 1;
+    } else if (cell == SEQREC_CELL_SIMPLERNN) {
+        pa.ldu = H;
+        pa.job[0] = PackStepJob{0, H, H, 0, 0};
+        pa.job[1] = PackStepJob{0, H, H, 1, HH};
+        nj = 2;
+    } else {
+        pa.ldu = 3 * H;
+        pa.job[0] = PackStepJob{0, H, 2 * H, 0, 0};
+        pa.job[1] = PackStepJob{2 * H, H, H, 0, 2 * HH};
+        pa.job[2] = PackStepJob{2 * H, H, H, 1, 3 * HH};
+        pa.job[3] = PackStepJob{0, 2 * H, H, 1, 4 * HH};
+        pa.job[4] = PackStepJob{2 * H, H, H, 1, 6 * HH, 1};        // U_h^T for the wide BPTT tile
+        nj = 5;
     }
-    if (cell == SEQREC_CELL_SIMPLERNN) {
-        PackStepArgs ps = {};
-        ps.U = U; ps.out = upack; ps.ldu = H;
-        ps.job[0] = PackStepJob{0, H, H, 0, 0};
-        ps.job[1] = PackStepJob{0, H, H, 1, HH};
-        hipLaunchKernelGGL(pack_step_kernel, dim3(128, 2), dim3(256), 0, st, ps);
-        SEQREC_LAUNCH_CHECK();
-        return 0;
-    }
-    PackStepArgs pa = {};
-    pa.U = U; pa.out = upack; pa.ldu = 3 * H;
-    pa.job[0] = PackStepJob{0, H, 2 * H, 0, 0};
-    pa.job[1] = PackStepJob{2 * H, H, H, 0, 2 * HH};
-    pa.job[2] = PackStepJob{2 * H, H, H, 1, 3 * HH};
-    pa.job[3] = PackStepJob{0, 2 * H, H, 1, 4 * HH};
-    pa.job[4] = PackStepJob{2 * H, H, H, 1, 6 * HH, 1};        // U_h^T for the wide BPTT tile
-    hipLaunchKernelGGL(pack_step_kernel, dim3(128, 5), dim3(256), 0, st, pa);
+    if (sample) sj.njobs = nj;
+    hipLaunchKernelGGL(pack_step_kernel, dim3(gx, nj + extra), dim3(256), 0, st, pa, sj);
     SEQREC_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int seqrec_rnn_pack_u_stepwise(int cell, int H, const float* U, float* upack, void* stream) {
+    return pack_u_impl(cell, H, U, upack, nullptr, as_stream(stream));
+}
+// seqrec_rnn_pack_u_stepwise + seqrec_sample_gather in ONE launch (both open a sampled-softmax training step and depend
+// only on the weights): same outputs as the two calls
+extern "C" int seqrec_rnn_pack_u_sample(int cell, int H, const float* U, float* upack, uint64_t seed, uint64_t step, int K,
+                                        const uint32_t* thresh, const int32_t* alias, int V, const float* table, int width,
+                                        const float* logq, int32_t* neg_out, float* rows_out, float* logq_out, void* stream) {
+    if (K <= 0 || V <= 0 || width <= 0) return SEQREC_E_ARG;
+    if (!thresh || !alias || !table || !neg_out || !rows_out || (logq_out && !logq)) return SEQREC_E_ARG;
+    if ((width & 3) == 0 && ((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(rows_out)) & 15)) return SEQREC_E_ARG;
+    SampleJob sj = {};
+    sj.key = key64(seed, 1); sj.step = step; sj.K = K; sj.V = V; sj.width = width;
+    sj.thresh = thresh; sj.alias = alias; sj.table = table; sj.logq = logq; sj.neg = neg_out; sj.rows = rows_out; sj.lq = logq_out;
+    return pack_u_impl(cell, H, U, upack, &sj, as_stream(stream));
 }
 
 // ---- launch-graph cache: one instantiated hipGraph per launch SEQUENCE (the ordered kernel functions of a plan:

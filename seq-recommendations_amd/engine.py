@@ -203,6 +203,7 @@ class Engine:
         self._views = {}
         self._cur_st = None
         self._side_stream = None
+        self._fuse_prologue = _os.environ.get("SEQREC_FUSE_PROLOGUE", "1") != "0"   # A/B switch: U re-pack + negatives in one launch
         self._slab_scatter = _os.environ.get("SEQREC_SLAB_SCATTER", "1") != "0"   # A/B switch: dX / dEneg reach the scatter as split-K slabs
         self._slab_min_k = int(_os.environ.get("SEQREC_SLAB_MIN_K", "256"))
         self._overlap = _os.environ.get("SEQREC_OVERLAP", "0") != "0"      # A/B switch: dEneg GEMM on a side stream under the BPTT (measured +-0.5 %: off)
@@ -676,6 +677,17 @@ class Engine:
             return r
         drops = self._drop_masks(d, step) if train else {}
         r["drops"] = drops
+        pre_neg = None
+        if (self.stepwise and self.upack_dirty and c.output != "full" and negatives is None and not stop_at_hidden
+                and self.sampler is not None and self._fuse_prologue):
+            # the re-pack of U and the draw + gather of the step's negatives both depend on the weights alone: one launch
+            K = c.K
+            Et = P["E"] if c.tied else P["Eout"]
+            th, al, lq = self.sampler
+            pre_neg = (self.buf("neg", K, dtype=torch.int32), self.buf("Eneg", K, Hp), self.buf("lq_neg", K) if c.logq else None)
+            call("seqrec_rnn_pack_u_sample", CELL[c.cell], Hp, ptr(P["U"]), ptr(self.upack), int(c.seed), int(step), K, ptr(th),
+                 ptr(al), c.V_out, ptr(Et), Hp, ptr(lq if c.logq else None), ptr(pre_neg[0]), ptr(pre_neg[1]), ptr(pre_neg[2]), st)
+            self.upack_dirty = False
         XW = self.buf("XW", n, GHp)
         bias = P.get("b")
         if c.input == "onehot":
@@ -735,7 +747,9 @@ class Engine:
             th, al, lq = self.sampler
             Eneg = self.buf("Eneg", K, Hp)
             lq_neg = self.buf("lq_neg", K) if c.logq else None      # the candidates' log-Q once per step, not once per row
-            if negatives is None:
+            if pre_neg is not None:
+                neg = pre_neg[0]                                    # drawn and gathered in the step's opening launch
+            elif negatives is None:
                 neg = self.buf("neg", K, dtype=torch.int32)         # draw + row gather + log-Q gather: one launch
                 call("seqrec_sample_gather", int(c.seed), int(step), K, ptr(th), ptr(al), c.V_out, ptr(Et), Hp,
                      ptr(lq if c.logq else None), ptr(neg), ptr(Eneg), ptr(lq_neg), st)

@@ -566,6 +566,19 @@ def test_counter_rng_bit_exact_vs_oracle():
         np.testing.assert_array_equal(neg2.cpu().numpy(), ids)
         np.testing.assert_array_equal(rows.cpu().numpy(), tab[ids])
         np.testing.assert_array_equal(lqo.cpu().numpy(), lq[ids])
+        # the same draw + gathers riding in the launch that re-packs U (seqrec_rnn_pack_u_sample): both outputs as the two calls
+        for cell, H in ((2, 256), (0, 64), (1, 128)):
+            G = {0: 1, 1: 4, 2: 3}[cell]
+            U = dev(rng.normal(size=(H, G * H)).astype(np.float32))
+            nf = int(L.load().seqrec_rnn_upack_floats(cell, H))
+            up_a = torch.zeros(nf, device="cuda"); up_b = torch.full((nf,), 7.0, device="cuda")
+            neg3 = torch.empty(K, dtype=torch.int32, device="cuda"); rows3 = torch.empty((K, W), device="cuda"); lq3 = torch.empty(K, device="cuda")
+            call("seqrec_rnn_pack_u_stepwise", cell, H, ptr(U), ptr(up_a), st())
+            call("seqrec_rnn_pack_u_sample", cell, H, ptr(U), ptr(up_b), 7, 3, K, ptr(thd), ptr(ald), V, ptr(dev(tab)), W, ptr(dev(lq)),
+                 ptr(neg3), ptr(rows3), ptr(lq3), st())
+            torch.cuda.synchronize()
+            assert torch.equal(up_a, up_b)
+            assert torch.equal(neg3, neg2) and torch.equal(rows3, rows) and torch.equal(lq3, lqo)
     rk = np.arange(50, dtype=np.int64) * 977 + 13
     m = torch.zeros((50, 12), device="cuda")
     call("seqrec_dropout_mask", 11, 35, ptr(dev(rk)), 50, 10, 12, 0.3, ptr(m), st())
