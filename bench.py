@@ -179,6 +179,8 @@ def kernel_model(cfgd, n_tok, K, B):
         "seqrec_gemm_f32[logits]": ("mfma", 2.0 * n_tok * K * H),
         "seqrec_gemm_f32[dH]": ("mfma", 2.0 * n_tok * K * H),
         "seqrec_gemm_f32[dEneg]": ("mfma", 2.0 * n_tok * K * H),
+        "seqrec_gemm_f32_slabs[dEneg]": ("mfma", 2.0 * n_tok * K * H),       # split-K slabs left for the row scatter: no reduce launch
+        "seqrec_gemm_f32_slabs[dX]": ("mfma", 2.0 * n_tok * D * G * H),
         "seqrec_gemm_f32[dW]": ("mfma", 2.0 * n_tok * D * G * H),
         "seqrec_gemm_f32[dX]": ("mfma", 2.0 * n_tok * D * G * H),
         "seqrec_gemm_f32[dU]": ("mfma", 2.0 * n_tok * H * G * H / (2 if G == 3 else 1)),   # GRU: two launches

@@ -203,6 +203,7 @@ class Engine:
         self._views = {}
         self._cur_st = None
         self._side_stream = None
+        self.last_slabs = {}
         self._fuse_prologue = _os.environ.get("SEQREC_FUSE_PROLOGUE", "1") != "0"   # A/B switch: U re-pack + negatives in one launch
         self._slab_scatter = _os.environ.get("SEQREC_SLAB_SCATTER", "1") != "0"   # A/B switch: dX / dEneg reach the scatter as split-K slabs
         self._slab_min_k = int(_os.environ.get("SEQREC_SLAB_MIN_K", "256"))
@@ -366,6 +367,7 @@ class Engine:
         st = self._cur_st if self._cur_st is not None else self._stream()
         call("seqrec_gemm_f32_slabs", int(a_kc), int(b_kc), M, N, K, ptr(A), lda, ptr(B), ldb, int(max(splitk, 1)), ptr(ws),
              ctypes.addressof(ns), st, tag=tag)
+        self.last_slabs[name] = (ws, int(ns.value), M, N)       # for inspection (tests rebuild the product from the slabs)
         return ws, int(ns.value), M * N
 
     @staticmethod
@@ -774,6 +776,7 @@ class Engine:
         """One full step on an uploaded batch: forward, masked-mean CE, BPTT, global-norm clip,
         Adagrad.  Returns the batch loss as a 1-element device tensor (no host sync)."""
         c, P = self.cfg, self.P
+        self.last_slabs.clear()
         if step is None:
             step = self.step_count
         self.step_count = step + 1

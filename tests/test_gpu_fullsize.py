@@ -182,7 +182,14 @@ def test_row_gradients_equal_a_torch_index_add_of_the_three_scatter_lists(world)
     neg = _negatives(eng, 33)
     eng.train_step(d, lr=0.01, eps=1e-8, clipnorm=1.0, step=33, negatives=neg, apply_update=False)
     Hd, dlt = eng.buf("Hout", n, eng.Hp), eng.buf("dlt", n)
-    dX, dEneg = eng.buf("dX", n, eng.Dp), eng.buf("dEneg", K, eng.Hp)
+    def product(slab_name, name, M, N):
+        # dX / dEneg reach the scatter as split-K slabs (seqrec_gemm_f32_slabs): the product is their sum
+        if slab_name in eng.last_slabs:
+            ws, ns, m_, n_ = eng.last_slabs[slab_name]
+            assert (m_, n_) == (M, N) and ns >= 1
+            return ws[: ns * M * N].view(ns, M, N).double().sum(0).float()
+        return eng.buf(name, M, N)
+    dX, dEneg = product("dX_slabs", "dX", n, eng.Dp), product("dEneg_slabs", "dEneg", K, eng.Hp)
     ids, tgt, ng = d["ids"].long(), d["tgt"].long(), neg.long()
     lists = {"E": [(ids, dX)], "Eout": [(tgt, dlt[:, None] * Hd), (ng, dEneg)]}
     if c.tied:
