@@ -533,11 +533,21 @@ __global__ void __launch_bounds__(1024) opt_sqnorm_kernel(OptPlan pl, float* __r
         for (int k = 0; k < RPW; ++k) r[k] = (i0 + k < J.n) ? J.rows[i0 + k] : -1;
 #pragma unroll
         for (int k = 0; k < RPW; ++k) own[k] = r[k] >= 0 && J.slot[r[k]] == J.base + (int)(i0 + k);
-        for (int c = lane; c < J.width; c += 64) {
+        if ((J.width & 3) == 0 && ((uintptr_t)J.gtab & 15) == 0) {       // 16 bytes per lane: a 256-wide row is one load
+            for (int c = lane; c < J.width / 4; c += 64) {
 #pragma unroll
-            for (int k = 0; k < RPW; ++k) {
-                const float g = own[k] ? J.gtab[(long)r[k] * J.width + c] : 0.f;
-                s += g * g;
+                for (int k = 0; k < RPW; ++k) {
+                    const float4 g = own[k] ? reinterpret_cast<const float4*>(J.gtab + (long)r[k] * J.width)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    s += (g.x * g.x + g.y * g.y) + (g.z * g.z + g.w * g.w);
+                }
+            }
+        } else {
+            for (int c = lane; c < J.width; c += 64) {
+#pragma unroll
+                for (int k = 0; k < RPW; ++k) {
+                    const float g = own[k] ? J.gtab[(long)r[k] * J.width + c] : 0.f;
+                    s += g * g;
+                }
             }
         }
     }
@@ -618,12 +628,29 @@ __global__ void opt_apply_kernel(OptPlan pl, const float* __restrict__ sq, float
     const int r = J.rows[i];
     if (r < 0 || J.slot[r] != J.base + (int)i) return;
     const long o = (long)r * J.width;
-    for (int c = lane; c < J.width; c += 64) {
-        const float g = J.gtab[o + c] * sc;
-        const float a = J.accum[o + c] + g * g;
-        J.accum[o + c] = a;
-        J.table[o + c] -= lr * g / (sqrtf(a) + eps);
-        J.gtab[o + c] = 0.f;
+    if ((J.width & 3) == 0 && (((uintptr_t)J.gtab | (uintptr_t)J.accum | (uintptr_t)J.table) & 15) == 0) {
+        // 16 bytes per lane: a 256-wide row is ONE load per array and one store per array -- the element-wise loop below is
+        // four dependent rounds of (3 loads -> 3 stores), the stores of a round fencing the loads of the next (may alias)
+        for (int c = lane; c < J.width / 4; c += 64) {
+            float4 g = reinterpret_cast<const float4*>(J.gtab + o)[c];
+            float4 a = reinterpret_cast<const float4*>(J.accum + o)[c];
+            float4 p = reinterpret_cast<const float4*>(J.table + o)[c];
+            g.x *= sc; g.y *= sc; g.z *= sc; g.w *= sc;
+            a.x += g.x * g.x; a.y += g.y * g.y; a.z += g.z * g.z; a.w += g.w * g.w;
+            p.x -= lr * g.x / (sqrtf(a.x) + eps); p.y -= lr * g.y / (sqrtf(a.y) + eps);
+            p.z -= lr * g.z / (sqrtf(a.z) + eps); p.w -= lr * g.w / (sqrtf(a.w) + eps);
+            reinterpret_cast<float4*>(J.accum + o)[c] = a;
+            reinterpret_cast<float4*>(J.table + o)[c] = p;
+            reinterpret_cast<float4*>(J.gtab + o)[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else {
+        for (int c = lane; c < J.width; c += 64) {
+            const float g = J.gtab[o + c] * sc;
+            const float a = J.accum[o + c] + g * g;
+            J.accum[o + c] = a;
+            J.table[o + c] -= lr * g / (sqrtf(a) + eps);
+            J.gtab[o + c] = 0.f;
+        }
     }
     if (lane == 0) J.slot[r] = INT_MAX;
 }
