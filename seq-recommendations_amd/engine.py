@@ -328,6 +328,11 @@ class Engine:
             use.append(sk * sum(a * b for a, b in shapes))
             ws = max(ws, max(use))
         need["gemm_ws"] = ws
+        if self._slab_scatter and c.merge != "sorted":      # the slab forms of dX / dEneg keep their own buffers up to the scatter
+            if c.input == "embed":
+                need["dX_slabs"] = max(1, GHp // self._slab_min_k) * n * self.Dp
+            if c.output == "sampled":
+                need["dEneg_slabs"] = max(self._splitk(c.K, Hp, m) for m in range(64, n + 64, 64)) * c.K * Hp
         for name, sz in need.items():
             self.buf(name, int(max(sz, 1)))
         self.buf("neg", c.K if c.output == "sampled" else 1, dtype=torch.int32)
