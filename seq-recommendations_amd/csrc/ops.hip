@@ -438,15 +438,15 @@ __global__ void __launch_bounds__(768) rows_scatter_combine_kernel(RowsMulti m) 
         if (lane == 0) atomicMin(J.slot + r[k], J.base + (int)(i0 + k));   // the leader is the smallest index of its row here
     }
 }
-__global__ void rows_sqnorm_multi_kernel(RowsMulti m, float* __restrict__ sq) {
+__global__ void __launch_bounds__(1024) rows_sqnorm_multi_kernel(RowsMulti m, float* __restrict__ sq) {
     // every wave owns RPW consecutive contributions and issues their (random, HBM-latency-bound)
     // accesses together: RPW slot reads, then RPW predicated row reads -- instead of RPW dependent
-    // round trips; one same-address atomic per 4*RPW contributions.
+    // round trips; one same-address atomic per 16*RPW contributions (1024-thread workgroups: see opt_sqnorm_kernel).
     constexpr int RPW = 4;
     const seqrec_rows_job& J = m.j[blockIdx.y];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long i0 = ((long)blockIdx.x * (blockDim.x >> 6) + wv) * RPW;
-    __shared__ float part[4];
+    __shared__ float part[16];
     int r[RPW];
     bool own[RPW];
 #pragma unroll
@@ -465,7 +465,8 @@ __global__ void rows_sqnorm_multi_kernel(RowsMulti m, float* __restrict__ sq) {
     if (lane == 0) part[wv] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float t = part[0] + part[1] + part[2] + part[3];
+        float t = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += part[w];
         if (t != 0.f) atomicAdd(sq, t);
     }
 }
@@ -1343,7 +1344,7 @@ extern "C" int seqrec_rows_sqnorm_multi(const seqrec_rows_job* jobs, int count, 
     int rc = fill_rows_multi(jobs, count, m, maxn);
     if (rc || maxn == 0) return rc;
     if (!sq_accum) return SEQREC_E_ARG;
-    hipLaunchKernelGGL(rows_sqnorm_multi_kernel, dim3((unsigned)((maxn + 15) / 16), count), dim3(256), 0, as_stream(stream), m, sq_accum);
+    hipLaunchKernelGGL(rows_sqnorm_multi_kernel, dim3((unsigned)((maxn + 63) / 64), count), dim3(1024), 0, as_stream(stream), m, sq_accum);
     SEQREC_LAUNCH_CHECK();
     return 0;
 }
