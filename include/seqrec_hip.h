@@ -101,6 +101,11 @@ typedef struct seqrec_gemm_desc {
 } seqrec_gemm_desc;
 int seqrec_gemm_f32_grouped(int count, int a_kcontig, int b_kcontig, const seqrec_gemm_desc* descs_host,
                             int splitk, float* workspace, void* stream);
+/*      the grouped products with their split-K partial sums LEFT in `workspace` (problem i at float offset
+ *      sum_{j<i} n_slabs * M_j * N_j, slab s at + s * M_i * N_i, row stride N_i; *n_slabs <= splitk of them): no reduce
+ *      launch; C / ldc / bias / accumulate of the descs are not used here.  seqrec_opt_sqnorm_slabs finishes them. */
+int seqrec_gemm_f32_grouped_slabs(int count, int a_kcontig, int b_kcontig, const seqrec_gemm_desc* descs_host,
+                                  int splitk, float* workspace, int* n_slabs, void* stream);
 /*      diagnostics (tests): force the workgroup tile of the LDS-DMA GEMM kernels -- tile 1 = 64x64, 2 = 128x64,
  *      3 = 128x128 (grouped form: 1 or 2); <= 0 restores the built-in choice.  Results never depend on it beyond
  *      the order of the split-K partial sums. */
@@ -275,6 +280,15 @@ int seqrec_adagrad_dense_multi(int count, float* const* p, float* const* a, cons
 int seqrec_opt_sqnorm(int n_dense, const float* const* grads, const int64_t* numel,
                       const seqrec_rows_job* jobs_host, int n_jobs, float* sq_accum,
                       const float* loss_rows, int64_t n_loss, float* loss_out, void* stream);
+/*      opt_sqnorm_slabs: additionally up to 4 dense gradients that arrive as split-K slabs
+ *      (seqrec_gemm_f32_grouped_slabs with the same descs, n_slabs and workspace; bias NULL, accumulate 0): the launch
+ *      adds the slabs in slab order, WRITES every product to descs[i].C (row stride ldc) for seqrec_opt_apply and adds its
+ *      squares to the norm -- the weight gradients' reduce launch rides in the norm launch.  Those tensors must NOT also be
+ *      listed in `grads`; n_dense + n_products <= 8. */
+int seqrec_opt_sqnorm_slabs(int n_dense, const float* const* grads, const int64_t* numel,
+                            int n_products, const seqrec_gemm_desc* products_host, int n_slabs, const float* workspace,
+                            const seqrec_rows_job* jobs_host, int n_jobs, float* sq_accum,
+                            const float* loss_rows, int64_t n_loss, float* loss_out, void* stream);
 /*      loss_out (nullable, 2 floats): the same launch also reduces the per-token losses of the CE kernels with one
  *      spare workgroup in a fixed order -- loss_out[0] = sum, loss_out[1] = sum / n_loss (the Keras token mean): no
  *      separate reduction launch in a training step.  seqrec_loss_reduce is that reduction on its own (evaluation). */

@@ -41,6 +41,7 @@ _SIGS = {
     "seqrec_gemm_f32_fused": [I, I, L, L, L, P, L, P, L, P, L, P, I, I, P, P, P],
     "seqrec_gemm_workspace_floats": [L, L, I],
     "seqrec_gemm_f32_grouped": [I, I, I, P, I, P, P],
+    "seqrec_gemm_f32_grouped_slabs": [I, I, I, P, I, P, P, P],
     "seqrec_debug_gemm_tile": [I, I],
     "seqrec_debug_scan_cluster": [I],
     "seqrec_cluster_scan_errors": [P],
@@ -63,6 +64,7 @@ _SIGS = {
     "seqrec_topk_merge": [P, L, L, I, I, P, P, P, P],
     "seqrec_topk_finish": [P, P, L, I, P, P, P],
     "seqrec_opt_sqnorm": [I, P, P, P, I, P, P, L, P, P],
+    "seqrec_opt_sqnorm_slabs": [I, P, P, I, P, I, P, P, I, P, P, L, P, P],
     "seqrec_loss_reduce": [P, L, P, P],
     "seqrec_opt_apply": [I, P, P, P, P, P, I, P, F, F, F, P, P, P, P],
     "seqrec_prior_grad": [P, P, L, C.c_float, P, P, P],

@@ -1079,8 +1079,23 @@ extern "C" int seqrec_rank_count_thr(const float* hd, int H, const float* Eout, 
 
 // ---- grouped form: up to 4 problems with the same layout flags and split count in ONE launch
 // (used for the weight gradients dW, dU_zr, dU_h that share K = N_tok)
+static int gemm_grouped_impl(int count, int a_kcontig, int b_kcontig, const seqrec_gemm_desc* d, int splitk, float* workspace,
+                             void* stream, int* slabs_out);
 extern "C" int seqrec_gemm_f32_grouped(int count, int a_kcontig, int b_kcontig, const seqrec_gemm_desc* d,
                                        int splitk, float* workspace, void* stream) {
+    return gemm_grouped_impl(count, a_kcontig, b_kcontig, d, splitk, workspace, stream, nullptr);
+}
+// the grouped products with their split-K partial sums LEFT in the workspace (problem i at the offset the reducing form
+// uses: sum_{j<i} n_slabs M_j N_j; its slab s at + s M_i N_i, row stride N_i): descs' C / ldc / bias / accumulate are not
+// touched here -- seqrec_opt_sqnorm_slabs finishes the products where the gradient norm reads them anyway
+extern "C" int seqrec_gemm_f32_grouped_slabs(int count, int a_kcontig, int b_kcontig, const seqrec_gemm_desc* d,
+                                             int splitk, float* workspace, int* n_slabs, void* stream) {
+    if (!workspace || !n_slabs) return SEQREC_E_ARG;
+    *n_slabs = 0;
+    return gemm_grouped_impl(count, a_kcontig, b_kcontig, d, splitk, workspace, stream, n_slabs);
+}
+static int gemm_grouped_impl(int count, int a_kcontig, int b_kcontig, const seqrec_gemm_desc* d, int splitk, float* workspace,
+                             void* stream, int* slabs_out) {
     if (count < 1 || count > 4 || !d || splitk < 1) return SEQREC_E_ARG;
     hipStream_t st = as_stream(stream);
     GemmGroup gg = {};
@@ -1092,11 +1107,11 @@ extern "C" int seqrec_gemm_f32_grouped(int count, int a_kcontig, int b_kcontig, 
     const int splits = (int)((K + kps - 1) / kps) < 1 ? 1 : (int)((K + kps - 1) / kps);
     if (splits > 1 && !workspace) return SEQREC_E_ARG;
     for (int i = 0; i < count; ++i) {
-        if (d[i].K != K || d[i].M <= 0 || d[i].N <= 0 || !d[i].A || !d[i].B || !d[i].C) return SEQREC_E_ARG;
+        if (d[i].K != K || d[i].M <= 0 || d[i].N <= 0 || !d[i].A || !d[i].B || (!d[i].C && !slabs_out)) return SEQREC_E_ARG;
         GemmArgs& g = gg.g[i];
-        g.A = d[i].A; g.B = d[i].B; g.bias = splits > 1 ? nullptr : d[i].bias;
+        g.A = d[i].A; g.B = d[i].B; g.bias = (splits > 1 || slabs_out) ? nullptr : d[i].bias;
         g.M = d[i].M; g.N = d[i].N; g.K = K; g.lda = d[i].lda; g.ldb = d[i].ldb;
-        g.accumulate = d[i].accumulate;
+        g.accumulate = slabs_out ? 0 : d[i].accumulate;
         g.epi = 0; g.tgt = nullptr; g.thr = nullptr; g.rank = nullptr;
         g.a_idx = d[i].a_index;
         g.add_table = nullptr; g.add_idx = nullptr; g.add_scale = nullptr; g.add_ld = 0;
@@ -1107,7 +1122,7 @@ extern "C" int seqrec_gemm_f32_grouped(int count, int a_kcontig, int b_kcontig, 
         g.tiles_n = (int)tn;
         gg.ntiles[i] = (int)(tm * tn);
         if (tm * tn > maxtiles) maxtiles = tm * tn;
-        if (splits > 1) { g.C = workspace + wsoff; g.ldc = g.N; } else { g.C = d[i].C; g.ldc = d[i].ldc; }
+        if (splits > 1 || slabs_out) { g.C = workspace + wsoff; g.ldc = g.N; } else { g.C = d[i].C; g.ldc = d[i].ldc; }
         rg.ws[i] = workspace + wsoff; rg.C[i] = d[i].C; rg.bias[i] = d[i].bias; rg.M[i] = g.M; rg.N[i] = g.N;
         rg.ldc[i] = d[i].ldc; rg.accumulate[i] = d[i].accumulate;
         wsoff += (long)splits * g.M * g.N;
@@ -1137,6 +1152,7 @@ extern "C" int seqrec_gemm_f32_grouped(int count, int a_kcontig, int b_kcontig, 
     else if (!a_kcontig && b_kcontig) hipLaunchKernelGGL((gemm_f32_grouped_kernel<64, 64, 16, false, true>), grid, block, 0, st, gg);
     else hipLaunchKernelGGL((gemm_f32_grouped_kernel<64, 64, 16, false, false>), grid, block, 0, st, gg);
     SEQREC_LAUNCH_CHECK();
+    if (slabs_out) { *slabs_out = splits; return 0; }
     if (splits > 1) {
         hipLaunchKernelGGL(splitk_reduce_grouped_kernel, dim3(256, count), dim3(256), 0, st, rg, splits);
         SEQREC_LAUNCH_CHECK();

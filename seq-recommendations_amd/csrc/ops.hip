@@ -512,8 +512,12 @@ __device__ __forceinline__ void block_loss_reduce(const float* __restrict__ x, l
 __global__ void loss_reduce_kernel(const float* __restrict__ x, long n, float* __restrict__ out) { block_loss_reduce(x, n, out); }
 // 1024-thread workgroups: every workgroup ends in ONE atomic on the same address, and those serialise at ~10 ns each
 // (tools/rows_probe.py: the launch took 15 us whatever the rows were, with ~940 workgroups of 256)
-__global__ void __launch_bounds__(1024) opt_sqnorm_kernel(OptPlan pl, float* __restrict__ sq) {
-    if ((int)blockIdx.y == pl.nd + pl.nr) {                 // spare row: the batch loss
+// products that arrive as split-K slabs (seqrec_gemm_f32_grouped_slabs): grid rows nd .. nd + np - 1 add the slabs in slab
+// order (== the reduce launch of the reducing form), WRITE the product to its place (C, row stride ldc) for the update
+// launch, and add its squares to the norm -- the reduce launch of the weight gradients rides in the norm launch
+struct SlabPieces { const float* ws[4]; float* C[4]; long M[4], N[4], ldc[4]; int np, n_slabs; };
+__global__ void __launch_bounds__(1024) opt_sqnorm_kernel(OptPlan pl, SlabPieces sp, float* __restrict__ sq) {
+    if ((int)blockIdx.y == pl.nd + sp.np + pl.nr) {         // spare row: the batch loss
         if (blockIdx.x == 0) block_loss_reduce(pl.loss_rows, pl.n_loss, pl.loss_out);
         return;
     }
@@ -524,9 +528,19 @@ __global__ void __launch_bounds__(1024) opt_sqnorm_kernel(OptPlan pl, float* __r
         const float* g = pl.d.g[blockIdx.y];
         const long n = pl.d.n[blockIdx.y];
         for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += g[i] * g[i];
+    } else if ((int)blockIdx.y < pl.nd + sp.np) {
+        const int p = blockIdx.y - pl.nd;
+        const float* __restrict__ ws = sp.ws[p];
+        const long N = sp.N[p], total = sp.M[p] * N, ldc = sp.ldc[p];
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            float v = 0.f;
+            for (int z = 0; z < sp.n_slabs; ++z) v += ws[(long)z * total + i];
+            sp.C[p][ldc == N ? i : (i / N) * ldc + i % N] = v;
+            s += v * v;
+        }
     } else {
         constexpr int RPW = 4;
-        const seqrec_rows_job& J = pl.r.j[blockIdx.y - pl.nd];
+        const seqrec_rows_job& J = pl.r.j[blockIdx.y - pl.nd - sp.np];
         const long i0 = ((long)blockIdx.x * (blockDim.x >> 6) + wv) * RPW;
         int r[RPW];
         bool own[RPW];
@@ -1391,19 +1405,44 @@ extern "C" int seqrec_loss_reduce(const float* loss_rows, int64_t n, float* loss
     SEQREC_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int seqrec_opt_sqnorm_slabs(int n_dense, const float* const* grads, const int64_t* numel,
+                                       int n_products, const seqrec_gemm_desc* products, int n_slabs, const float* workspace,
+                                       const seqrec_rows_job* jobs_host, int n_jobs, float* sq_accum,
+                                       const float* loss_rows, int64_t n_loss, float* loss_out, void* stream) {
+    if (n_products < 0 || n_products > 4 || n_dense < 0 || n_dense + n_products > 8) return SEQREC_E_ARG;
+    if (n_products && (!products || !workspace || n_slabs < 1)) return SEQREC_E_ARG;
+    OptPlan pl;
+    long maxn = 0;
+    if (n_dense + n_jobs > 0) {
+        const int rc = fill_opt_plan(n_dense, nullptr, nullptr, grads, numel, jobs_host, n_jobs, false, pl, maxn);
+        if (rc) return rc;
+    } else {
+        if (!n_products) return SEQREC_E_ARG;
+        pl = OptPlan{};
+    }
+    if (!sq_accum || (loss_out && (!loss_rows || n_loss <= 0))) return SEQREC_E_ARG;
+    SlabPieces sp = {};
+    sp.np = n_products; sp.n_slabs = n_slabs;
+    long off = 0;
+    for (int i = 0; i < n_products; ++i) {
+        const seqrec_gemm_desc& d = products[i];
+        if (d.M <= 0 || d.N <= 0 || !d.C || d.ldc < d.N) return SEQREC_E_ARG;
+        if (d.bias || d.accumulate) return SEQREC_E_UNSUPPORTED;
+        sp.ws[i] = workspace + off; sp.C[i] = d.C; sp.M[i] = d.M; sp.N[i] = d.N; sp.ldc[i] = d.ldc;
+        off += (long)n_slabs * d.M * d.N;
+    }
+    pl.loss_rows = loss_rows; pl.n_loss = (long)n_loss; pl.loss_out = loss_out;
+    const unsigned gx = (unsigned)std::max<long>(8, (maxn + 63) / 64);
+    hipLaunchKernelGGL(opt_sqnorm_kernel, dim3(gx, n_dense + n_products + n_jobs + (loss_out ? 1 : 0)), dim3(1024), 0,
+                       as_stream(stream), pl, sp, sq_accum);
+    SEQREC_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int seqrec_opt_sqnorm(int n_dense, const float* const* grads, const int64_t* numel,
                                  const seqrec_rows_job* jobs_host, int n_jobs, float* sq_accum,
                                  const float* loss_rows, int64_t n_loss, float* loss_out, void* stream) {
-    OptPlan pl;
-    long maxn;
-    const int rc = fill_opt_plan(n_dense, nullptr, nullptr, grads, numel, jobs_host, n_jobs, false, pl, maxn);
-    if (rc) return rc;
-    if (!sq_accum || (loss_out && (!loss_rows || n_loss <= 0))) return SEQREC_E_ARG;
-    pl.loss_rows = loss_rows; pl.n_loss = (long)n_loss; pl.loss_out = loss_out;
-    const unsigned gx = (unsigned)std::max<long>(8, (maxn + 63) / 64);
-    hipLaunchKernelGGL(opt_sqnorm_kernel, dim3(gx, n_dense + n_jobs + (loss_out ? 1 : 0)), dim3(1024), 0, as_stream(stream), pl, sq_accum);
-    SEQREC_LAUNCH_CHECK();
-    return 0;
+    return seqrec_opt_sqnorm_slabs(n_dense, grads, numel, 0, nullptr, 0, nullptr, jobs_host, n_jobs, sq_accum, loss_rows, n_loss,
+                                   loss_out, stream);
 }
 extern "C" int64_t seqrec_opt_sqnorm_ordered_floats(int n_dense, int n_jobs, int64_t max_job_rows) {
     const long gx = std::max<long>(32, (max_job_rows + 15) / 16);

@@ -205,6 +205,7 @@ class Engine:
         self._side_stream = None
         self.last_slabs = {}
         self._fuse_prologue = _os.environ.get("SEQREC_FUSE_PROLOGUE", "1") != "0"   # A/B switch: U re-pack + negatives in one launch
+        self._slab_wgrad = _os.environ.get("SEQREC_SLAB_WGRAD", "1") != "0"        # A/B switch: the weight gradients' split-K reduce rides in the norm launch
         self._slab_scatter = _os.environ.get("SEQREC_SLAB_SCATTER", "1") != "0"   # A/B switch: dX / dEneg reach the scatter as split-K slabs
         self._slab_min_k = int(_os.environ.get("SEQREC_SLAB_MIN_K", "256"))
         self._overlap = _os.environ.get("SEQREC_OVERLAP", "0") != "0"      # A/B switch: dEneg GEMM on a side stream under the BPTT (measured +-0.5 %: off)
@@ -800,6 +801,8 @@ class Engine:
         sparse_jobs = []     # scatter lists of this step (see _job)
         join_side = False    # a side-stream GEMM has to be joined before its consumer
         wgrad = []           # deferred weight-gradient GEMMs (M, N, K, A, lda, B, ldb, C, ldc), launched grouped
+        wcover = set()       # dense tensors whose gradient those products tile completely
+        wg_slabs = None      # (descs, count, n_slabs, workspace) when the products were left as split-K slabs for the norm launch
         dHd = self.buf("dHd", n, Hp)
         cs_ws = self.buf("colsum_ws", 64 * max(GHp, self.Vp, c.K if c.output == "sampled" else 1))
         if c.output == "full":
@@ -888,8 +891,10 @@ class Engine:
             elif c.cell == "gru":
                 wgrad.append((Hp, 2 * Hp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp, hidx))
                 wgrad.append((Hp, Hp, n, r["aux"], Hp, dPre[:, 2 * Hp:], GHp, Gd["U"][:, 2 * Hp:], GHp))
+                wcover.add("U")
             else:
                 wgrad.append((Hp, GHp, n, Hprev, Hp, dPre, GHp, Gd["U"], GHp, hidx))
+                wcover.add("U")
         if c.input == "onehot":
             if tr["Wk"]:
                 sparse_jobs.append(self._job("Wk", d["ids"], dPre, GHp, drops.get("in"), n, GHp, 0))
@@ -899,6 +904,7 @@ class Engine:
             wname = "W" if c.input == "embed" else "Wk"
             if tr[wname]:
                 wgrad.append((Kd, GHp, n, X, Kd, dPre, GHp, Gd[wname], GHp, r["X_index"]))
+                wcover.add(wname)
             if c.input == "embed" and tr["E"]:
                 ns_x = ss_x = 0
                 if self._slab_scatter and c.merge != "sorted" and "in" not in drops:
@@ -917,6 +923,7 @@ class Engine:
             if 0 < len(wgrad) < 4:
                 # db = ones^T . dPre rides in the same launch as the other token reductions (M = 1)
                 wgrad.append((1, GHp, n, self._ones(n), self.ONES_LD, dPre, GHp, Gd["b"], GHp))
+                wcover.add("b")
             else:
                 call("seqrec_colsum", ptr(dPre), n, GHp, GHp, ptr(Gd["b"]), 0, ptr(cs_ws), st)
         if wgrad:
@@ -925,7 +932,15 @@ class Engine:
             sk = self._splitk_tiles(tiles, n)
             wsz = sum(sk * w_[0] * w_[1] for w_ in wgrad)
             wsp = self.buf("gemm_ws", wsz) if sk > 1 else None
-            call("seqrec_gemm_f32_grouped", len(wgrad), 0, 0, _lib.gemm_descs(wgrad), sk, ptr(wsp), st, tag="dW+dU")
+            if (self._slab_wgrad and apply_update and sk > 1 and c.merge != "sorted" and not self.priors and len(sparse_jobs) <= 4
+                    and len([k for k in Gd if tr[k]]) <= 8):
+                # the split-K slabs stay unreduced: the norm launch adds them, writes the gradients and takes their squares
+                import ctypes
+                descs, ns = _lib.gemm_descs(wgrad), ctypes.c_int(0)
+                call("seqrec_gemm_f32_grouped_slabs", len(wgrad), 0, 0, descs, sk, ptr(wsp), ctypes.addressof(ns), st, tag="dW+dU")
+                wg_slabs = (descs, len(wgrad), int(ns.value), wsp)
+            else:
+                call("seqrec_gemm_f32_grouped", len(wgrad), 0, 0, _lib.gemm_descs(wgrad), sk, ptr(wsp), st, tag="dW+dU")
         if join_side:
             torch.cuda.current_stream(self.dev).wait_event(self._ev_join)
         # ---- row-sparse contributions: one launch for (up to 4) scatter lists
@@ -955,6 +970,12 @@ class Engine:
                 npart = int(_lib.load().seqrec_opt_sqnorm_ordered_floats(len(dk), cnt, mx))
                 call("seqrec_opt_sqnorm_ordered", len(dk), gp, nn, arr, cnt, ptr(self.buf("sq_partials", npart)), npart, ptr(cur), 0,
                      ptr(lrows), n, ptr(self.loss_out), st)
+            elif wg_slabs is not None:
+                plain = [k for k in dk if k not in wcover]
+                gpp = _lib.ptr_array([Gd[k] for k in plain]) if plain else None
+                nnp = _lib.i64_array([Gd[k].numel() for k in plain]) if plain else None
+                call("seqrec_opt_sqnorm_slabs", len(plain), gpp, nnp, wg_slabs[1], wg_slabs[0], wg_slabs[2], ptr(wg_slabs[3]), arr, cnt,
+                     ptr(cur), ptr(lrows), n, ptr(self.loss_out), st)
             else:
                 call("seqrec_opt_sqnorm", len(dk), gp, nn, arr, cnt, ptr(cur), ptr(lrows), n, ptr(self.loss_out), st)
             call("seqrec_opt_apply", len(dk), _lib.ptr_array([P[k] for k in dk]) if dk else None,

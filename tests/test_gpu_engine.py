@@ -319,25 +319,6 @@ def test_bench_single_gpu_line_carries_cpu_baseline_and_parity():
     assert 0.0 <= out["recall_at_20"] <= 1.0
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_engine_ranks_share_one_gpu_vs_global_oracle(world):
-    """2 / 4 processes (the GPU box kills a run with more than 6 processes on its card -- 4 ranks + this test
-    process is the most that fits; the 8-rank routing itself runs on CPU in test_distributed_cpu.py) share cuda:0 (collectives staged through gloo) and train the row-sharded model
-    for two steps; rank 0 checks global loss, replicated weights and every table shard against the
-    oracle run on the global model with the same stratified negatives, plus the sharded eval loss
-    and Recall@K rank counting (tests/dist_gpu_worker.py)."""
-    import os
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
-           "127.0.0.1", "--master-port", str(29640 + world), os.path.join(here, "dist_gpu_worker.py")]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
-    assert r.stdout.count("case ok") == 4 and r.stdout.count("rank counts ok") == 3 and r.stdout.count("sharded topk ok") == 3
-
-
 def test_bench_multi_rank_code_path_rehearsal():
     """bench.py's N > 1 path (rank-sliced batches, broadcast of the replicated weights, barrier + MAX
     timing, sharded Recall@20, ONE JSON line from rank 0) rehearsed with two processes on this one GPU

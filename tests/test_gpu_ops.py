@@ -477,6 +477,57 @@ def test_gemm_slabs_feed_the_scatter_like_the_reduced_product(W):
     assert lib.seqrec_rows_merge_sorted(arr, cnt, ptr(mws), nbytes, None) == -3
 
 
+def test_norm_launch_finishes_grouped_slab_products():
+    """seqrec_gemm_f32_grouped_slabs + seqrec_opt_sqnorm_slabs == seqrec_gemm_f32_grouped + seqrec_opt_sqnorm: the products
+    written by the norm launch are bit-identical to the reducing form (same slab order), two of them column blocks of ONE
+    tensor (dU_zr | dU_h), one a [1, N] row (db); the norm agrees to rounding; a plain dense tensor, a scatter list and
+    the batch loss ride along in both."""
+    import ctypes
+    rng = np.random.default_rng(91)
+    n, H, sk = 1500, 64, 4
+    A1 = dev(rng.normal(size=(n, H)).astype(np.float32)); A2 = dev(rng.normal(size=(n, H)).astype(np.float32))
+    ones = torch.ones((n, 4), device="cuda")
+    D = dev(rng.normal(size=(n, 3 * H)).astype(np.float32) * 0.1)
+    extra = dev(rng.normal(size=777).astype(np.float32))
+    V, W, m = 400, 64, 300
+    rows = dev(rng.permutation(V)[:m].astype(np.int32)); vals = dev(rng.normal(size=(m, W)).astype(np.float32))
+    lrows = dev(rng.random(n).astype(np.float32))
+    res = []
+    for slabs in (False, True):
+        U = torch.full((H, 3 * H), 5.0, device="cuda"); b = torch.full((3 * H,), 5.0, device="cuda")
+        items = [(H, 2 * H, n, A1, H, D, 3 * H, U, 3 * H), (H, H, n, A2, H, D[:, 2 * H:], 3 * H, U[:, 2 * H:], 3 * H),
+                 (1, 3 * H, n, ones, 4, D, 3 * H, b, 3 * H)]
+        descs = L.gemm_descs(items)
+        ws = torch.zeros(sk * sum(i[0] * i[1] for i in items), device="cuda")
+        gt = torch.zeros((V, W), device="cuda"); slot = torch.full((V,), 2 ** 31 - 1, dtype=torch.int32, device="cuda")
+        arr, cnt = L.rows_jobs([dict(table=gt, accum=gt, gtab=gt, slot=slot, rows=rows, vals=vals, ldv=W, row_scale=None, n=m,
+                                     width=W, base=0)])
+        call("seqrec_rows_scatter_add_multi", arr, cnt, st())
+        sq = torch.zeros(1, device="cuda"); lo = torch.zeros(2, device="cuda")
+        if slabs:
+            ns = ctypes.c_int(0)
+            call("seqrec_gemm_f32_grouped_slabs", 3, 0, 0, descs, sk, ptr(ws), ctypes.addressof(ns), st())
+            assert ns.value == sk
+            call("seqrec_opt_sqnorm_slabs", 1, L.ptr_array([extra]), L.i64_array([extra.numel()]), 3, descs, ns.value, ptr(ws), arr, cnt,
+                 ptr(sq), ptr(lrows), n, ptr(lo), st())
+        else:
+            call("seqrec_gemm_f32_grouped", 3, 0, 0, descs, sk, ptr(ws), st())
+            call("seqrec_opt_sqnorm", 3, L.ptr_array([extra, U, b]), L.i64_array([extra.numel(), U.numel(), b.numel()]), arr, cnt,
+                 ptr(sq), ptr(lrows), n, ptr(lo), st())
+        torch.cuda.synchronize()
+        res.append((U, b, sq.item(), lo.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[0][3], res[1][3])
+    assert abs(res[0][2] - res[1][2]) <= 2e-6 * res[0][2]
+    ref = float((res[0][0].double() ** 2).sum() + (res[0][1].double() ** 2).sum() + (extra.double() ** 2).sum() + (vals.double() ** 2).sum())
+    assert abs(res[1][2] - ref) <= 1e-5 * ref
+    # argument checks: a product listed with a bias or accumulate is refused, so is a missing workspace
+    lib = L.load()
+    bad = L.gemm_descs(items); bad[0].accumulate = 1
+    assert lib.seqrec_opt_sqnorm_slabs(0, None, None, 3, bad, sk, ptr(ws), None, 0, ptr(sq), None, 0, None, None) == -3
+    assert lib.seqrec_opt_sqnorm_slabs(0, None, None, 3, descs, sk, None, None, 0, ptr(sq), None, 0, None, None) == -1
+
+
 def test_fused_optimizer_launches_equal_the_separate_kernels():
     """seqrec_opt_sqnorm / seqrec_opt_apply (two launches for the whole clipnorm + Adagrad step) against
     the five separate kernels on the same data: dense tensors of odd sizes + two scatter lists with

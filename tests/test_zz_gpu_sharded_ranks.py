@@ -1,0 +1,29 @@
+"""The staged multi-rank runs of the row-sharded engine (several processes share cuda:0, collectives staged through gloo).
+
+They live in the file that sorts LAST on purpose: on 3 of ~12 GPU boxes of round 2 the 4-rank run's LSTM-512 case came back
+with the same wrong second-step losses (every rank lower than the oracle: [3.595, 5.605, 5.082, 6.456] against
+[4.093, 6.426, 6.220, 7.587]) while 20+ runs on the other boxes, the 2-rank run on the same boxes and a run with every
+torch.empty poisoned (SEQREC_POISON=1) were right.  Not explained yet; tests/dist_gpu_worker.py prints what
+every rank saw when it happens, and `tools/dist4_repeat.sh` repeats the run with per-rank checksums."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_engine_ranks_share_one_gpu_vs_global_oracle(world):
+    """2 / 4 processes (the GPU box kills a run with more than 6 processes on its card -- 4 ranks + this test
+    process is the most that fits; the 8-rank routing itself runs on CPU in test_distributed_cpu.py) share cuda:0 (collectives staged through gloo) and train the row-sharded model
+    for two steps; rank 0 checks global loss, replicated weights and every table shard against the
+    oracle run on the global model with the same stratified negatives, plus the sharded eval loss
+    and Recall@K rank counting (tests/dist_gpu_worker.py)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(29640 + world), os.path.join(here, "dist_gpu_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
+    assert r.stdout.count("case ok") == 4 and r.stdout.count("rank counts ok") == 3 and r.stdout.count("sharded topk ok") == 3
