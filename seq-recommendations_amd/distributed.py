@@ -478,8 +478,9 @@ class ShardedEngine(Engine):
             if c.logq and self.logq_global is not None:
                 parts.append(("lq_tgt", self.logq_global_host[rb.tgt].view(np.int32)))
             # everything the step needs from the host in ONE int32 blob: the batch's index arrays and its routing
-            blob = torch.from_numpy(np.concatenate([np.asarray(x, dtype=np.int32) for _, x in parts])).to(self.dev, non_blocking=True)
-            d = {"n": n, "T": rb.T, "B": rb.B, "rb": rb, "blob": blob, "plan": plan}
+            host = torch.from_numpy(np.concatenate([np.asarray(x, dtype=np.int32) for _, x in parts]))
+            blob = host.to(self.dev, non_blocking=True)      # `host` stays referenced from d: the copy may outlive this call
+            d = {"n": n, "T": rb.T, "B": rb.B, "rb": rb, "blob": blob, "plan": plan, "_host": [host]}
             o = 0
             for name, x in parts:
                 d[name] = blob[o:o + len(x)]

@@ -500,9 +500,12 @@ class Engine:
             parts.append(rb.ids.astype(np.int32))
         if rb.tgt is not None:
             parts.append(rb.tgt.astype(np.int32))
-        blob = torch.from_numpy(np.concatenate(parts)).to(self.dev, non_blocking=True)
+        # the host source of every non-blocking copy stays referenced from the batch dict: the copy may still be reading it
+        # when this function returns (pageable memory: the runtime is free to pin it and transfer later)
+        host = [torch.from_numpy(np.concatenate(parts))]
+        blob = host[0].to(self.dev, non_blocking=True)
         o = 0
-        d = {"n": n, "T": rb.T, "B": rb.B, "rb": rb}
+        d = {"n": n, "T": rb.T, "B": rb.B, "rb": rb, "_host": host}
         d["step_off"] = blob[o:o + rb.T + 1]; o += rb.T + 1
         d["prev"] = blob[o:o + n]; o += n
         if rb.ids is not None:
@@ -512,11 +515,13 @@ class Engine:
         if rb.x is not None:
             x = np.zeros((n, self.Fp), np.float32)
             x[:, : rb.x.shape[1]] = rb.x
-            d["x"] = torch.from_numpy(x).to(self.dev, non_blocking=True)
+            host.append(torch.from_numpy(x))
+            d["x"] = host[-1].to(self.dev, non_blocking=True)
         if getattr(rb, "xs", None) is not None and c.x_to_y:
             xs = np.zeros((n, self.Fxp), np.float32)
             xs[:, : rb.xs.shape[1]] = rb.xs
-            d["xs"] = torch.from_numpy(xs).to(self.dev, non_blocking=True)
+            host.append(torch.from_numpy(xs))
+            d["xs"] = host[-1].to(self.dev, non_blocking=True)
         d["blob"] = blob
         return d
 
@@ -548,9 +553,10 @@ class Engine:
             call("seqrec_pack_batch_host", ptr(ds["flat"]), ptr(ds["starts"]), sess.ctypes.data, so32.ctypes.data, B, T,
                  ptr(d["sess"]), ptr(d["step_off"]), ptr(d["ids"]), ptr(d["tgt"]), ptr(d["prev"]), st)
         else:
-            blob = torch.from_numpy(np.concatenate([so32, sess])).to(self.dev, non_blocking=True)
+            host = torch.from_numpy(np.concatenate([so32, sess]))
+            blob = host.to(self.dev, non_blocking=True)
             d = {"n": n, "T": T, "B": B, "rb": rb, "blob": blob, "step_off": blob[: T + 1], "sess": blob[T + 1:],
-                 "ids": out[:n], "tgt": out[n:2 * n], "prev": out[2 * n:3 * n], "_out": out}
+                 "ids": out[:n], "tgt": out[n:2 * n], "prev": out[2 * n:3 * n], "_out": out, "_host": [host]}
             call("seqrec_pack_batch", ptr(ds["flat"]), ptr(ds["starts"]), ptr(d["sess"]), ptr(d["step_off"]), B, T, ptr(d["ids"]),
                  ptr(d["tgt"]), ptr(d["prev"]), st)
         if history:
