@@ -98,7 +98,9 @@ def main():
             # the update's inputs as the device saw them (a second-step loss that equals "no update at all" was seen on a few
             # boxes: clip scale 0 would do that -- squared norm inf, or a wild token count)
             sc_, sq_, nt_ = float(eng.scale.item()), float(eng.sq.item()), float(eng.ntok.item()) if eng.unified else 0.0
-            print("update", case["cell"], case["H"], "rank", rank, "step", s, "scale", sc_, "sq", sq_, "ntok", nt_, flush=True)
+            gmax = {k: float(v.abs().max().item()) for k, v in eng.Gd.items()}      # the (summed) dense gradients survive the update
+            print("update", case["cell"], case["H"], "rank", rank, "step", s, "scale", sc_, "sq", sq_, "ntok", nt_, "max |dense grad|", gmax,
+                  flush=True)
             assert np.isfinite(sc_) and sc_ > 0.0, (case, rank, s, sc_, sq_, nt_)
             if eng.unified and s == 0:
                 assert ev == losses[0], (ev, losses[0])
