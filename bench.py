@@ -185,6 +185,7 @@ def kernel_model(cfgd, n_tok, K, B):
         "seqrec_gemm_f32[dX]": ("mfma", 2.0 * n_tok * D * G * H),
         "seqrec_gemm_f32[dU]": ("mfma", 2.0 * n_tok * H * G * H / (2 if G == 3 else 1)),   # GRU: two launches
         "seqrec_gemm_f32_grouped[dW+dU]": ("mfma", 2.0 * n_tok * G * H * (D + H)),          # dW and dU in one launch
+        "seqrec_gemm_f32_grouped_slabs[dW+dU]": ("mfma", 2.0 * n_tok * G * H * (D + H)),    # slabs finished by the norm launch
         "seqrec_gather_rows[E]": ("hbm", 8.0 * D * n_tok),                                   # 4 B read + 4 B written / elt
     }
     return m
