@@ -584,7 +584,12 @@ class ShardedEngine(Engine):
         dk = sorted(Gd)
         gp = _lib.ptr_array([Gd[k] for k in dk])
         nn = _lib.i64_array([Gd[k].numel() for k in dk])
-        call("seqrec_sqnorm_multi", len(dk), gp, nn, ptr(self.sq), st)
+        # the dense norm in a FIXED order (per-block partials added in index order, no float atomics): every rank adds the same
+        # number to the (all-reduced, hence identical) row norm, so the clip scale -- and with it the replicated weights --
+        # stay bit-identical across ranks; the float-atomic form differed in the last bit from rank to rank
+        npart = int(_lib.load().seqrec_opt_sqnorm_ordered_floats(len(dk), 0, 0))
+        call("seqrec_opt_sqnorm_ordered", len(dk), gp, nn, None, 0, ptr(self.buf("sq_partials", npart)), npart, ptr(self.sq), 1,
+             None, 0, None, st)
         arr, cnt = rows_job if rows_job is not None else (None, 0)
         call("seqrec_opt_apply", len(dk), _lib.ptr_array([P[k] for k in dk]), _lib.ptr_array([self.A[k] for k in dk]), gp, nn,
              arr, cnt, ptr(self.sq), float(clipnorm if clipnorm else 0.0), lr, eps, ptr(self.scale), None, ptr(div), st)

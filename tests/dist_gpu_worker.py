@@ -141,6 +141,12 @@ def main():
             got["Eout"] = eng.get_param("Eout")
         allgot = [None] * R
         dist.all_gather_object(allgot, got)
+        scales = [None] * R
+        dist.all_gather_object(scales, float(eng.scale.item()))
+        assert len(set(scales)) == 1, ("the clip scale must be bit-identical on every rank (replicated weights)", scales)
+        for k in ("W", "U", "b"):
+            for r in range(1, R):
+                assert np.array_equal(allgot[r][k], allgot[0][k]), ("replicated weights differ between ranks", case, k, r)
         if rank == 0:
             ocfg = dict(cell=cell, act="relu", input="embed", output="sampled", tied=tied, use_bias=True, out_bias=False)
             op = {k: v.copy() for k, v in p.items()}
