@@ -160,6 +160,20 @@ int seqrec_rnn_bwd_stepwise(int cell, int act, int H, int H_real, int T, int B,
                             const float* dHout, const float* Hout, const float* gates, const float* aux,
                             float* dPre, const float* upack, float* workspace, const float* rmask,
                             int use_graph, void* stream);
+/*      the same BPTT with its input gradient given IN PARTS -- dHout[q, :] = sum_{s < n_slabs} (slabs + s * slab_stride)[q*H + :]
+ *      + add_scale[q] * add_table[add_index[q] * add_ld + :] (add_table NULL: no such term; add_scale NULL = 1; add_index < 0
+ *      adds nothing): the split-K slabs of dH = dlogits . Eneg (seqrec_gemm_f32_slabs) and the target-row term that the
+ *      reduce launch of seqrec_gemm_f32_fused would add.  The cluster form of the GRU scan adds the parts where it reads
+ *      dHout (no reduce launch); every other form first writes the sum to `dHout_scratch` (n_tok * H floats, required). */
+typedef struct seqrec_dh_parts {
+    const float* slabs; int32_t n_slabs; int32_t reserved_; int64_t slab_stride;
+    const float* add_table; const int32_t* add_index; const float* add_scale; int64_t add_ld;
+} seqrec_dh_parts;
+int seqrec_rnn_bwd_stepwise_parts(int cell, int act, int H, int H_real, int T, int B,
+                                  const int32_t* step_off, const int32_t* step_off_host, int64_t n_tok,
+                                  const seqrec_dh_parts* parts, float* dHout_scratch, const float* Hout, const float* gates,
+                                  const float* aux, float* dPre, const float* upack, float* workspace, const float* rmask,
+                                  int use_graph, void* stream);
 /*      step_off_host: int32[T+1] on the HOST (required): every launch gets its exact geometry as kernel arguments;
  *      step_off (device copy) is not read by these two entry points and may be NULL (kept for signature stability).
  *      use_graph != 0: the call's launch sequence is captured ONCE per distinct kernel sequence (cell, activation, H,

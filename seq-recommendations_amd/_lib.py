@@ -52,6 +52,7 @@ _SIGS = {
     "seqrec_rnn_pack_u_stepwise": [I, I, P, P, P],
     "seqrec_rnn_fwd_stepwise": [I, I, I, I, I, I, P, P, P, P, P, P, P, P, I, P],
     "seqrec_rnn_bwd_stepwise": [I, I, I, I, I, I, P, P, L, P, P, P, P, P, P, P, P, I, P],
+    "seqrec_rnn_bwd_stepwise_parts": [I, I, I, I, I, I, P, P, L, P, P, P, P, P, P, P, P, P, I, P],
     "seqrec_graph_cache_clear": [],
     "seqrec_full_softmax_ce": [P, L, P, L, I, F, P, P, P],
     "seqrec_sampled_softmax_ce": [P, L, P, I, P, P, P, P, P, P, L, I, F, P, P, P],
@@ -156,6 +157,22 @@ class GemmFuse(C.Structure):
 def gemm_fuse(a_index=None, add_table=None, add_index=None, add_scale=None, add_ld=0):
     f = GemmFuse()
     f.a_index = None if a_index is None else a_index.data_ptr()
+    f.add_table = None if add_table is None else add_table.data_ptr()
+    f.add_index = None if add_index is None else add_index.data_ptr()
+    f.add_scale = None if add_scale is None else add_scale.data_ptr()
+    f.add_ld = int(add_ld)
+    return f
+
+
+class DhParts(C.Structure):
+    """seqrec_dh_parts (include/seqrec_hip.h)."""
+    _fields_ = [("slabs", P), ("n_slabs", C.c_int32), ("reserved_", C.c_int32), ("slab_stride", L), ("add_table", P),
+                ("add_index", P), ("add_scale", P), ("add_ld", L)]
+
+
+def dh_parts(slabs, n_slabs, slab_stride, add_table=None, add_index=None, add_scale=None, add_ld=0):
+    f = DhParts()
+    f.slabs, f.n_slabs, f.slab_stride = slabs.data_ptr(), int(n_slabs), int(slab_stride)
     f.add_table = None if add_table is None else add_table.data_ptr()
     f.add_index = None if add_index is None else add_index.data_ptr()
     f.add_scale = None if add_scale is None else add_scale.data_ptr()

@@ -28,6 +28,8 @@ struct ClusterArgs {
     unsigned* flags;                           // [groups][64]: words 0..31 phase counters, 32..63 XCC ids
     unsigned* error;                           // set when a bounded spin ran out
     unsigned epoch;
+    // BPTT input gradient in parts (seqrec_dh_parts): dHout = slab 0, dh_ns slabs dh_stride floats apart, + dh_scale[q] * dh_add[dh_idx[q]]
+    int dh_ns; long dh_stride; const float* dh_add; const int* dh_idx; const float* dh_scale; long dh_ld;
     int so[CL_TMAX + 1];
 };
 
@@ -301,7 +303,13 @@ __global__ __launch_bounds__(256) void gru_cluster_bwd(ClusterArgs a) {
     auto prefetch = [&](int t) {
         const int p0 = a.so[t], nact = min(16, a.so[t + 1] - p0 - r0);
         const long q = (long)p0 + r0 + (row < nact ? row : 0);
-        n_dh = a.dHout[q * H + col];
+        float v = a.dHout[q * H + col];
+        for (int sl = 1; sl < a.dh_ns; ++sl) v += a.dHout[(long)sl * a.dh_stride + q * H + col];      // slab order == the reduce launch
+        if (a.dh_add) {
+            const int ix = a.dh_idx[q];
+            v += ix < 0 ? 0.f : (a.dh_scale ? a.dh_scale[q] : 1.f) * a.dh_add[(long)ix * a.dh_ld + col];
+        }
+        n_dh = v;
         n_z = a.gates[q * GH + col]; n_r = a.gates[q * GH + H + col]; n_hh = a.gates[q * GH + 2 * H + col];
         n_h0 = t > 0 ? a.Hout[((long)a.so[t - 1] + r0 + (row < nact ? row : 0)) * H + col] : 0.f;
     };
@@ -474,7 +482,8 @@ template <int ACT> const void* bwd_kernel(int J) {
 }  // namespace
 
 bool seqrec_cluster_gru_bwd(int act, int H, int H_real, int T, const int32_t* soh, const float* dHout, const float* Hout,
-                            const float* gates, const float* aux, float* dPre, const float* upack, hipStream_t st, int* rc) {
+                            const float* gates, const float* aux, float* dPre, const float* upack, hipStream_t st, int* rc,
+                            const seqrec_dh_parts* parts) {
     (void)aux;
     if (!cluster_enabled() || T > CL_TMAX || T < 1) return false;
     const int J = H / 64, CB = H / 16;
@@ -488,6 +497,10 @@ bool seqrec_cluster_gru_bwd(int act, int H, int H_real, int T, const int32_t* so
     if (gcap > CL_MAX_GROUPS) gcap = CL_MAX_GROUPS;
     ClusterArgs a = {};
     a.H_real = H_real; a.T = T; a.dHout = dHout; a.Hout = const_cast<float*>(Hout); a.gates = const_cast<float*>(gates); a.dPre = dPre;
+    if (parts) {
+        a.dHout = parts->slabs; a.dh_ns = parts->n_slabs; a.dh_stride = (long)parts->slab_stride;
+        a.dh_add = parts->add_table; a.dh_idx = parts->add_index; a.dh_scale = parts->add_scale; a.dh_ld = (long)parts->add_ld;
+    }
     a.pk_a = upack + 3l * H * H; a.pk_b = upack + 4l * H * H;
     for (int t = 0; t <= T; ++t) a.so[t] = soh[t];
     for (int g0 = 0; g0 < G; g0 += gcap) {

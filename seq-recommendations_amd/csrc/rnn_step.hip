@@ -1064,15 +1064,57 @@ extern "C" int seqrec_rnn_fwd_stepwise(int cell, int act, int H, int H_real, int
 }
 
 // workspace: 2 * N_tok * H floats (carried dh per token, dcar / carried dc per token)
+namespace {
+// dHout = sum of the parts (the forms of the scan that read dHout from ONE array): same order of additions as the reduce
+// launch of the producing GEMM (slabs in slab order, then the row term)
+__global__ void dh_parts_sum_kernel(seqrec_dh_parts p, int H, long total, float* __restrict__ out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int s = 0; s < p.n_slabs; ++s) v += p.slabs[(long)s * p.slab_stride + i];
+        if (p.add_table) {
+            const long q = i / H;
+            const int ix = p.add_index[q];
+            v += ix < 0 ? 0.f : (p.add_scale ? p.add_scale[q] : 1.f) * p.add_table[(long)ix * p.add_ld + (i - q * H)];
+        }
+        out[i] = v;
+    }
+}
+}  // namespace
+
+static int rnn_bwd_stepwise_impl(int cell, int act, int H, int H_real, int T, int B, const int32_t* step_off_host, int64_t n_tok,
+                                 const float* dHout, const seqrec_dh_parts* parts, float* dh_scratch, const float* Hout,
+                                 const float* gates, const float* aux, float* dPre, const float* upack, float* workspace,
+                                 const float* rmask, int use_graph, void* stream);
+
 extern "C" int seqrec_rnn_bwd_stepwise(int cell, int act, int H, int H_real, int T, int B,
                                        const int32_t* step_off, const int32_t* step_off_host, int64_t n_tok,
                                        const float* dHout, const float* Hout, const float* gates, const float* aux,
                                        float* dPre, const float* upack, float* workspace, const float* rmask,
                                        int use_graph, void* stream) {
     (void)step_off;
+    return rnn_bwd_stepwise_impl(cell, act, H, H_real, T, B, step_off_host, n_tok, dHout, nullptr, nullptr, Hout, gates, aux, dPre,
+                                 upack, workspace, rmask, use_graph, stream);
+}
+extern "C" int seqrec_rnn_bwd_stepwise_parts(int cell, int act, int H, int H_real, int T, int B,
+                                             const int32_t* step_off, const int32_t* step_off_host, int64_t n_tok,
+                                             const seqrec_dh_parts* parts, float* dHout_scratch, const float* Hout,
+                                             const float* gates, const float* aux, float* dPre, const float* upack,
+                                             float* workspace, const float* rmask, int use_graph, void* stream) {
+    (void)step_off;
+    if (!parts || !parts->slabs || parts->n_slabs < 1 || !dHout_scratch) return SEQREC_E_ARG;
+    if (parts->n_slabs > 1 && parts->slab_stride < n_tok * H) return SEQREC_E_ARG;
+    if (parts->add_table && (!parts->add_index || parts->add_ld < H)) return SEQREC_E_ARG;
+    return rnn_bwd_stepwise_impl(cell, act, H, H_real, T, B, step_off_host, n_tok, nullptr, parts, dHout_scratch, Hout, gates, aux,
+                                 dPre, upack, workspace, rmask, use_graph, stream);
+}
+
+static int rnn_bwd_stepwise_impl(int cell, int act, int H, int H_real, int T, int B, const int32_t* step_off_host, int64_t n_tok,
+                                 const float* dHout, const seqrec_dh_parts* parts, float* dh_scratch, const float* Hout,
+                                 const float* gates, const float* aux, float* dPre, const float* upack, float* workspace,
+                                 const float* rmask, int use_graph, void* stream) {
     if (!ok_shape(cell, act, H, H_real, T, B)) return SEQREC_E_SHAPE;
     if (T == 0 || B == 0) return 0;
-    if (!step_off_host || !dHout || !Hout || !dPre || !upack || !workspace || n_tok <= 0) return SEQREC_E_ARG;
+    if (!step_off_host || (!dHout && !parts) || !Hout || !dPre || !upack || !workspace || n_tok <= 0) return SEQREC_E_ARG;
     if (cell != SEQREC_CELL_SIMPLERNN && (!gates || !aux)) return SEQREC_E_ARG;
     hipStream_t st = as_stream(stream);
     const int J = H / 64;
@@ -1080,7 +1122,16 @@ extern "C" int seqrec_rnn_bwd_stepwise(int cell, int act, int H, int H_real, int
     const int32_t* soh = step_off_host;
     if (cell == SEQREC_CELL_GRU && !rmask) {          // cluster form: one launch, in-kernel exchange (rnn_cluster.hip)
         int rc = 0;
-        if (seqrec_cluster_gru_bwd(act, H, H_real, T, soh, dHout, Hout, gates, aux, dPre, upack, st, &rc)) return rc;
+        if (seqrec_cluster_gru_bwd(act, H, H_real, T, soh, dHout, Hout, gates, aux, dPre, upack, st, &rc, parts)) return rc;
+    }
+    if (parts) {                                      // every other form reads dHout from one array
+        const long total = (long)soh[T] * H;
+        if (total > 0) {
+            hipLaunchKernelGGL(dh_parts_sum_kernel, dim3((unsigned)std::min<long>(2048, (total + 255) / 256)), dim3(256), 0, st, *parts, H,
+                               total, dh_scratch);
+            SEQREC_LAUNCH_CHECK();
+        }
+        dHout = dh_scratch;
     }
     Plan pl;
     pl.reserve(2 * (size_t)T);

@@ -58,7 +58,8 @@ def profile_stop():
     return out
 
 
-def call(name, *args, tag=None):
+def call(name, *args, tag=None, prof_name=None):
+    """prof_name: the per-call profile books this call under another entry point's name (a variant of the same step)."""
     if _PROF is None:
         return _raw_call(name, *args)
     a = torch.cuda.Event(enable_timing=True)
@@ -66,7 +67,7 @@ def call(name, *args, tag=None):
     a.record()
     _raw_call(name, *args)
     b.record()
-    _PROF["events"].append((name, tag, a, b))
+    _PROF["events"].append((prof_name or name, tag, a, b))
 
 
 def _pad_h(H):
@@ -205,6 +206,10 @@ class Engine:
         self._side_stream = None
         self.last_slabs = {}
         self._fuse_prologue = _os.environ.get("SEQREC_FUSE_PROLOGUE", "1") != "0"   # A/B switch: U re-pack + negatives in one launch
+        # A/B switch, OFF: dH reaches the BPTT as split-K slabs + row term (seqrec_rnn_bwd_stepwise_parts).  Measured: the reduce
+        # launch (5 us) goes, but the cluster BPTT's per-step operand prefetch grows from 5 to 9 loads with a dependent index
+        # hop and the call from 110 to 138 us -- 0.405 -> 0.427 ms per step
+        self._slab_dh = _os.environ.get("SEQREC_SLAB_DH", "0") != "0"
         self._slab_wgrad = _os.environ.get("SEQREC_SLAB_WGRAD", "1") != "0"        # A/B switch: the weight gradients' split-K reduce rides in the norm launch
         self._slab_scatter = _os.environ.get("SEQREC_SLAB_SCATTER", "1") != "0"   # A/B switch: dX / dEneg reach the scatter as split-K slabs
         self._slab_min_k = int(_os.environ.get("SEQREC_SLAB_MIN_K", "256"))
@@ -333,6 +338,8 @@ class Engine:
             if c.input == "embed":
                 need["dX_slabs"] = max(1, GHp // self._slab_min_k) * n * self.Dp
             if c.output == "sampled":
+                if self._slab_dh:
+                    need["dH_slabs"] = max(self._splitk(m, Hp, c.K) * m * Hp for m in range(64, n + 64, 64))
                 need["dEneg_slabs"] = max(self._splitk(c.K, Hp, m) for m in range(64, n + 64, 64)) * c.K * Hp
         for name, sz in need.items():
             self.buf(name, int(max(sz, 1)))
@@ -663,10 +670,20 @@ class Engine:
             call("seqrec_rnn_fwd", CELL[c.cell], ACT[c.act], Hp, c.H, d["T"], d["B"], ptr(d["step_off"]), ptr(XW),
                  ptr(Hout), ptr(gates), ptr(aux), ptr(self.upack), st)
 
-    def _scan_bwd(self, d, dHout, Hout, gates, aux, dPre, rmask=None):
+    def _scan_bwd(self, d, dHout, Hout, gates, aux, dPre, rmask=None, parts=None):
+        """parts (_lib.dh_parts): dHout arrives as split-K slabs + a row term; dHout is then scratch for the scan forms that need
+        the sum in one array (seqrec_rnn_bwd_stepwise_parts)."""
         c, st = self.cfg, self._stream()
         Hp = self.Hp
-        if self.stepwise:
+        if self.stepwise and parts is not None:
+            import ctypes
+            so = d["rb"].step_off
+            cap = d["n"]
+            wsp = self.buf("scan_ws", 2 * cap * Hp)
+            call("seqrec_rnn_bwd_stepwise_parts", CELL[c.cell], ACT[c.act], Hp, c.H, d["T"], d["B"], None, so.ctypes.data, cap,
+                 ctypes.addressof(parts), ptr(dHout), ptr(Hout), ptr(gates), ptr(aux), ptr(dPre), ptr(self.upack), ptr(wsp),
+                 ptr(rmask), int(self.use_graph), st, prof_name="seqrec_rnn_bwd_stepwise")
+        elif self.stepwise:
             so = d["rb"].step_off
             cap = d["n"]
             wsp = self.buf("scan_ws", 2 * cap * Hp)
@@ -806,6 +823,7 @@ class Engine:
         tr = self.trainable
         sparse_jobs = []     # scatter lists of this step (see _job)
         join_side = False    # a side-stream GEMM has to be joined before its consumer
+        dh_parts = None      # dH as split-K slabs + target-row term for the BPTT (seqrec_rnn_bwd_stepwise_parts)
         wgrad = []           # deferred weight-gradient GEMMs (M, N, K, A, lda, B, ldb, C, ldc), launched grouped
         wcover = set()       # dense tensors whose gradient those products tile completely
         wg_slabs = None      # (descs, count, n_slabs, workspace) when the products were left as split-K slabs for the norm launch
@@ -837,8 +855,15 @@ class Engine:
             Et = P[tname]
             dln, dlt, neg, Eneg = r["dln"], r["dlt"], r["neg"], r["Eneg"]
             # dH = dlogits . Eneg + dlt * Eout[tgt]: the target-row term rides in the GEMM's final write
-            self.gemm(1, 0, n, Hp, K, dln, K, Eneg, Hp, dHd, Hp, splitk=self._splitk(n, Hp, K), tag="dH",
-                      fuse=_lib.gemm_fuse(add_table=Et, add_index=d["tgt"], add_scale=dlt, add_ld=Hp))
+            sk_h = self._splitk(n, Hp, K)
+            if self._slab_dh and self.stepwise and sk_h > 1 and "out" not in drops:
+                # dH's only reader is the BPTT: its split-K slabs and the target-row term go there as parts (the cluster scan
+                # adds them where it reads dHout -- no reduce launch; other scan forms sum them into dHd first)
+                hs, ns_h, ss_h = self.gemm_slabs(1, 0, n, Hp, K, dln, K, Eneg, Hp, "dH_slabs", sk_h, tag="dH")
+                dh_parts = _lib.dh_parts(hs, ns_h, ss_h, add_table=Et, add_index=d["tgt"], add_scale=dlt, add_ld=Hp)
+            else:
+                self.gemm(1, 0, n, Hp, K, dln, K, Eneg, Hp, dHd, Hp, splitk=sk_h, tag="dH",
+                          fuse=_lib.gemm_fuse(add_table=Et, add_index=d["tgt"], add_scale=dlt, add_ld=Hp))
             if tr[tname]:
                 dEneg = self.buf("dEneg", K, Hp)
                 ns_neg = ss_neg = 0
@@ -870,7 +895,7 @@ class Engine:
         if "out" in drops:
             call("seqrec_mul", ptr(dHd), ptr(drops["out"]), ptr(dHd), n * Hp, st)
         dPre = self.buf("dPre", n, GHp)
-        self._scan_bwd(d, dHout, r["Hout"], r["gates"], r["aux"], dPre, drops.get("rec"))
+        self._scan_bwd(d, dHout, r["Hout"], r["gates"], r["aux"], dPre, drops.get("rec"), parts=dh_parts)
         bias_in_group = c.use_bias and tr["b"] and "rec" not in drops
         if c.use_bias and tr["b"] and not bias_in_group:
             call("seqrec_colsum", ptr(dPre), n, GHp, GHp, ptr(Gd["b"]), 0, ptr(cs_ws), st)

@@ -750,6 +750,62 @@ def test_cluster_scan_equals_stepwise_scan(H, B, maxlen, act):
         lib.seqrec_debug_scan_cluster(-1)
 
 
+@pytest.mark.parametrize("cell,H,B,maxlen", [("gru", 256, 300, 30), ("gru", 128, 77, 12), ("lstm", 64, 50, 9)])
+def test_bptt_with_its_input_gradient_in_parts(cell, H, B, maxlen):
+    """seqrec_rnn_bwd_stepwise_parts (dHout = 3 split-K slabs + scale[q] * table[index[q]], index -1 = no term) against
+    seqrec_rnn_bwd_stepwise on the materialised sum (same order of additions): the cluster form of the GRU adds the parts
+    in its own loads, the step-wise form (forced for the GRU, the only one for the LSTM) sums them into the scratch array
+    first -- dPre bit for bit in both."""
+    import ctypes
+    lib = L.load()
+    rng = np.random.default_rng(H + B)
+    rb, XW, U = packed_scan_inputs(rng, cell, H, B, maxlen)
+    n, G = rb.n_tok, {"gru": 3, "lstm": 4}[cell]
+    ci = L.CELL[cell]
+    up = torch.empty(int(lib.seqrec_rnn_upack_floats(ci, H)), device="cuda")
+    XWd, Ud = dev(XW), dev(U)
+    call("seqrec_rnn_pack_u_stepwise", ci, H, ptr(Ud), ptr(up), st())
+    so = rb.step_off
+    ns, V = 3, 500
+    slabs = dev((rng.normal(size=(ns, n + 5, H)) * 0.3).astype(np.float32))          # slab stride > n * H
+    table = dev(rng.normal(size=(V, H + 8)).astype(np.float32)); idx = rng.integers(0, V, size=n).astype(np.int32)
+    idx[::7] = -1
+    idxd, scale = dev(idx), dev(rng.normal(size=n).astype(np.float32))
+    total = (slabs[0, :n] + slabs[1, :n]) + slabs[2, :n]
+    term = scale[:, None] * table[torch.from_numpy(np.maximum(idx, 0)).cuda().long(), :H]
+    total = total + torch.where(torch.from_numpy(idx >= 0).cuda()[:, None], term, torch.zeros_like(term))
+    parts = L.dh_parts(slabs, ns, (n + 5) * H, add_table=table, add_index=idxd, add_scale=scale, add_ld=H + 8)
+    try:
+        for mode in ((1, 0) if cell == "gru" else (-1,)):
+            lib.seqrec_debug_scan_cluster(mode)
+            Hout = torch.zeros((n, H), device="cuda"); gates = torch.zeros((n, G * H), device="cuda"); aux = torch.zeros((n, H), device="cuda")
+            call("seqrec_rnn_fwd_stepwise", ci, L.ACT["tanh"], H, H, rb.T, rb.B, None, so.ctypes.data, ptr(XWd), ptr(Hout), ptr(gates),
+                 ptr(aux), ptr(up), None, 0, st())
+            res = []
+            for use_parts in (False, True):
+                dPre = torch.full((n, G * H), float("nan"), device="cuda"); ws = torch.zeros(2 * n * H, device="cuda")
+                if use_parts:
+                    scratch = torch.full((n, H), float("nan"), device="cuda")
+                    call("seqrec_rnn_bwd_stepwise_parts", ci, L.ACT["tanh"], H, H, rb.T, rb.B, None, so.ctypes.data, n,
+                         ctypes.addressof(parts), ptr(scratch), ptr(Hout), ptr(gates), ptr(aux), ptr(dPre), ptr(up), ptr(ws), None, 0, st())
+                else:
+                    call("seqrec_rnn_bwd_stepwise", ci, L.ACT["tanh"], H, H, rb.T, rb.B, None, so.ctypes.data, n, ptr(total), ptr(Hout),
+                         ptr(gates), ptr(aux), ptr(dPre), ptr(up), ptr(ws), None, 0, st())
+                torch.cuda.synchronize()
+                res.append(dPre)
+            assert torch.isfinite(res[1]).all()
+            assert torch.equal(res[0], res[1]), (cell, mode)
+        assert lib.seqrec_cluster_scan_errors(st()) == 0
+        # argument checks
+        bad = L.dh_parts(slabs, 0, (n + 5) * H)
+        assert lib.seqrec_rnn_bwd_stepwise_parts(ci, 0, H, H, rb.T, rb.B, None, so.ctypes.data, n, ctypes.addressof(bad), ptr(total), ptr(Hout),
+                                                 ptr(gates), ptr(aux), ptr(dPre), ptr(up), ptr(ws), None, 0, None) == -1
+        assert lib.seqrec_rnn_bwd_stepwise_parts(ci, 0, H, H, rb.T, rb.B, None, so.ctypes.data, n, ctypes.addressof(parts), None, ptr(Hout),
+                                                 ptr(gates), ptr(aux), ptr(dPre), ptr(up), ptr(ws), None, 0, None) == -1
+    finally:
+        lib.seqrec_debug_scan_cluster(-1)
+
+
 @pytest.mark.parametrize("width,V,sizes", [(256, 5000, (2603, 2000, 2603)), (1, 300, (700, 50)), (100, 64, (900,)),
                                            (512, 2000, (4000, 4000)), (2048, 40, (300, 17)), (64, 7, (5000, 3, 129))])
 def test_sorted_merge_is_bitwise_reproducible_and_equals_the_atomic_scatter(width, V, sizes):
