@@ -807,13 +807,15 @@ def test_bptt_with_its_input_gradient_in_parts(cell, H, B, maxlen):
 
 
 @pytest.mark.parametrize("width,V,sizes", [(256, 5000, (2603, 2000, 2603)), (1, 300, (700, 50)), (100, 64, (900,)),
-                                           (512, 2000, (4000, 4000)), (2048, 40, (300, 17)), (64, 7, (5000, 3, 129))])
+                                           (512, 2000, (4000, 4000)), (2048, 40, (300, 17)), (64, 7, (5000, 3, 129)),
+                                           (256, 5000, (6000, 5001)), (128, 3000, (8192,)), (128, 3000, (8193,))])
 def test_sorted_merge_is_bitwise_reproducible_and_equals_the_atomic_scatter(width, V, sizes):
     """csrc/merge.hip (deterministic row-gradient merge) against numpy float64 sums and against the
     float-atomic scatter: same gradient table to rounding, same owner slots exactly, and two invocations on
     the same inputs agree bit for bit.  Rows are Zipf-skewed so that single rows collect hundreds of
     contributions (runs longer than one 64-position tile and longer than two: the partial chain), V = 7 puts
-    thousands on one row; -1 rows are fillers; one list carries a per-contribution scale."""
+    thousands on one row; -1 rows are fillers; one list carries a per-contribution scale.  (A one-workgroup bitonic sort
+    in LDS for up to 8 192 contributions was tried in place of the device radix sort: 292 against 234 us per call.)"""
     rng = np.random.default_rng(width + V)
     jobs, base = [], 0
     ref = np.zeros((V, width), np.float64)
