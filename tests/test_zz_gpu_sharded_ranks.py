@@ -1,10 +1,11 @@
 """The staged multi-rank runs of the row-sharded engine (several processes share cuda:0, collectives staged through gloo).
 
-They live in the file that sorts LAST on purpose: on 3 of ~12 GPU boxes of round 2 the 4-rank run's LSTM-512 case came back
-with the same wrong second-step losses (every rank lower than the oracle: [3.595, 5.605, 5.082, 6.456] against
-[4.093, 6.426, 6.220, 7.587]) while 20+ runs on the other boxes, the 2-rank run on the same boxes and a run with every
-torch.empty poisoned (SEQREC_POISON=1) were right.  Not explained yet; tests/dist_gpu_worker.py prints what
-every rank saw when it happens, and `tools/dist4_repeat.sh` repeats the run with per-rank checksums."""
+They live in the file that sorts LAST on purpose: in 3 runs of round 2 (25 minutes apart at most, fresh boxes) the 4-rank
+run's LSTM-512 case came back with the same wrong second-step losses ([3.595, 5.605, 5.082, 6.456] against
+[4.093, 6.426, 6.220, 7.587]: exactly what the oracle gives when the first step's update is not applied), while the 60+
+runs before and after, the 2-rank run in the same process and a run with every torch.empty poisoned (SEQREC_POISON=1)
+were right.  Not explained yet; tests/dist_gpu_worker.py prints clip scale, squared norm, token count and
+gradient maxima of every rank and step, and `tools/dist4_repeat.sh` repeats the run with per-rank checksums."""
 import pytest
 
 pytestmark = pytest.mark.gpu
