@@ -33,7 +33,9 @@
 extern "C" {
 #endif
 
-#define SEQREC_ABI_VERSION 2
+/* 3: seqrec_rows_job grew (n_slabs, slab_stride); new entry points seqrec_gemm_f32_slabs, seqrec_gemm_f32_grouped_slabs,
+ *    seqrec_opt_sqnorm_slabs, seqrec_pack_batch_host, seqrec_rnn_pack_u_sample, seqrec_rnn_bwd_stepwise_parts */
+#define SEQREC_ABI_VERSION 3
 
 enum { SEQREC_OK = 0, SEQREC_E_ARG = -1, SEQREC_E_SHAPE = -2, SEQREC_E_UNSUPPORTED = -3 };
 

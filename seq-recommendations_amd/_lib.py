@@ -31,6 +31,8 @@ F = C.c_float
 D = C.c_double
 U64 = C.c_uint64
 
+ABI_VERSION = 3          # SEQREC_ABI_VERSION of include/seqrec_hip.h this binding was written against
+
 # name -> argtypes   (restype is int unless listed in _RESTYPES)
 _SIGS = {
     "seqrec_abi_version": [],
@@ -213,6 +215,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
         fn.argtypes = args
         fn.restype = _RESTYPES.get(name, I)
+    if lib.seqrec_abi_version() != ABI_VERSION:      # struct layouts below are those of this version (seqrec_rows_job grew in 3)
+        raise SeqrecError("%s has ABI version %d, this binding needs %d: rebuild it (__graft_entry__.build())"
+                          % (LIB_PATH, lib.seqrec_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 
