@@ -12,11 +12,33 @@
  *   - every pointer is a DEVICE pointer (hipMalloc'ed, e.g. torch tensor
  *     data_ptr()) unless its name ends in _host;
  *   - fp32 everywhere ("dtype": "f32"), row-major, sizes in elements;
- *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered,
- *     nothing synchronises, allocates or touches global mutable state;
+ *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered and
+ *     no entry point synchronises, except the three that say so
+ *     (seqrec_cluster_scan_errors, seqrec_release_stream, seqrec_graph_cache_clear);
  *   - return value: 0 = ok, negative = SEQREC_E_* (bad argument / unsupported
  *     shape, detected on the host BEFORE anything is launched), positive =
  *     hipError_t of a failed launch.  No exceptions cross the boundary.
+ *     Conditions only the DEVICE can see (a gradient norm that is not finite, an
+ *     index outside its table, an in-kernel wait that ran out) are reported
+ *     through a caller-owned status word (SEQREC_STATUS_* bits, uint32_t in
+ *     device memory, zeroed by the caller) and through
+ *     seqrec_cluster_scan_errors; the Python engine raises on either at its
+ *     next host synchronisation (engine.Engine.check_status).
+ *   - Hidden state.  Workspaces are the caller's, with two exceptions that
+ *     live inside the library, both keyed by stream and both freed by
+ *     seqrec_release_stream(stream):
+ *       (1) the cluster form of the recurrent scans (seqrec_rnn_*_stepwise)
+ *           keeps 16.25 KB of exchange flags per stream -- hipMalloc + a
+ *           synchronous hipMemset on the stream's FIRST cluster scan, then
+ *           epoch-numbered (no reset between calls);
+ *       (2) use_graph != 0 keeps captured launch graphs (a ring of up to 4
+ *           executables per kernel sequence and stream, <= 512 sequences,
+ *           mutex-guarded; seqrec_graph_cache_clear drops them all).
+ *     Two process-wide test switches exist (seqrec_debug_*): they select
+ *     between equivalent kernel forms or force a failure path, are not
+ *     thread-safe, and no product code calls them.
+ *     One stream per caller thread; calls on one stream must not be issued
+ *     concurrently from two threads.
  *
  * Ragged session batch layout ("time-major packed", produced by
  * batching.pack_sessions; replaces the dense pre-padded (N,T,V) one-hot tensors
@@ -35,9 +57,20 @@ extern "C" {
 
 /* 3: seqrec_rows_job grew (n_slabs, slab_stride); new entry points seqrec_gemm_f32_slabs, seqrec_gemm_f32_grouped_slabs,
  *    seqrec_opt_sqnorm_slabs, seqrec_pack_batch_host, seqrec_rnn_pack_u_sample, seqrec_rnn_bwd_stepwise_parts */
-#define SEQREC_ABI_VERSION 3
+/* 4: seqrec_opt_apply takes a status word; new entry points seqrec_gather_rows_bounded, seqrec_release_stream,
+ *    seqrec_cluster_scan_errors_reset, seqrec_debug_cluster_spin_limit; the packed layout of the step-wise LSTM forward
+ *    kernel changed (seqrec_rnn_pack_u_stepwise and the scans of one library always agree) */
+#define SEQREC_ABI_VERSION 4
 
 enum { SEQREC_OK = 0, SEQREC_E_ARG = -1, SEQREC_E_SHAPE = -2, SEQREC_E_UNSUPPORTED = -3 };
+/* bits of a device status word (see Conventions): set with atomic OR by the kernels, never cleared by them */
+enum {
+    SEQREC_STATUS_BAD_NORM = 1,      /* seqrec_opt_apply: squared gradient norm negative, NaN or infinite -- update NOT applied */
+    SEQREC_STATUS_BAD_DIVISOR = 2,   /* seqrec_opt_apply: *grad_div not a finite number > 0            -- update NOT applied */
+    SEQREC_STATUS_BAD_SCALE = 4,     /* seqrec_opt_apply: clip scale 0 / not finite (a norm so large that clipnorm / norm
+                                        underflows): the step would be a silent no-op                  -- update NOT applied */
+    SEQREC_STATUS_BAD_INDEX = 8      /* seqrec_gather_rows_bounded: an index >= table_rows (read as a zero row) */
+};
 
 /* recurrent cell (Keras layer constructed at model.py:248-254,344-352; GRU = extension) */
 enum { SEQREC_CELL_SIMPLERNN = 0, SEQREC_CELL_LSTM = 1, SEQREC_CELL_GRU = 2 };
@@ -56,6 +89,11 @@ const char* seqrec_build_arch(void);
  *      Algorithmic HBM bytes: 8 * width per row (4 read + 4 written). */
 int seqrec_gather_rows(const float* table, const int32_t* ids, float* out, int64_t n, int width,
                        const float* row_scale, const float* bias, int accumulate, void* stream);
+/*      the same with the table's row count: an index >= table_rows reads nothing (zero row, like a negative one) and sets
+ *      SEQREC_STATUS_BAD_INDEX in *status (nullable).  For index lists that crossed PCIe or a collective (the row exchange
+ *      of distributed.py): a stale or corrupted index cannot pull arbitrary memory into a gradient. */
+int seqrec_gather_rows_bounded(const float* table, int64_t table_rows, const int32_t* ids, float* out, int64_t n, int width,
+                               const float* row_scale, const float* bias, int accumulate, uint32_t* status, void* stream);
 
 /* ---- dense GEMM on the fp32 MFMA path (exact fp32; v_mfma_f32_32x32x2_f32).
  *      C[M,N] (+)= opA(A)[M,K] . opB(B)[K,N] (+ bias[N]).  Replaces the BLAS calls Theano makes for
@@ -112,13 +150,21 @@ int seqrec_gemm_f32_grouped_slabs(int count, int a_kcontig, int b_kcontig, const
  *      3 = 128x128 (grouped form: 1 or 2); <= 0 restores the built-in choice.  Results never depend on it beyond
  *      the order of the split-K partial sums. */
 void seqrec_debug_gemm_tile(int tile, int grouped_tile);
-/*      diagnostics (tests): GRU scan form of seqrec_rnn_fwd_stepwise / _bwd_stepwise -- 1 cluster (one launch, in-kernel
- *      exchange between the column-slice workgroups of a row block), 0 step-wise (one launch per recurrent product),
- *      -1 the built-in choice (cluster whenever the call qualifies; SEQREC_SCAN_CLUSTER=0 disables it). */
+/*      diagnostics (tests ONLY; process-wide, not thread-safe): scan form of seqrec_rnn_fwd_stepwise / _bwd_stepwise --
+ *      1 cluster (one launch, in-kernel exchange between the column-slice workgroups of a row block), 0 step-wise (one
+ *      launch per recurrent product), -1 the built-in choice (cluster whenever the call qualifies; SEQREC_SCAN_CLUSTER=0
+ *      disables it).  seqrec_debug_cluster_spin_limit(polls > 0) shortens the bounded waits of the cluster kernels so that a
+ *      test can drive their failure path (0 restores the built-in 2^22 polls). */
 void seqrec_debug_scan_cluster(int mode);
-/*      every wait inside the cluster kernels is a BOUNDED spin; this returns how many ran out on `stream` since its first
- *      cluster scan (0 in a healthy run; synchronises the stream; -1 on a HIP error). */
+void seqrec_debug_cluster_spin_limit(int polls);
+/*      every wait inside the cluster kernels is a BOUNDED spin.  A wave whose wait runs out counts it, writes NaN into the
+ *      output element it owns (Hout / dPre of that step: nothing downstream looks plausible, and the gradient norm of the
+ *      step is not finite, which seqrec_opt_apply refuses) and leaves.  scan_errors returns the count on `stream` since
+ *      its first cluster scan or the last reset (0 in a healthy run; SYNCHRONISES the stream; -1 on a HIP error). */
 int seqrec_cluster_scan_errors(void* stream);
+int seqrec_cluster_scan_errors_reset(void* stream);
+/*      frees the library's per-stream state (Conventions: hidden state); synchronises the stream first */
+int seqrec_release_stream(void* stream);
 
 /* ---- recurrent scan over the ragged batch (Keras K.rnn under Masking).
  *      H must be 64, 128, 256 or 512 (callers zero-pad); H_real <= H are the live units.
@@ -143,12 +189,17 @@ int seqrec_rnn_bwd(int cell, int act, int H, int H_real, int T, int B, const int
                    const float* dHout, const float* Hout, const float* gates, const float* aux,
                    float* dPre, const float* upack, void* stream);
 
-/*      Step-wise form of the same scan (rnn_step.hip): one small whole-chip launch per recurrent
- *      GEMM (GRU: 2 per step; LSTM/SimpleRNN: 1 forward, pointwise + GEMM backward) instead of one
- *      persistent workgroup per 16 sessions -- shorter
- *      critical path when few long sessions dominate (MSNBC-shaped batches); same buffers and results.
+/*      Step-wise entry points of the same scan: two forms behind one signature, chosen per call.
+ *      CLUSTER form (rnn_cluster.hip, rnn_cluster2.hip; every cell, with or without rmask, T <= 159): ONE launch per
+ *      call; the 16 session rows of a row block belong to a group of H/16 resident workgroups that keep their slices of
+ *      the recurrent kernel in registers and exchange h (LSTM, SimpleRNN: one exchange per step; GRU: two) inside the
+ *      kernel.  Taken when all workgroups of a launch can be resident (occupancy query; larger batches go in slices).
+ *      STEP-WISE form (rnn_step.hip): one small whole-chip launch per recurrent GEMM (GRU: 2 per step; LSTM/SimpleRNN:
+ *      1 forward, pointwise + GEMM backward) -- for T > 159, SEQREC_SCAN_CLUSTER=0, the LSTM forward with rmask at
+ *      H = 512, and as the form the cluster kernels are tested against.  Same buffers; Hout / gates / aux agree BIT FOR
+ *      BIT between the forms, dPre to the last bits.
  *      upack: seqrec_rnn_upack_floats() floats written by seqrec_rnn_pack_u_stepwise.
- *      bwd workspace: 2 * N_tok * H floats.
+ *      bwd workspace: 2 * N_tok * H floats (step-wise form only).
  *      rmask (nullable): recurrent-dropout multipliers [G][B][H] for the SORTED session rows
  *      (Keras recurrent_dropout, model.py:346,351: one mask per gate, fixed over time); with it the
  *      GRU aux stash holds r*h_prev WITHOUT the mask. */
@@ -181,8 +232,10 @@ int seqrec_rnn_bwd_stepwise_parts(int cell, int act, int H, int H_real, int T, i
  *      use_graph != 0: the call's launch sequence is captured ONCE per distinct kernel sequence (cell, activation, H,
  *      direction, T) into a hipGraph (process-wide cache, <= 512 entries); every later call REWRITES the nodes'
  *      grids and arguments for its batch (hipGraphExecKernelNodeSetParams) and replays -- same kernels, same
- *      arguments as the eager form, ~0.6 us of host time per launch instead of ~3 us.  This cache is the only
- *      hidden state of the library; seqrec_graph_cache_clear() drops it. */
+ *      arguments as the eager form, ~0.6 us of host time per launch instead of ~3 us.  An executable is only
+ *      rewritten after the event recorded behind its previous launch has completed (ring of 4 per sequence and
+ *      stream), so calls may be enqueued back to back without host synchronisation.  seqrec_graph_cache_clear()
+ *      drops the cache (waits for launches still queued). */
 int seqrec_graph_cache_clear(void);
 
 /* ---- softmax + Theano categorical_crossentropy under the Keras token-mean mask
@@ -320,8 +373,12 @@ int seqrec_opt_sqnorm_ordered(int n_dense, const float* const* grads, const int6
 int seqrec_opt_apply(int n_dense, float* const* params, float* const* accums, const float* const* grads,
                      const int64_t* numel, const seqrec_rows_job* jobs_host, int n_jobs, const float* sq,
                      float clipnorm, float lr, float eps, float* scale_out, float* zero_next,
-                     const float* grad_div, void* stream);
-/*      grad_div (nullable DEVICE scalar): the gradients in memory are sums still to be divided by *grad_div -- the
+                     const float* grad_div, uint32_t* status, void* stream);
+/*      status (nullable device word): *sq not a finite number >= 0, *grad_div not a finite number > 0 or a clip scale that
+ *      is 0 / not finite set SEQREC_STATUS_BAD_NORM / _BAD_DIVISOR / _BAD_SCALE and the launch changes NOTHING (weights,
+ *      accumulators and gradient tables stay as they are; *scale_out still receives the scale): an overflowing or
+ *      uninitialised gradient value can neither poison the weights nor turn the step into a silent no-op (scale 0).
+ *      grad_div (nullable DEVICE scalar): the gradients in memory are sums still to be divided by *grad_div -- the
  *      global token count of a multi-GPU step, which only exists after the all-reduce; norm, clip scale and update
  *      then use g / *grad_div, so no step needs the count on the host.  *scale_out receives clip_scale / *grad_div. */
 

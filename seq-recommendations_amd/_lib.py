@@ -23,6 +23,11 @@ STREAM_DROP_OUT = 3
 STREAM_DROP_REC = 4
 
 ERRORS = {-1: "SEQREC_E_ARG", -2: "SEQREC_E_SHAPE", -3: "SEQREC_E_UNSUPPORTED"}
+# bits of a device status word (SEQREC_STATUS_* of include/seqrec_hip.h)
+STATUS_BITS = {1: "gradient norm not finite (SEQREC_STATUS_BAD_NORM): an overflowing, NaN or uninitialised gradient value -- update refused",
+               2: "gradient divisor / token count not a finite number > 0 (SEQREC_STATUS_BAD_DIVISOR) -- update refused",
+               4: "clip scale 0 or not finite (SEQREC_STATUS_BAD_SCALE): the step would have been a silent no-op -- update refused",
+               8: "row index outside its table (SEQREC_STATUS_BAD_INDEX): read as a zero row"}
 
 P = C.c_void_p
 I = C.c_int
@@ -31,13 +36,14 @@ F = C.c_float
 D = C.c_double
 U64 = C.c_uint64
 
-ABI_VERSION = 3          # SEQREC_ABI_VERSION of include/seqrec_hip.h this binding was written against
+ABI_VERSION = 4          # SEQREC_ABI_VERSION of include/seqrec_hip.h this binding was written against
 
 # name -> argtypes   (restype is int unless listed in _RESTYPES)
 _SIGS = {
     "seqrec_abi_version": [],
     "seqrec_build_arch": [],
     "seqrec_gather_rows": [P, P, P, L, I, P, P, I, P],
+    "seqrec_gather_rows_bounded": [P, L, P, P, L, I, P, P, I, P, P],
     "seqrec_gemm_f32": [I, I, L, L, L, P, L, P, L, P, L, P, I, I, P, P],
     "seqrec_gemm_f32_slabs": [I, I, L, L, L, P, L, P, L, I, P, P, P],
     "seqrec_gemm_f32_fused": [I, I, L, L, L, P, L, P, L, P, L, P, I, I, P, P, P],
@@ -47,6 +53,9 @@ _SIGS = {
     "seqrec_debug_gemm_tile": [I, I],
     "seqrec_debug_scan_cluster": [I],
     "seqrec_cluster_scan_errors": [P],
+    "seqrec_cluster_scan_errors_reset": [P],
+    "seqrec_debug_cluster_spin_limit": [I],
+    "seqrec_release_stream": [P],
     "seqrec_rnn_upack_floats": [I, I],
     "seqrec_rnn_pack_u": [I, I, P, P, P],
     "seqrec_rnn_fwd": [I, I, I, I, I, I, P, P, P, P, P, P, P],
@@ -69,7 +78,7 @@ _SIGS = {
     "seqrec_opt_sqnorm": [I, P, P, P, I, P, P, L, P, P],
     "seqrec_opt_sqnorm_slabs": [I, P, P, I, P, I, P, P, I, P, P, L, P, P],
     "seqrec_loss_reduce": [P, L, P, P],
-    "seqrec_opt_apply": [I, P, P, P, P, P, I, P, F, F, F, P, P, P, P],
+    "seqrec_opt_apply": [I, P, P, P, P, P, I, P, F, F, F, P, P, P, P, P],
     "seqrec_prior_grad": [P, P, L, C.c_float, P, P, P],
     "seqrec_pack_batch": [P, P, P, P, I, I, P, P, P, P],
     "seqrec_pack_batch_host": [P, P, P, P, I, I, P, P, P, P, P, P],
@@ -101,6 +110,7 @@ _SIGS = {
 _RESTYPES = {
     "seqrec_debug_gemm_tile": None,
     "seqrec_debug_scan_cluster": None,
+    "seqrec_debug_cluster_spin_limit": None,
     "seqrec_build_arch": C.c_char_p,
     "seqrec_gemm_workspace_floats": L,
     "seqrec_rnn_upack_floats": L,

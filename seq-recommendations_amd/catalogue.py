@@ -134,7 +134,9 @@ class SampledRNNModel:
             self._step += 1
             tot += l * float(len(sel))
             cnt += len(sel)
-        return float(tot.item()) / max(cnt, 1)
+        out = float(tot.item()) / max(cnt, 1)
+        eng.check_status()                 # the epoch's host sync: raise if a kernel reported a failure (Engine.check_status)
+        return out
 
     def fit_model(self, x_train, y_train=None, validation_data=None, n_epochs=10, batch_size=512, verbose=1, callbacks=None,
                   shuffle=True):

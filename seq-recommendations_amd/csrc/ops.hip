@@ -15,14 +15,20 @@ namespace {
 template <bool VEC4>
 __global__ void gather_rows_kernel(const float* __restrict__ table, const int* __restrict__ ids,
                                    float* __restrict__ out, long n, int width, const float* __restrict__ row_scale,
-                                   const float* __restrict__ bias, int accumulate) {
+                                   const float* __restrict__ bias, int accumulate, long table_rows, unsigned* __restrict__ status) {
+    // table_rows > 0: an id >= table_rows reads NOTHING (zero row) and is recorded in *status -- a stale or corrupted index
+    // then cannot pull arbitrary memory into a gradient (seqrec_gather_rows_bounded)
     const int per = VEC4 ? width / 4 : width;
     const long total = n * per;
     for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long)gridDim.x * blockDim.x) {
         const long i = c / per;
         const int q = (int)(c % per);
-        const int id = ids[i];
-        const float s = row_scale ? row_scale[i] : 1.f;
+        int id = ids[i];
+        if (table_rows > 0 && id >= table_rows) {
+            if (q == 0 && status) atomicOr(status, (unsigned)SEQREC_STATUS_BAD_INDEX);
+            id = -1;
+        }
+        const float s = (row_scale && id >= 0) ? row_scale[i] : 1.f;
         if (VEC4) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (id >= 0) v = reinterpret_cast<const float4*>(table + (long)id * width)[q];
@@ -613,16 +619,29 @@ __global__ void opt_sqnorm_partial_kernel(OptPlan pl, float* __restrict__ partia
     if (threadIdx.x == 0) partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 __global__ void opt_apply_kernel(OptPlan pl, const float* __restrict__ sq, float clipnorm, float lr, float eps,
-                                 float* __restrict__ scale_out, float* __restrict__ zero_next, const float* __restrict__ grad_div) {
+                                 float* __restrict__ scale_out, float* __restrict__ zero_next, const float* __restrict__ grad_div,
+                                 unsigned* __restrict__ status) {
     // grad_div (nullable device scalar): the gradients in memory are SUMS still to be divided by it (the global token
     // count of a multi-GPU step, known only after the all-reduce): norm and update use g / grad_div
-    const float inv_div = grad_div ? 1.f / grad_div[0] : 1.f;
-    const float nrm = sqrtf(sq[0]) * inv_div;
+    const float sqv = sq[0], gd = grad_div ? grad_div[0] : 1.f;
+    const float inv_div = 1.f / gd;
+    const float nrm = sqrtf(sqv) * inv_div;
     const float sc = ((clipnorm > 0.f && nrm >= clipnorm) ? clipnorm / nrm : 1.f) * inv_div;   // Keras clip_norm (== clip_scale_kernel)
+    // A squared norm that is not a finite number >= 0, a divisor that is not a finite number > 0 or a scale that is not a
+    // finite number > 0 can only come from a wrong input (an overflowing or uninitialised gradient value, a wild token
+    // count).  Applied, the first two poison every weight and the last is a SILENT no-op of the whole step (scale 0:
+    // gradients, accumulators and weights all unchanged).  Neither happens: the condition is recorded in *status
+    // (SEQREC_STATUS_*; the engine raises on it at its next host sync) and the launch leaves everything as it is.
+    unsigned bad = 0;
+    if (!(sqv >= 0.f) || !isfinite(sqv)) bad |= SEQREC_STATUS_BAD_NORM;
+    if (!(gd > 0.f) || !isfinite(gd)) bad |= SEQREC_STATUS_BAD_DIVISOR;
+    if (!bad && (!(sc > 0.f) || !isfinite(sc))) bad |= SEQREC_STATUS_BAD_SCALE;
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         scale_out[0] = sc;
         if (zero_next) zero_next[0] = 0.f;            // the OTHER norm slot: nobody reads or adds to it during this step
+        if (bad && status) atomicOr(status, bad);
     }
+    if (bad) return;                                   // uniform over the launch: every thread read the same three scalars
     if ((int)blockIdx.y < pl.nd) {
         float* p = pl.d.p[blockIdx.y];
         float* a = pl.d.a[blockIdx.y];
@@ -731,8 +750,8 @@ inline int grid_for(long work, int per_block, int cap = 4096) {
 extern "C" int seqrec_abi_version(void) { return SEQREC_ABI_VERSION; }
 extern "C" const char* seqrec_build_arch(void) { return "gfx950"; }
 
-extern "C" int seqrec_gather_rows(const float* table, const int32_t* ids, float* out, int64_t n, int width,
-                                  const float* row_scale, const float* bias, int accumulate, void* stream) {
+static int gather_rows_impl(const float* table, int64_t table_rows, const int32_t* ids, float* out, int64_t n, int width,
+                            const float* row_scale, const float* bias, int accumulate, uint32_t* status, void* stream) {
     if (n < 0 || width <= 0) return SEQREC_E_ARG;
     if (n == 0) return 0;
     if (!table || !ids || !out) return SEQREC_E_ARG;
@@ -740,10 +759,20 @@ extern "C" int seqrec_gather_rows(const float* table, const int32_t* ids, float*
                                            reinterpret_cast<uintptr_t>(bias)) & 15) == 0;
     const long total = (long)n * (vec ? width / 4 : width);
     const int blocks = grid_for(total, 256, 8192);
-    if (vec) hipLaunchKernelGGL(gather_rows_kernel<true>, dim3(blocks), dim3(256), 0, as_stream(stream), table, ids, out, (long)n, width, row_scale, bias, accumulate);
-    else hipLaunchKernelGGL(gather_rows_kernel<false>, dim3(blocks), dim3(256), 0, as_stream(stream), table, ids, out, (long)n, width, row_scale, bias, accumulate);
+    if (vec) hipLaunchKernelGGL(gather_rows_kernel<true>, dim3(blocks), dim3(256), 0, as_stream(stream), table, ids, out, (long)n, width, row_scale, bias, accumulate, (long)table_rows, status);
+    else hipLaunchKernelGGL(gather_rows_kernel<false>, dim3(blocks), dim3(256), 0, as_stream(stream), table, ids, out, (long)n, width, row_scale, bias, accumulate, (long)table_rows, status);
     SEQREC_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int seqrec_gather_rows(const float* table, const int32_t* ids, float* out, int64_t n, int width,
+                                  const float* row_scale, const float* bias, int accumulate, void* stream) {
+    return gather_rows_impl(table, 0, ids, out, n, width, row_scale, bias, accumulate, nullptr, stream);
+}
+extern "C" int seqrec_gather_rows_bounded(const float* table, int64_t table_rows, const int32_t* ids, float* out, int64_t n,
+                                          int width, const float* row_scale, const float* bias, int accumulate,
+                                          uint32_t* status, void* stream) {
+    if (table_rows <= 0) return SEQREC_E_ARG;
+    return gather_rows_impl(table, table_rows, ids, out, n, width, row_scale, bias, accumulate, status, stream);
 }
 
 extern "C" int seqrec_full_softmax_ce(float* logits, int64_t ld, const int32_t* tgt, int64_t n, int V,
@@ -1471,7 +1500,7 @@ extern "C" int seqrec_opt_sqnorm_ordered(int n_dense, const float* const* grads,
 extern "C" int seqrec_opt_apply(int n_dense, float* const* params, float* const* accums, const float* const* grads,
                                 const int64_t* numel, const seqrec_rows_job* jobs_host, int n_jobs, const float* sq,
                                 float clipnorm, float lr, float eps, float* scale_out, float* zero_next,
-                                const float* grad_div, void* stream) {
+                                const float* grad_div, uint32_t* status, void* stream) {
     OptPlan pl;
     long maxn;
     const int rc = fill_opt_plan(n_dense, params, accums, grads, numel, jobs_host, n_jobs, true, pl, maxn);
@@ -1479,7 +1508,7 @@ extern "C" int seqrec_opt_apply(int n_dense, float* const* params, float* const*
     if (!sq || !scale_out) return SEQREC_E_ARG;
     const unsigned gx = (unsigned)std::max<long>(n_dense ? 256 : 1, (maxn + 3) / 4);
     hipLaunchKernelGGL(opt_apply_kernel, dim3(gx, n_dense + n_jobs), dim3(256), 0, as_stream(stream), pl, sq, clipnorm, lr, eps,
-                       scale_out, zero_next, grad_div);
+                       scale_out, zero_next, grad_div, status);
     SEQREC_LAUNCH_CHECK();
     return 0;
 }

@@ -1,4 +1,4 @@
-// Cluster form of the GRU scan: ONE launch per scan call.  The 16 session rows of a row block are owned by a GROUP of
+// Cluster form of the recurrent scans (GRU here; LSTM and SimpleRNN in rnn_cluster2.hip): ONE launch per scan call.  The 16 session rows of a row block are owned by a GROUP of
 // H/16 workgroups, one per 16 hidden columns, that stay resident for the whole scan with their slices of the recurrent
 // kernel in registers and exchange h / r*h (forward) and d / [dpre_z|dpre_r] (BPTT) INSIDE the kernel:
 //   producer: stores its 16 x 16 slice, drains the stores (vmcnt 0), workgroup barrier, one flag store;
@@ -11,27 +11,18 @@
 // and a group switches to plain stores only if all its members report the same XCD.
 // Same arithmetic as the step-wise kernels, element for element (K split over the 4 waves, partial tiles summed in the same
 // order), so the two forms agree bit for bit.  Step offsets travel in the kernel arguments (T <= CL_TMAX).
-#include "common.h"
-#include "rnn_cluster.h"
+#include "rnn_cluster_dev.h"
 #include <cstdlib>
 #include <map>
 #include <mutex>
 
-namespace {
+using namespace seqrec_cluster;
 
-constexpr int CL_TMAX = 159;
-struct ClusterArgs {
-    int H_real, T, n_groups, g_base;
-    const float* XW; float* Hout; float* gates; float* aux;
-    const float* dHout; float* dPre;
-    const float* pk_a; const float* pk_b;      // packed B operands of the two products (rnn_step.hip layouts)
-    unsigned* flags;                           // [groups][64]: words 0..31 phase counters, 32..63 XCC ids
-    unsigned* error;                           // set when a bounded spin ran out
-    unsigned epoch;
-    // BPTT input gradient in parts (seqrec_dh_parts): dHout = slab 0, dh_ns slabs dh_stride floats apart, + dh_scale[q] * dh_add[dh_idx[q]]
-    int dh_ns; long dh_stride; const float* dh_add; const int* dh_idx; const float* dh_scale; long dh_ld;
-    int so[CL_TMAX + 1];
-};
+#ifdef SEQREC_CLUSTER_SPINS
+__device__ unsigned long long seqrec_cluster::g_cl_spins[8];
+#endif
+
+namespace {
 
 // Diagnostic build only (-DSEQREC_CLUSTER_STAMP, tools/cluster_stamps.py): workgroup (group 0, column block 1) sums the
 // s_memrealtime (100 MHz) spent between marked points of a step; no stamp exists in the product build.
@@ -45,91 +36,6 @@ __device__ unsigned long long g_cl_stamp[32];
 #define CS(i)
 #define CS_FLUSH(base_)
 #endif
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void st_f32(float* p, float v, bool wt) {          // wt: write-through (device scope)
-    if (wt) asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
-    else asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void st_u32(unsigned* p, unsigned v, bool wt) {
-    if (wt) asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
-    else asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ unsigned ld_u32_dev(const unsigned* p) {            // device-scope load (bypasses the CU's L1)
-    unsigned v;
-    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-// The A rows of a product, coalesced: a wave needs rows 0..15 x its K slice [w*K/4, +K/4) -- 16 pieces of K bytes.  In MFMA
-// operand order lane (row, q) reads K/16 consecutive floats of its row: every dwordx4 instruction then touches 16 rows x 4
-// separate 16-byte pieces (64 requests, 32 half-used lines; the stamped build: 0.55-0.67 us per row load).  Here each row's
-// slice is read by CONSECUTIVE lanes (full lines) straight into LDS by LDS-DMA (device scope), 16-byte chunk c of row m
-// landing at chunk c ^ (m mod chunks) (the swizzle is applied on the source address: an LDS-DMA image is lane-linear), and
-// the wave re-reads its own image in operand order, conflict-free.  Same values in the same registers as the direct form.
-template <int K> __device__ __forceinline__ void ld_rows_dma(float (&a)[K / 16], const float* base, long row_stride, int nact,
-                                                              int kslice0, float* lds_wave, int lane) {
-    constexpr int SL = K / 4;                      // floats of a row's slice (64 at K = 256)
-    constexpr int LPR = SL / 4;                    // 16-byte chunks per row slice = lanes per row: 16 at K = 256
-    constexpr int RPI = 64 / LPR;                  // rows per DMA instruction: 4 at K = 256
-    constexpr int NI = 16 / RPI;                   // DMA instructions: 4 at K = 256
-    static_assert(LPR <= 64 && LPR >= 4, "slice fits a wave instruction");
-    const int wl = __builtin_amdgcn_readfirstlane(0);
-    (void)wl;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int rl = RPI * i + lane / LPR;                       // image row
-        const int ch = (lane % LPR) ^ (rl % LPR);                  // source chunk that lands at position lane % LPR
-        const float* p = base + (long)min(rl, nact - 1) * row_stride + kslice0 + 4 * ch;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                         (__attribute__((address_space(3))) void*)(lds_wave + i * (RPI * SL)), 16, 0, 16 /* sc1 */);
-    }
-    const int m = lane & 15, q = lane >> 4;
-    const float* src = lds_wave + m * SL;
-#pragma unroll
-    for (int j = 0; j < K / 64; ++j) {
-        const int pos = (q * (K / 64) + j) ^ (m % LPR);
-        const float4 t = *reinterpret_cast<const float4*>(src + 4 * pos);
-        a[4 * j] = t.x; a[4 * j + 1] = t.y; a[4 * j + 2] = t.z; a[4 * j + 3] = t.w;
-    }
-}
-// (A scalar-load poll -- s_load_dwordx16 glc, so that the poll leaves the vector-memory counter alone -- was measured at
-// 2.6-3.0 us per wait against 0.35 us for the vector poll below: profiles/r02_v3_cluster_step_stamps.txt.)
-// producer side with NB younger inline-asm stores allowed to stay in flight (they were issued AFTER the exchange stores;
-// the counter is in order, so vmcnt(NB) says the exchange stores -- and everything older -- are done)
-template <int NB> __device__ __forceinline__ void cl_publish_n(unsigned* myflag, unsigned value, bool wt) {
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NB) : "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) st_u32(myflag, value, wt);
-}
-
-// producer side of an exchange: my stores are in L2 / memory, then the flag
-__device__ __forceinline__ void cl_publish(unsigned* myflag, unsigned value, bool wt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) st_u32(myflag, value, wt);
-}
-// consumer side: every member's counter has reached `target` (wrap-safe); false = the bounded spin ran out.  Every wave
-// polls for itself: no workgroup barrier between the flags and the wave's own row loads
-#ifdef SEQREC_CLUSTER_SPINS          // diagnostic build (tools/cluster_spins.py): [0] waits, [1 + min(polls - 1, 6)] histogram of polls per wait
-__device__ unsigned long long g_cl_spins[8];
-#endif
-template <int CB> __device__ __forceinline__ bool cl_wait_w(const unsigned* fl, unsigned target, unsigned* error) {
-    const int lane = threadIdx.x & 63;
-    int spins = 0;
-    while (true) {
-        const unsigned f = lane < CB ? ld_u32_dev(fl + lane) : target;
-#ifdef SEQREC_CLUSTER_SPINS
-        if (lane == 0 && __all((int)(f - target) >= 0)) { atomicAdd(&g_cl_spins[0], 1ull); atomicAdd(&g_cl_spins[1 + min(spins, 6)], 1ull); }
-#endif
-        if (__all((int)(f - target) >= 0)) return true;
-        if (++spins > (1 << 22)) { if (lane == 0) atomicAdd(error, 1u); return false; }
-    }
-}
-template <int CB> __device__ __forceinline__ bool cl_same_xcd(const unsigned* fl) {
-    const unsigned mine = ld_u32_dev(fl + 32);
-    bool same = true;
-    for (int i = 1; i < CB; ++i) same = same && (ld_u32_dev(fl + 32 + i) == mine);
-    return same;
-}
 
 // one or two 16x16 tile products with K split over the 4 waves (rnn_step.hip tile_16x16_reg, same order of sums)
 template <int K, int NT>
@@ -161,12 +67,16 @@ __device__ __forceinline__ void cl_tiles(const float (&a)[K / 16], const float4 
     out0 = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
     if (NT == 2) out1 = (red[1024 + tid] + red[1280 + tid]) + (red[1536 + tid] + red[1792 + tid]);
 }
+template <int N> __device__ __forceinline__ void mul_vec(float (&o)[N], const float (&a)[N], const float (&m)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) o[i] = a[i] * m[i];
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // forward: per step  [z|r] = hs(xw + h_prev.U_zr) -> r*h_prev (exchange 1) -> h~ = act(xw_h + (r*h_prev).U_h),
 //          h = z h_prev + (1-z) h~ (exchange 2).  Thread (row, col) keeps its h element in a register across steps.
 // ------------------------------------------------------------------------------------------------------------------
-template <int J, int ACT>
+template <int J, int ACT, bool RD>
 __global__ __launch_bounds__(256) void gru_cluster_fwd(ClusterArgs a) {
     constexpr int H = 64 * J, GH = 3 * H, CB = H / 16, NB = H / 64;
     const int L = blockIdx.x, x = L & 7, s = L >> 3, jj = s / CB, c = s - jj * CB;
@@ -189,9 +99,18 @@ __global__ __launch_bounds__(256) void gru_cluster_fwd(ClusterArgs a) {
             bh[i] = pb[((size_t)(c * 4 + w) * NB + i) * 64 + lane];
         }
     }
+    // recurrent dropout (Keras recurrent_dropout: one mask per gate and session, fixed over time): the lane's multipliers of
+    // its A elements stay in registers for the whole scan (rnn_step.hip mask_vec: same products)
+    [[maybe_unused]] float mz[RD ? H / 16 : 1], mr[RD ? H / 16 : 1], mh[RD ? H / 16 : 1];
+    if constexpr (RD) {
+        const int srow = min(r0 + (lane & 15), a.B - 1), koff = w * (H / 4) + (lane >> 4) * (H / 16);
+        ld_mask(mz, a.rmask, a.B, H, 0, srow, koff);
+        ld_mask(mr, a.rmask, a.B, H, 1, srow, koff);
+        ld_mask(mh, a.rmask, a.B, H, 2, srow, koff);
+    }
     unsigned* fl = a.flags + (size_t)gl * 64;
     const unsigned base = a.epoch;
-    if (tid == 0) st_u32(fl + 32 + c, (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xF) + 1u, true);
+    if (tid == 0) st_u32(fl + 32 + c, xcc_id() + 1u, true);
     bool wt = true;                                   // write-through exchange stores until the group is known to share an XCD
     float hprev = 0.f;
     CS_DECL;
@@ -213,14 +132,17 @@ __global__ __launch_bounds__(256) void gru_cluster_fwd(ClusterArgs a) {
         const float xz = n_xz, xr = n_xr, xh = n_xh;
         float accz = 0.f, accr = 0.f, acch = 0.f, dummy;
         float av[H / 16];
+        [[maybe_unused]] float am[RD ? H / 16 : 1];
         CS(0);
         if (t > 0) {
-            if (!cl_wait_w<CB>(fl, base + 2u * t, a.error)) return;
+            // a wait that runs out: the step's output is poisoned (nothing downstream may look plausible) and the wave leaves
+            if (!cl_wait_w<CB>(fl, base + 2u * t, a.error, a.spin_limit)) { if (ok) a.Hout[q * H + col] = __builtin_nanf(""); return; }
             CS(1);
             if (t == 1) wt = !cl_same_xcd<CB>(fl);
             ld_rows_dma<H>(av, a.Hout + ((long)a.so[t - 1] + r0) * H, H, nact, w * (H / 4), stage + w * (16 * H / 4), lane);
             CS(2);
-            cl_tiles<H, 1>(av, br, br, red, tid, accr, dummy);        // r first: r * h_prev is what the others wait for
+            if constexpr (RD) { mul_vec(am, av, mr); cl_tiles<H, 1>(am, br, br, red, tid, accr, dummy); }
+            else cl_tiles<H, 1>(av, br, br, red, tid, accr, dummy);        // r first: r * h_prev is what the others wait for
             CS(3);
         }
         const float r = hard_sigmoid(accr + xr);
@@ -228,17 +150,19 @@ __global__ __launch_bounds__(256) void gru_cluster_fwd(ClusterArgs a) {
         if (t > 0) {
             cl_publish_n<0>(fl + c, base + 2u * t + 1u, wt);
             CS(4);
-            cl_tiles<H, 1>(av, bz, bz, red, tid, accz, dummy);        // z under the exchange (only the h update needs it)
+            if constexpr (RD) { mul_vec(am, av, mz); cl_tiles<H, 1>(am, bz, bz, red, tid, accz, dummy); }
+            else cl_tiles<H, 1>(av, bz, bz, red, tid, accz, dummy);        // z under the exchange (only the h update needs it)
             CS(5);
         }
         const float z = hard_sigmoid(accz + xz);
         if (t > 0) {
-            if (!cl_wait_w<CB>(fl, base + 2u * t + 1u, a.error)) return;
+            if (!cl_wait_w<CB>(fl, base + 2u * t + 1u, a.error, a.spin_limit)) { if (ok) a.Hout[q * H + col] = __builtin_nanf(""); return; }
             CS(6);
             ld_rows_dma<H>(av, a.aux + ((long)p0 + r0) * H, H, nact, w * (H / 4), stage + w * (16 * H / 4), lane);
             CS(7);
             __syncthreads();                                          // red: slower waves may still read the z product
-            cl_tiles<H, 1>(av, bh, bh, red, tid, acch, dummy);
+            if constexpr (RD) { mul_vec(am, av, mh); cl_tiles<H, 1>(am, bh, bh, red, tid, acch, dummy); }
+            else cl_tiles<H, 1>(av, bh, bh, red, tid, acch, dummy);
             CS(8);
         }
         const float hh = act_fwd<ACT>(acch + xh);
@@ -269,7 +193,7 @@ __global__ __launch_bounds__(256) void gru_cluster_fwd(ClusterArgs a) {
 //       dh_prev = dh z + drh r + [dpre_z|dpre_r].U_zr^T, carried to step t-1 in a register of thread (row, col).
 // Step 0 has no recurrent product and no exchange (h_prev = 0).
 // ------------------------------------------------------------------------------------------------------------------
-template <int J, int ACT>
+template <int J, int ACT, bool RD>
 __global__ __launch_bounds__(256) void gru_cluster_bwd(ClusterArgs a) {
     constexpr int H = 64 * J, GH = 3 * H, CB = H / 16, NB = H / 64;
     const int L = blockIdx.x, x = L & 7, s = L >> 3, jj = s / CB, c = s - jj * CB;
@@ -281,18 +205,25 @@ __global__ __launch_bounds__(256) void gru_cluster_bwd(ClusterArgs a) {
     float* stage = smem + 1024;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int row = tid >> 4, col = 16 * c + (tid & 15);
-    float4 bh[NB], bzr[2 * NB];
+    float4 bh[NB], bzr[1][2 * NB];
     {
         const float4* pa = reinterpret_cast<const float4*>(a.pk_a);      // U_h^T, K = H
         const float4* pb = reinterpret_cast<const float4*>(a.pk_b);      // [U_z U_r]^T, K = 2H
 #pragma unroll
         for (int i = 0; i < NB; ++i) bh[i] = pa[((size_t)(c * 4 + w) * NB + i) * 64 + lane];
 #pragma unroll
-        for (int i = 0; i < 2 * NB; ++i) bzr[i] = pb[((size_t)(c * 4 + w) * (2 * NB) + i) * 64 + lane];
+        for (int i = 0; i < 2 * NB; ++i) bzr[0][i] = pb[((size_t)(c * 4 + w) * (2 * NB) + i) * 64 + lane];
+    }
+    // recurrent dropout: the products come back through the masks of the OUTPUT element (row, col) -- d(r h m_h) -> d(r h),
+    // and the [z z r r] wave halves of the K = 2H product each through their gate's mask (rnn_step.hip gru_step_bwd)
+    [[maybe_unused]] float m_z = 1.f, m_r = 1.f, m_h = 1.f;
+    if constexpr (RD) {
+        const long srow = min(r0 + row, a.B - 1);
+        m_z = a.rmask[(0L * a.B + srow) * H + col]; m_r = a.rmask[(1L * a.B + srow) * H + col]; m_h = a.rmask[(2L * a.B + srow) * H + col];
     }
     unsigned* fl = a.flags + (size_t)gl * 64;
     unsigned count = a.epoch;                         // this workgroup's published exchanges so far (same sequence in every member)
-    if (tid == 0) st_u32(fl + 32 + c, (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xF) + 1u, true);
+    if (tid == 0) st_u32(fl + 32 + c, xcc_id() + 1u, true);
     bool wt = true, first_x = true;
     int tg = 0;                                       // steps this row block is alive
     while (tg < a.T && a.so[tg + 1] - a.so[tg] > r0) ++tg;
@@ -335,7 +266,8 @@ __global__ __launch_bounds__(256) void gru_cluster_bwd(ClusterArgs a) {
         if (ok) st_f32(a.dPre + q * GH + 2 * H + col, d, wt);
         cl_publish_n<0>(fl + c, ++count, wt);
         prefetch(t - 1);                              // behind the flag store: nothing on the exchange path is issued after it
-        if (!cl_wait_w<CB>(fl, count, a.error)) return;
+        // a wait that runs out: this step's gradient is poisoned (the norm then is not finite and the update refuses it)
+        if (!cl_wait_w<CB>(fl, count, a.error, a.spin_limit)) { if (ok) a.dPre[q * GH + col] = __builtin_nanf(""); return; }
         if (first_x) { wt = !cl_same_xcd<CB>(fl); first_x = false; }
         float acc = 0.f, dummy;
         {
@@ -343,29 +275,41 @@ __global__ __launch_bounds__(256) void gru_cluster_bwd(ClusterArgs a) {
             ld_rows_dma<H>(av, a.dPre + ((long)p0 + r0) * GH + 2 * H, GH, nact, w * (H / 4), stage + w * (16 * 2 * H / 4), lane);
             cl_tiles<H, 1>(av, bh, bh, red, tid, acc, dummy);
         }
+        if constexpr (RD) acc *= m_h;
         const float dcar = dh * z + acc * r;
         if (ok) {
             st_f32(a.dPre + q * GH + col, dh * (h0 - hh) * hard_sigmoid_grad(z), wt);
             st_f32(a.dPre + q * GH + H + col, acc * h0 * hard_sigmoid_grad(r), wt);
         }
         cl_publish_n<0>(fl + c, ++count, wt);
-        if (!cl_wait_w<CB>(fl, count, a.error)) return;
-        float acc2 = 0.f;
+        if (!cl_wait_w<CB>(fl, count, a.error, a.spin_limit)) { if (ok) a.dPre[q * GH + col] = __builtin_nanf(""); return; }
+        float acc2[1] = {0.f}, acc2b[1] = {0.f};
         {
             float av2[2 * H / 16];
             ld_rows_dma<2 * H>(av2, a.dPre + ((long)p0 + r0) * GH, GH, nact, w * (2 * H / 4), stage + w * (16 * 2 * H / 4), lane);
-            cl_tiles<2 * H, 1>(av2, bzr, bzr, red, tid, acc2, dummy);
+            cl_tiles_n<2 * H, 1, RD>(av2, bzr, red, tid, acc2, acc2b);
         }
-        carry = dcar + acc2;
+        if constexpr (RD) carry = dcar + (acc2[0] * m_z + acc2b[0] * m_r);
+        else carry = dcar + acc2[0];
     }
 }
 
-// per-stream flag buffers + epochs
-struct FlagBuf { unsigned* flags; unsigned* error; unsigned epoch; };
+}  // namespace
+
+// ---- host side shared by every cluster scan ------------------------------------------------------------------------
+namespace seqrec_cluster {
+namespace {
 std::map<hipStream_t, FlagBuf> g_flagbufs;
 std::mutex g_flag_mu;
-constexpr int CL_MAX_GROUPS = 64;
+int g_cluster_override = -1;                  // seqrec_debug_scan_cluster(): tests compare the two forms in one process
+int g_spin_override = 0;                      // seqrec_debug_cluster_spin_limit(): tests force a timeout
+std::map<const void*, int> g_wg_per_cu;       // kernel -> resident workgroups per CU (occupancy query, once per kernel)
+int g_cus = 0;
+}  // namespace
 
+// Hidden state of the library, part 1 of 2 (the other is the launch-graph cache of rnn_step.hip): 16.25 KB of exchange
+// flags per stream, allocated on the stream's first cluster scan, epoch-numbered so that calls need no reset, freed by
+// seqrec_release_stream.
 int get_flagbuf(hipStream_t st, int T, FlagBuf& out) {
     std::lock_guard<std::mutex> lk(g_flag_mu);
     auto it = g_flagbufs.find(st);
@@ -390,29 +334,61 @@ int get_flagbuf(hipStream_t st, int T, FlagBuf& out) {
     return 0;
 }
 
-int g_cluster_override = -1;                  // seqrec_debug_scan_cluster(): tests compare the two forms in one process
 bool cluster_enabled() {
     static const bool on = !(getenv("SEQREC_SCAN_CLUSTER") && atoi(getenv("SEQREC_SCAN_CLUSTER")) == 0);      // A/B switch
     return g_cluster_override >= 0 ? g_cluster_override != 0 : on;
 }
+int cluster_spin_limit() { return g_spin_override > 0 ? g_spin_override : CL_SPIN_LIMIT; }
 
-template <int ACT> const void* fwd_kernel(int J) {
-    switch (J) {
-        case 1: return reinterpret_cast<const void*>(gru_cluster_fwd<1, ACT>);
-        case 2: return reinterpret_cast<const void*>(gru_cluster_fwd<2, ACT>);
-        case 4: return reinterpret_cast<const void*>(gru_cluster_fwd<4, ACT>);
-        case 8: return reinterpret_cast<const void*>(gru_cluster_fwd<8, ACT>);
+// The in-kernel waits need every workgroup of a launch resident at once.  Groups are dealt to the XCDs round-robin
+// (group g -> XCD g mod 8, all its CB column-block workgroups with it), so the bound is per XCD: what the occupancy
+// query says one CU holds of this kernel x the CUs of an XCD, in whole groups.  0 = not even one group per XCD fits.
+// (Other processes or streams on the same GPU can still take the CUs away: the waits are bounded and report.)
+int cluster_group_cap(const void* kernel, int CB) {
+    std::lock_guard<std::mutex> lk(g_flag_mu);
+    if (g_cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        g_cus = n;
     }
-    return nullptr;
+    auto it = g_wg_per_cu.find(kernel);
+    if (it == g_wg_per_cu.end()) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, 0) != hipSuccess || nb < 0) nb = 0;
+        it = g_wg_per_cu.emplace(kernel, nb).first;
+    }
+    const int per_xcd = (it->second * (g_cus / 8)) / CB;           // whole groups one XCD can hold
+    int cap = 8 * per_xcd;
+    if (cap > CL_MAX_GROUPS) cap = CL_MAX_GROUPS;
+    return cap;
 }
 
-}  // namespace
+int launch_sliced(const void* fn, ClusterArgs& a, int CB, int G, int T, hipStream_t st) {
+    const int gcap = cluster_group_cap(fn, CB);
+    if (gcap < 1) return SEQREC_E_UNSUPPORTED;
+    a.spin_limit = cluster_spin_limit();
+    for (int g0 = 0; g0 < G; g0 += gcap) {
+        FlagBuf fb;
+        const int rc = get_flagbuf(st, T, fb);
+        if (rc) return rc;
+        a.flags = fb.flags; a.error = fb.error; a.epoch = fb.epoch;
+        a.g_base = g0; a.n_groups = G - g0 < gcap ? G - g0 : gcap;
+        const unsigned grid = 8u * CB * ((a.n_groups + 7) / 8);
+        void* argv[1] = {&a};
+        const hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(256), argv, 0, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+}  // namespace seqrec_cluster
 
-extern "C" void seqrec_debug_scan_cluster(int mode) { g_cluster_override = mode; }
+extern "C" void seqrec_debug_scan_cluster(int mode) { seqrec_cluster::g_cluster_override = mode; }
+extern "C" void seqrec_debug_cluster_spin_limit(int polls) { seqrec_cluster::g_spin_override = polls; }
 #ifdef SEQREC_CLUSTER_SPINS
 extern "C" void seqrec_debug_cluster_spins(unsigned long long* out, int reset) {
-    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cl_spins), z, sizeof(z)); return; }
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cl_spins), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(seqrec_cluster::g_cl_spins), z, sizeof(z)); return; }
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(seqrec_cluster::g_cl_spins), sizeof(unsigned long long) * 8);
 }
 #endif
 #ifdef SEQREC_CLUSTER_STAMP
@@ -423,6 +399,7 @@ extern "C" void seqrec_debug_cluster_stamps(unsigned long long* out) {
 
 // Bounded spins that ran out since the stream's first cluster scan (0 in a healthy run): synchronises the stream.
 extern "C" int seqrec_cluster_scan_errors(void* stream) {
+    using namespace seqrec_cluster;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     unsigned* dev = nullptr;
     {
@@ -436,83 +413,95 @@ extern "C" int seqrec_cluster_scan_errors(void* stream) {
     if (hipMemcpy(&h, dev, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return (int)(h > 0x7FFFFFFFu ? 0x7FFFFFFFu : h);
 }
-
-bool seqrec_cluster_gru_fwd(int act, int H, int H_real, int T, const int32_t* soh, const float* XW, float* Hout, float* gates,
-                            float* aux, const float* upack, hipStream_t st, int* rc) {
-    if (!cluster_enabled() || T > CL_TMAX || T < 1) return false;
-    const int J = H / 64, CB = H / 16;
-    const void* fn = act == 0 ? fwd_kernel<0>(J) : act == 1 ? fwd_kernel<1>(J) : fwd_kernel<2>(J);
-    if (!fn) return false;
-    const int B0 = soh[1] - soh[0];
-    if (B0 <= 0) { *rc = 0; return true; }
-    const int G = (B0 + 15) / 16;
-    // residency: every workgroup of a launch must be able to be resident at once (2 per CU); larger batches go in slices of
-    // row blocks (independent chains) on the same stream
-    int gcap = (512 / CB) & ~7;
-    if (gcap < 8) gcap = 8;
-    if (gcap > CL_MAX_GROUPS) gcap = CL_MAX_GROUPS;
-    ClusterArgs a = {};
-    a.H_real = H_real; a.T = T; a.XW = XW; a.Hout = Hout; a.gates = gates; a.aux = aux;
-    a.pk_a = upack; a.pk_b = upack + 2l * H * H;
-    for (int t = 0; t <= T; ++t) a.so[t] = soh[t];
-    for (int g0 = 0; g0 < G; g0 += gcap) {
-        FlagBuf fb;
-        if ((*rc = get_flagbuf(st, T, fb))) return true;
-        a.flags = fb.flags; a.error = fb.error; a.epoch = fb.epoch;
-        a.g_base = g0; a.n_groups = G - g0 < gcap ? G - g0 : gcap;
-        const unsigned grid = 8u * CB * ((a.n_groups + 7) / 8);
-        void* argv[1] = {&a};
-        const hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(256), argv, 0, st);
-        if (e != hipSuccess) { *rc = (int)e; return true; }
-    }
-    *rc = 0;
-    return true;
+// clears the counter (after the caller has reported it)
+extern "C" int seqrec_cluster_scan_errors_reset(void* stream) {
+    using namespace seqrec_cluster;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    std::lock_guard<std::mutex> lk(g_flag_mu);
+    auto it = g_flagbufs.find(st);
+    if (it == g_flagbufs.end()) return 0;
+    return (int)hipMemsetAsync(it->second.error, 0, sizeof(unsigned), st);
+}
+void seqrec_cluster_release_stream(hipStream_t st) {
+    using namespace seqrec_cluster;
+    std::lock_guard<std::mutex> lk(g_flag_mu);
+    auto it = g_flagbufs.find(st);
+    if (it == g_flagbufs.end()) return;
+    (void)hipFree(it->second.flags);
+    g_flagbufs.erase(it);
 }
 
+// ---- GRU dispatch ------------------------------------------------------------------------------------------------------
 namespace {
-template <int ACT> const void* bwd_kernel(int J) {
+template <int ACT, bool RD> const void* gru_fwd_kernel(int J) {
     switch (J) {
-        case 1: return reinterpret_cast<const void*>(gru_cluster_bwd<1, ACT>);
-        case 2: return reinterpret_cast<const void*>(gru_cluster_bwd<2, ACT>);
-        case 4: return reinterpret_cast<const void*>(gru_cluster_bwd<4, ACT>);
-        case 8: return reinterpret_cast<const void*>(gru_cluster_bwd<8, ACT>);
+        case 1: return reinterpret_cast<const void*>(gru_cluster_fwd<1, ACT, RD>);
+        case 2: return reinterpret_cast<const void*>(gru_cluster_fwd<2, ACT, RD>);
+        case 4: return reinterpret_cast<const void*>(gru_cluster_fwd<4, ACT, RD>);
+        case 8: return reinterpret_cast<const void*>(gru_cluster_fwd<8, ACT, RD>);
+    }
+    return nullptr;
+}
+template <int ACT, bool RD> const void* gru_bwd_kernel(int J) {
+    switch (J) {
+        case 1: return reinterpret_cast<const void*>(gru_cluster_bwd<1, ACT, RD>);
+        case 2: return reinterpret_cast<const void*>(gru_cluster_bwd<2, ACT, RD>);
+        case 4: return reinterpret_cast<const void*>(gru_cluster_bwd<4, ACT, RD>);
+        case 8: return reinterpret_cast<const void*>(gru_cluster_bwd<8, ACT, RD>);
     }
     return nullptr;
 }
 }  // namespace
 
-bool seqrec_cluster_gru_bwd(int act, int H, int H_real, int T, const int32_t* soh, const float* dHout, const float* Hout,
-                            const float* gates, const float* aux, float* dPre, const float* upack, hipStream_t st, int* rc,
-                            const seqrec_dh_parts* parts) {
-    (void)aux;
+bool seqrec_cluster_other_fwd(int cell, int act, int H, int H_real, int T, int B, const int32_t* soh, const float* XW, float* Hout,
+                              float* gates, float* aux, const float* upack, const float* rmask, hipStream_t st, int* rc);
+bool seqrec_cluster_other_bwd(int cell, int act, int H, int H_real, int T, int B, const int32_t* soh, const float* dHout,
+                              const float* Hout, const float* gates, const float* aux, float* dPre, const float* upack,
+                              const float* rmask, hipStream_t st, int* rc);
+
+bool seqrec_cluster_fwd(int cell, int act, int H, int H_real, int T, int B, const int32_t* soh, const float* XW, float* Hout,
+                        float* gates, float* aux, const float* upack, const float* rmask, hipStream_t st, int* rc) {
+    using namespace seqrec_cluster;
     if (!cluster_enabled() || T > CL_TMAX || T < 1) return false;
+    if (cell != SEQREC_CELL_GRU) return seqrec_cluster_other_fwd(cell, act, H, H_real, T, B, soh, XW, Hout, gates, aux, upack, rmask, st, rc);
     const int J = H / 64, CB = H / 16;
-    const void* fn = act == 0 ? bwd_kernel<0>(J) : act == 1 ? bwd_kernel<1>(J) : bwd_kernel<2>(J);
-    if (!fn) return false;
+    const void* fn = rmask ? (act == 0 ? gru_fwd_kernel<0, true>(J) : act == 1 ? gru_fwd_kernel<1, true>(J) : gru_fwd_kernel<2, true>(J))
+                           : (act == 0 ? gru_fwd_kernel<0, false>(J) : act == 1 ? gru_fwd_kernel<1, false>(J) : gru_fwd_kernel<2, false>(J));
+    if (!fn || cluster_group_cap(fn, CB) < 1) return false;
     const int B0 = soh[1] - soh[0];
     if (B0 <= 0) { *rc = 0; return true; }
-    const int G = (B0 + 15) / 16;
-    int gcap = (512 / CB) & ~7;
-    if (gcap < 8) gcap = 8;
-    if (gcap > CL_MAX_GROUPS) gcap = CL_MAX_GROUPS;
+    ClusterArgs a = {};
+    a.H_real = H_real; a.T = T; a.XW = XW; a.Hout = Hout; a.gates = gates; a.aux = aux; a.rmask = rmask; a.B = B;
+    a.pk_a = upack; a.pk_b = upack + 2l * H * H;
+    for (int t = 0; t <= T; ++t) a.so[t] = soh[t];
+    *rc = launch_sliced(fn, a, CB, (B0 + 15) / 16, T, st);
+    return true;
+}
+
+bool seqrec_cluster_bwd(int cell, int act, int H, int H_real, int T, int B, const int32_t* soh, const float* dHout, const float* Hout,
+                        const float* gates, const float* aux, float* dPre, const float* upack, const float* rmask, hipStream_t st,
+                        int* rc, const seqrec_dh_parts* parts) {
+    using namespace seqrec_cluster;
+    if (!cluster_enabled() || T > CL_TMAX || T < 1) return false;
+    if (cell != SEQREC_CELL_GRU) {
+        if (parts) return false;
+        return seqrec_cluster_other_bwd(cell, act, H, H_real, T, B, soh, dHout, Hout, gates, aux, dPre, upack, rmask, st, rc);
+    }
+    const int J = H / 64, CB = H / 16;
+    const void* fn = rmask ? (act == 0 ? gru_bwd_kernel<0, true>(J) : act == 1 ? gru_bwd_kernel<1, true>(J) : gru_bwd_kernel<2, true>(J))
+                           : (act == 0 ? gru_bwd_kernel<0, false>(J) : act == 1 ? gru_bwd_kernel<1, false>(J) : gru_bwd_kernel<2, false>(J));
+    if (!fn || cluster_group_cap(fn, CB) < 1) return false;
+    const int B0 = soh[1] - soh[0];
+    if (B0 <= 0) { *rc = 0; return true; }
     ClusterArgs a = {};
     a.H_real = H_real; a.T = T; a.dHout = dHout; a.Hout = const_cast<float*>(Hout); a.gates = const_cast<float*>(gates); a.dPre = dPre;
+    a.aux = const_cast<float*>(aux); a.rmask = rmask; a.B = B;
     if (parts) {
         a.dHout = parts->slabs; a.dh_ns = parts->n_slabs; a.dh_stride = (long)parts->slab_stride;
         a.dh_add = parts->add_table; a.dh_idx = parts->add_index; a.dh_scale = parts->add_scale; a.dh_ld = (long)parts->add_ld;
     }
     a.pk_a = upack + 3l * H * H; a.pk_b = upack + 4l * H * H;
     for (int t = 0; t <= T; ++t) a.so[t] = soh[t];
-    for (int g0 = 0; g0 < G; g0 += gcap) {
-        FlagBuf fb;
-        if ((*rc = get_flagbuf(st, T, fb))) return true;
-        a.flags = fb.flags; a.error = fb.error; a.epoch = fb.epoch;
-        a.g_base = g0; a.n_groups = G - g0 < gcap ? G - g0 : gcap;
-        const unsigned grid = 8u * CB * ((a.n_groups + 7) / 8);
-        void* argv[1] = {&a};
-        const hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(256), argv, 0, st);
-        if (e != hipSuccess) { *rc = (int)e; return true; }
-    }
-    *rc = 0;
+    *rc = launch_sliced(fn, a, CB, (B0 + 15) / 16, T, st);
     return true;
 }

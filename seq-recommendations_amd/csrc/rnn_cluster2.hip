@@ -1,0 +1,420 @@
+// Cluster form of the LSTM and SimpleRNN scans -- the only cells the reference builds (model.py:344-352), with its
+// recurrent_dropout (model.py:346,351).  Protocol, placement and residency rules: rnn_cluster.hip.  Both cells need ONE
+// in-kernel exchange per time step each way:
+//   forward   h_{t-1} (all four LSTM gates read it); thread (row, col) keeps c_t / nothing else across steps
+//   BPTT      the step's pre-activation gradients dPre_t [16 x G H] (they are the kernel's output anyway);
+//             thread (row, col) carries dh and dc to step t-1 in registers
+// Arithmetic = the step-wise kernels of rnn_step.hip element for element (K split over the 4 waves in the same
+// K-permuted order, partial tiles summed in the same order, the cell formulas from ONE shared definition), so the two
+// forms agree bit for bit in Hout / gates / c and to the last bits in dPre.
+// LSTM BPTT: K = 4H (2048 at H = 512), the wave's slice of a dPre row is H floats -- too long for registers next to the
+// wave's slice of U^T (128 VGPRs at H = 512).  It is streamed in PIECES of 32 floats per lane through a two-deep LDS-DMA
+// ring (8 KB per wave and piece): piece p + 1 is in flight while the 32 MFMAs of piece p run.
+#include "rnn_cluster_dev.h"
+
+using namespace seqrec_cluster;
+
+namespace {
+
+#define CL_PROLOGUE(CBV)                                                                              \
+    const int L = blockIdx.x, x = L & 7, s = L >> 3, jj = s / (CBV), c = s - jj * (CBV);              \
+    const int gl = x + 8 * jj;                                                                        \
+    const int r0 = 16 * (a.g_base + gl);                                                              \
+    if (gl >= a.n_groups || r0 >= a.so[1] - a.so[0]) return;                                          \
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;                                       \
+    const int row = tid >> 4, col = 16 * c + (tid & 15);                                              \
+    unsigned* fl = a.flags + (size_t)gl * 64;                                                         \
+    if (tid == 0) st_u32(fl + 32 + c, xcc_id() + 1u, true);                                          \
+    bool wt = true /* write-through exchange stores until the group is known to share an XCD */
+
+template <int N> __device__ __forceinline__ void mul_vec(float (&o)[N], const float (&a)[N], const float (&m)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) o[i] = a[i] * m[i];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// SimpleRNN forward: h_t = act(xw_t + h_{t-1} . U)      (rnn_step.hip srnn_step_fwd)
+// ------------------------------------------------------------------------------------------------------------------
+template <int J, int ACT, bool RD>
+__global__ __launch_bounds__(256) void srnn_cluster_fwd(ClusterArgs a) {
+    constexpr int H = 64 * J, CB = H / 16, NB = H / 64;
+    CL_PROLOGUE(CB);
+    __shared__ float smem[1024 + 4 * 16 * (H / 4)];
+    float* red = smem;
+    float* stage = smem + 1024 + w * (16 * H / 4);
+    float4 b[1][NB];
+    {
+        const float4* pa = reinterpret_cast<const float4*>(a.pk_a);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) b[0][i] = pa[((size_t)(c * 4 + w) * NB + i) * 64 + lane];
+    }
+    [[maybe_unused]] float mk[RD ? H / 16 : 1];
+    if constexpr (RD) ld_mask(mk, a.rmask, a.B, H, 0, min(r0 + (lane & 15), a.B - 1), w * (H / 4) + (lane >> 4) * (H / 16));
+    const unsigned base = a.epoch;
+    float n_x = 0.f;
+    auto prefetch_xw = [&](int t) {
+        const int p0 = a.so[t], nact = min(16, a.so[t + 1] - p0 - r0);
+        if (row < nact) n_x = a.XW[((long)p0 + r0 + row) * H + col];
+    };
+    prefetch_xw(0);
+    for (int t = 0; t < a.T; ++t) {
+        const int p0 = a.so[t], bt = a.so[t + 1] - p0;
+        if (bt <= r0) break;
+        const int nact = min(16, bt - r0);
+        const bool ok = row < nact;
+        const long q = (long)p0 + r0 + row;
+        const bool more = t + 1 < a.T && a.so[t + 2] - a.so[t + 1] > r0;
+        const float xw = n_x;
+        float acc[1] = {0.f}, unused[1];
+        if (t > 0) {
+            if (!cl_wait_w<CB>(fl, base + (unsigned)t, a.error, a.spin_limit)) { if (ok) a.Hout[q * H + col] = __builtin_nanf(""); return; }
+            if (t == 1) wt = !cl_same_xcd<CB>(fl);
+            float av[H / 16];
+            ld_rows_dma<H>(av, a.Hout + ((long)a.so[t - 1] + r0) * H, H, nact, w * (H / 4), stage, lane);
+            if constexpr (RD) mul_vec(av, av, mk);
+            cl_tiles_n<H, 1>(av, b, red, tid, acc, unused);
+        }
+        float y = act_fwd<ACT>(acc[0] + xw);
+        if (col >= a.H_real) y = 0.f;
+        if (ok) st_f32(a.Hout + q * H + col, y, wt);
+        if (more) {
+            cl_publish_n<0>(fl + c, base + (unsigned)t + 1u, wt);     // (its barrier also orders this step's reads of `red` before the next writes)
+            prefetch_xw(t + 1);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// SimpleRNN BPTT: dPre_t = dh act'(h_t);  dh_{t-1} += dPre_t . U^T        (pointwise_bwd_step + gemm_bwd_step<H>)
+// ------------------------------------------------------------------------------------------------------------------
+template <int J, int ACT, bool RD>
+__global__ __launch_bounds__(256) void srnn_cluster_bwd(ClusterArgs a) {
+    constexpr int H = 64 * J, CB = H / 16, NB = H / 64;
+    CL_PROLOGUE(CB);
+    __shared__ float smem[1024 + 4 * 16 * (H / 4)];
+    float* red = smem;
+    float* stage = smem + 1024 + w * (16 * H / 4);
+    float4 b[1][NB];
+    {
+        const float4* pb = reinterpret_cast<const float4*>(a.pk_b);      // U^T, K = H
+#pragma unroll
+        for (int i = 0; i < NB; ++i) b[0][i] = pb[((size_t)(c * 4 + w) * NB + i) * 64 + lane];
+    }
+    [[maybe_unused]] float m_o = 1.f;
+    if constexpr (RD) m_o = a.rmask[(long)min(r0 + row, a.B - 1) * H + col];
+    unsigned count = a.epoch;
+    bool first_x = true;
+    int tg = 0;
+    while (tg < a.T && a.so[tg + 1] - a.so[tg] > r0) ++tg;
+    float carry = 0.f, n_dh = 0.f, n_h = 0.f;
+    auto prefetch = [&](int t) {
+        const int p0 = a.so[t], nact = min(16, a.so[t + 1] - p0 - r0);
+        const long q = (long)p0 + r0 + (row < nact ? row : 0);
+        n_dh = a.dHout[q * H + col]; n_h = a.Hout[q * H + col];
+    };
+    if (tg > 0) prefetch(tg - 1);
+    for (int t = tg - 1; t >= 0; --t) {
+        const int p0 = a.so[t], bt = a.so[t + 1] - p0;
+        const int bnext = t + 1 < a.T ? a.so[t + 2] - a.so[t + 1] : 0;
+        const int nact = min(16, bt - r0);
+        const bool ok = row < nact;
+        const long q = (long)p0 + r0 + (ok ? row : 0);
+        float dh = n_dh;
+        if (r0 + row < bnext) dh += carry;
+        const float dp = dh * act_grad<ACT>(n_h);
+        if (t == 0) { if (ok) a.dPre[q * H + col] = dp; break; }
+        if (ok) st_f32(a.dPre + q * H + col, dp, wt);
+        cl_publish_n<0>(fl + c, ++count, wt);
+        prefetch(t - 1);
+        if (!cl_wait_w<CB>(fl, count, a.error, a.spin_limit)) { if (ok) a.dPre[q * H + col] = __builtin_nanf(""); return; }
+        if (first_x) { wt = !cl_same_xcd<CB>(fl); first_x = false; }
+        float acc[1] = {0.f}, unused[1];
+        {
+            float av[H / 16];
+            ld_rows_dma<H>(av, a.dPre + ((long)p0 + r0) * H, H, nact, w * (H / 4), stage, lane);
+            cl_tiles_n<H, 1>(av, b, red, tid, acc, unused);
+        }
+        carry = RD ? acc[0] * m_o : acc[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// LSTM forward: [i|f|c~|o] = xw_t + h_{t-1} . U ;  c_t = f c_{t-1} + i c~ ;  h_t = o act(c_t)      (lstm_step_fwd)
+// The wave's K slice of h_{t-1} feeds all four gate tiles (8 independent accumulators).
+// ------------------------------------------------------------------------------------------------------------------
+template <int J, int ACT, bool RD>
+__global__ __launch_bounds__(256, 2) void lstm_cluster_fwd(ClusterArgs a) {
+    constexpr int H = 64 * J, GH = 4 * H, CB = H / 16, NB = H / 64;
+    CL_PROLOGUE(CB);
+    __shared__ float smem[4096 + 4 * 16 * (H / 4)];       // 4 gate tiles x 4 waves of partial sums + the waves' A-row images
+    float* red = smem;
+    float* stage = smem + 4096 + w * (16 * H / 4);
+    float4 b[4][NB];
+    {
+        const float4* pa = reinterpret_cast<const float4*>(a.pk_a);      // packed [U_i U_f U_c U_o], N = 4H: gate g's column block = g CB + c
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < NB; ++i) b[g][i] = pa[((size_t)((g * CB + c) * 4 + w) * NB + i) * 64 + lane];
+    }
+    [[maybe_unused]] float mk[RD ? 4 : 1][RD ? H / 16 : 1];
+    if constexpr (RD) {
+        const int srow = min(r0 + (lane & 15), a.B - 1), koff = w * (H / 4) + (lane >> 4) * (H / 16);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) ld_mask(mk[g], a.rmask, a.B, H, g, srow, koff);
+    }
+    const unsigned base = a.epoch;
+    float cprev = 0.f;
+    float n_x[4] = {0.f, 0.f, 0.f, 0.f};
+    auto prefetch_xw = [&](int t) {
+        const int p0 = a.so[t], nact = min(16, a.so[t + 1] - p0 - r0);
+        if (row < nact) {
+            const float* xw = a.XW + ((long)p0 + r0 + row) * GH + col;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) n_x[g] = xw[g * H];
+        }
+    };
+    prefetch_xw(0);
+    for (int t = 0; t < a.T; ++t) {
+        const int p0 = a.so[t], bt = a.so[t + 1] - p0;
+        if (bt <= r0) break;
+        const int nact = min(16, bt - r0);
+        const bool ok = row < nact;
+        const long q = (long)p0 + r0 + row;
+        const bool more = t + 1 < a.T && a.so[t + 2] - a.so[t + 1] > r0;
+        float xw[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xw[g] = n_x[g];
+        float acc[4] = {0.f, 0.f, 0.f, 0.f}, unused[4];
+        if (t > 0) {
+            if (!cl_wait_w<CB>(fl, base + (unsigned)t, a.error, a.spin_limit)) { if (ok) a.Hout[q * H + col] = __builtin_nanf(""); return; }
+            if (t == 1) wt = !cl_same_xcd<CB>(fl);
+            float av[H / 16];
+            ld_rows_dma<H>(av, a.Hout + ((long)a.so[t - 1] + r0) * H, H, nact, w * (H / 4), stage, lane);
+            if constexpr (RD) {
+                // every gate reads h_{t-1} through its own mask: four masked copies of the A operand, one tile each
+                float4 b1[1][NB];
+                float am[H / 16], o1[1], u1[1];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    mul_vec(am, av, mk[g]);
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) b1[0][i] = b[g][i];
+                    if (g) __syncthreads();                          // red of the previous gate has been read
+                    cl_tiles_n<H, 1>(am, b1, red, tid, o1, u1);
+                    acc[g] = o1[0];
+                }
+            } else {
+                cl_tiles_n<H, 4>(av, b, red, tid, acc, unused);
+            }
+        }
+        float gi, gf, gg, go, cn, hn;
+        lstm_cell_fwd<ACT>(acc[0] + xw[0], acc[1] + xw[1], acc[2] + xw[2], acc[3] + xw[3], cprev, col < a.H_real, gi, gf, gg, go, cn, hn);
+        if (ok) {
+            st_f32(a.Hout + q * H + col, hn, wt);
+            // c and the gate stash (for the BPTT) ride behind the exchange store
+            st_f32(a.aux + q * H + col, cn, false);
+            st_f32(a.gates + q * GH + col, gi, false);
+            st_f32(a.gates + q * GH + H + col, gf, false);
+            st_f32(a.gates + q * GH + 2 * H + col, gg, false);
+            st_f32(a.gates + q * GH + 3 * H + col, go, false);
+        }
+        cprev = cn;
+        if (more) {
+            cl_publish_n<5>(fl + c, base + (unsigned)t + 1u, wt);
+            prefetch_xw(t + 1);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// LSTM BPTT: per step (descending) the four pre-activation gradients of (row, col) from dh, dc and the stash (exchange),
+// then dh_{t-1}[row, col] = dPre_t[row, :] . U^T[:, col] with K = 4H split over the waves as [i f c o]
+// (pointwise_bwd_step<LSTM> + gemm_bwd_step<4H>).  dh and dc for step t-1 stay in registers of thread (row, col).
+// ------------------------------------------------------------------------------------------------------------------
+template <int J, int ACT, bool RD>
+__global__ __launch_bounds__(256, 2) void lstm_cluster_bwd(ClusterArgs a) {
+    constexpr int H = 64 * J, GH = 4 * H, CB = H / 16, K = 4 * H;
+    constexpr int SLQ = K / 16;                          // floats of a lane's run of its A row: H / 4
+    constexpr int CHF = SLQ < 32 ? SLQ : 32;             // floats per piece
+    constexpr int NPC = SLQ / CHF;                       // pieces per step: 1, 1, 2, 4 at H = 64 ... 512
+    constexpr int IMG = 16 * 4 * CHF;                    // floats of a piece image
+    CL_PROLOGUE(CB);
+    __shared__ float smem[1024 + 4 * (NPC > 1 ? 2 : 1) * IMG];
+    float* red = smem;
+    float* ring = smem + 1024 + w * ((NPC > 1 ? 2 : 1) * IMG);
+    float4 b[K / 64];
+    {
+        const float4* pb = reinterpret_cast<const float4*>(a.pk_b);      // U^T, K = 4H: wave w owns gate block w
+#pragma unroll
+        for (int i = 0; i < K / 64; ++i) b[i] = pb[((size_t)(c * 4 + w) * (K / 64) + i) * 64 + lane];
+    }
+    [[maybe_unused]] float m_g[4] = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (RD) {
+        const long srow = min(r0 + row, a.B - 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) m_g[g] = a.rmask[((long)g * a.B + srow) * H + col];
+    }
+    unsigned count = a.epoch;
+    bool first_x = true;
+    int tg = 0;
+    while (tg < a.T && a.so[tg + 1] - a.so[tg] > r0) ++tg;
+    float dh_carry = 0.f, dc_carry = 0.f;
+    // element-wise operands of a step, requested one step ahead (they do not depend on the exchange)
+    float n_dh = 0.f, n_g[4] = {0.f, 0.f, 0.f, 0.f}, n_cn = 0.f, n_cp = 0.f;
+    auto prefetch = [&](int t) {
+        const int p0 = a.so[t], nact = min(16, a.so[t + 1] - p0 - r0);
+        const int rr = row < nact ? row : 0;
+        const long q = (long)p0 + r0 + rr;
+        n_dh = a.dHout[q * H + col];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) n_g[g] = a.gates[q * GH + g * H + col];
+        n_cn = a.aux[q * H + col];
+        n_cp = t > 0 ? a.aux[((long)a.so[t - 1] + r0 + rr) * H + col] : 0.f;
+    };
+    if (tg > 0) prefetch(tg - 1);
+    const int kslice0 = w * (K / 4);
+    for (int t = tg - 1; t >= 0; --t) {
+        const int p0 = a.so[t], bt = a.so[t + 1] - p0;
+        const int bnext = t + 1 < a.T ? a.so[t + 2] - a.so[t + 1] : 0;
+        const int nact = min(16, bt - r0);
+        const bool ok = row < nact;
+        const long q = (long)p0 + r0 + (ok ? row : 0);
+        const bool carried = r0 + row < bnext;
+        const float dh = carried ? n_dh + dh_carry : n_dh;
+        float di, df, dg, dout, dcp;
+        lstm_cell_bwd<ACT>(dh, carried ? dc_carry : 0.f, n_g[0], n_g[1], n_g[2], n_g[3], n_cn, n_cp, di, df, dg, dout, dcp);
+        dc_carry = dcp;
+        if (t == 0) {
+            if (ok) {
+                float* o = a.dPre + q * GH + col;
+                o[0] = di; o[H] = df; o[2 * H] = dg; o[3 * H] = dout;
+            }
+            break;
+        }
+        if (ok) {
+            st_f32(a.dPre + q * GH + col, di, wt);
+            st_f32(a.dPre + q * GH + H + col, df, wt);
+            st_f32(a.dPre + q * GH + 2 * H + col, dg, wt);
+            st_f32(a.dPre + q * GH + 3 * H + col, dout, wt);
+        }
+        cl_publish_n<0>(fl + c, ++count, wt);
+        prefetch(t - 1);
+        if (!cl_wait_w<CB>(fl, count, a.error, a.spin_limit)) { if (ok) a.dPre[q * GH + col] = __builtin_nanf(""); return; }
+        if (first_x) { wt = !cl_same_xcd<CB>(fl); first_x = false; }
+        // dPre rows of the step, wave w's gate block, in pieces through the two-deep ring
+        const float* rows = a.dPre + ((long)p0 + r0) * GH;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        dma_piece_issue<SLQ, CHF>(rows, GH, nact, kslice0, 0, ring, lane);
+#pragma unroll
+        for (int pc = 0; pc < NPC; ++pc) {
+            if (pc + 1 < NPC) dma_piece_issue<SLQ, CHF>(rows, GH, nact, kslice0, pc + 1, ring + ((pc + 1) & 1) * IMG, lane);
+            // the ring slot of piece pc + 1 was last read two pieces ago (program order of one wave; its LDS reads have
+            // returned: the MFMAs that consumed them were issued) -- and the prefetch loads above are older than every
+            // piece: the counter is in order, so "all but the newest piece" means piece pc has landed
+            if (pc + 1 < NPC) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(16 / (64 / CHF)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            f32x4 av[CHF / 4];
+            dma_piece_read<CHF>(av, ring + (pc & 1) * IMG, lane);
+#pragma unroll
+            for (int i = 0; i < CHF / 4; ++i) {
+                const float4 bb = b[pc * (CHF / 4) + i];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][0], bb.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][1], bb.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][2], bb.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][3], bb.w, acc1, 0, 0, 0);
+            }
+            // (slot pc & 1 is rewritten by piece pc + 2: its reads have returned -- dma_piece_read waits for them)
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[w * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc0[r] + acc1[r];
+        __syncthreads();
+        if constexpr (RD) {
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) v += red[g * 256 + tid] * m_g[g];
+            dh_carry = v;
+        } else {
+            dh_carry = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+        }
+        // (the next write of `red` is behind the next step's publish barrier)
+    }
+}
+
+#define KERNEL_TABLE(NAME, KERN)                                                                                     \
+    const void* NAME(int J, int act, bool rd) {                                                                      \
+        switch ((J * 4 + act) * 2 + (rd ? 1 : 0)) {                                                                  \
+            case (1 * 4 + 0) * 2: return reinterpret_cast<const void*>(KERN<1, 0, false>);                           \
+            case (1 * 4 + 1) * 2: return reinterpret_cast<const void*>(KERN<1, 1, false>);                           \
+            case (1 * 4 + 2) * 2: return reinterpret_cast<const void*>(KERN<1, 2, false>);                           \
+            case (2 * 4 + 0) * 2: return reinterpret_cast<const void*>(KERN<2, 0, false>);                           \
+            case (2 * 4 + 1) * 2: return reinterpret_cast<const void*>(KERN<2, 1, false>);                           \
+            case (2 * 4 + 2) * 2: return reinterpret_cast<const void*>(KERN<2, 2, false>);                           \
+            case (4 * 4 + 0) * 2: return reinterpret_cast<const void*>(KERN<4, 0, false>);                           \
+            case (4 * 4 + 1) * 2: return reinterpret_cast<const void*>(KERN<4, 1, false>);                           \
+            case (4 * 4 + 2) * 2: return reinterpret_cast<const void*>(KERN<4, 2, false>);                           \
+            case (8 * 4 + 0) * 2: return reinterpret_cast<const void*>(KERN<8, 0, false>);                           \
+            case (8 * 4 + 1) * 2: return reinterpret_cast<const void*>(KERN<8, 1, false>);                           \
+            case (8 * 4 + 2) * 2: return reinterpret_cast<const void*>(KERN<8, 2, false>);                           \
+            case (1 * 4 + 0) * 2 + 1: return reinterpret_cast<const void*>(KERN<1, 0, true>);                        \
+            case (1 * 4 + 1) * 2 + 1: return reinterpret_cast<const void*>(KERN<1, 1, true>);                        \
+            case (1 * 4 + 2) * 2 + 1: return reinterpret_cast<const void*>(KERN<1, 2, true>);                        \
+            case (2 * 4 + 0) * 2 + 1: return reinterpret_cast<const void*>(KERN<2, 0, true>);                        \
+            case (2 * 4 + 1) * 2 + 1: return reinterpret_cast<const void*>(KERN<2, 1, true>);                        \
+            case (2 * 4 + 2) * 2 + 1: return reinterpret_cast<const void*>(KERN<2, 2, true>);                        \
+            case (4 * 4 + 0) * 2 + 1: return reinterpret_cast<const void*>(KERN<4, 0, true>);                        \
+            case (4 * 4 + 1) * 2 + 1: return reinterpret_cast<const void*>(KERN<4, 1, true>);                        \
+            case (4 * 4 + 2) * 2 + 1: return reinterpret_cast<const void*>(KERN<4, 2, true>);                        \
+            case (8 * 4 + 0) * 2 + 1: return RD8 ? reinterpret_cast<const void*>(KERN<8, 0, RD8>) : nullptr;         \
+            case (8 * 4 + 1) * 2 + 1: return RD8 ? reinterpret_cast<const void*>(KERN<8, 1, RD8>) : nullptr;         \
+            case (8 * 4 + 2) * 2 + 1: return RD8 ? reinterpret_cast<const void*>(KERN<8, 2, RD8>) : nullptr;         \
+        }                                                                                                            \
+        return nullptr;                                                                                              \
+    }
+// H = 512 with recurrent dropout: the forward LSTM would need 128 mask + 128 kernel registers per lane -> step-wise form;
+// the other three kernels keep one multiplier per thread (BPTT) or 32 per lane (SimpleRNN forward)
+#define RD8 true
+KERNEL_TABLE(srnn_fwd_kernel, srnn_cluster_fwd)
+KERNEL_TABLE(srnn_bwd_kernel, srnn_cluster_bwd)
+KERNEL_TABLE(lstm_bwd_kernel, lstm_cluster_bwd)
+#undef RD8
+#define RD8 false
+KERNEL_TABLE(lstm_fwd_kernel, lstm_cluster_fwd)
+#undef RD8
+
+}  // namespace
+
+bool seqrec_cluster_other_fwd(int cell, int act, int H, int H_real, int T, int B, const int32_t* soh, const float* XW, float* Hout,
+                              float* gates, float* aux, const float* upack, const float* rmask, hipStream_t st, int* rc) {
+    const int J = H / 64, CB = H / 16;
+    const bool lstm = cell == SEQREC_CELL_LSTM;
+    const void* fn = lstm ? lstm_fwd_kernel(J, act, rmask != nullptr) : srnn_fwd_kernel(J, act, rmask != nullptr);
+    if (!fn || cluster_group_cap(fn, CB) < 1) return false;
+    // an LSTM forward with dropout at H = 512 would be followed by a cluster BPTT: both forms are the same arithmetic
+    const int B0 = soh[1] - soh[0];
+    if (B0 <= 0) { *rc = 0; return true; }
+    ClusterArgs a = {};
+    a.H_real = H_real; a.T = T; a.XW = XW; a.Hout = Hout; a.gates = gates; a.aux = aux; a.rmask = rmask; a.B = B;
+    a.pk_a = upack;
+    for (int t = 0; t <= T; ++t) a.so[t] = soh[t];
+    *rc = launch_sliced(fn, a, CB, (B0 + 15) / 16, T, st);
+    return true;
+}
+
+bool seqrec_cluster_other_bwd(int cell, int act, int H, int H_real, int T, int B, const int32_t* soh, const float* dHout,
+                              const float* Hout, const float* gates, const float* aux, float* dPre, const float* upack,
+                              const float* rmask, hipStream_t st, int* rc) {
+    const int J = H / 64, CB = H / 16;
+    const bool lstm = cell == SEQREC_CELL_LSTM;
+    const void* fn = lstm ? lstm_bwd_kernel(J, act, rmask != nullptr) : srnn_bwd_kernel(J, act, rmask != nullptr);
+    if (!fn || cluster_group_cap(fn, CB) < 1) return false;
+    const int B0 = soh[1] - soh[0];
+    if (B0 <= 0) { *rc = 0; return true; }
+    ClusterArgs a = {};
+    a.H_real = H_real; a.T = T; a.dHout = dHout; a.Hout = const_cast<float*>(Hout); a.gates = const_cast<float*>(gates);
+    a.aux = const_cast<float*>(aux); a.dPre = dPre; a.rmask = rmask; a.B = B;
+    a.pk_b = upack + (lstm ? 4l : 1l) * H * H;
+    for (int t = 0; t <= T; ++t) a.so[t] = soh[t];
+    *rc = launch_sliced(fn, a, CB, (B0 + 15) / 16, T, st);
+    return true;
+}

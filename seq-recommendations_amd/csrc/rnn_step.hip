@@ -19,6 +19,7 @@
 // the launches.
 #include "common.h"
 #include "rnn_cluster.h"
+#include "rnn_cluster_dev.h"
 #include <algorithm>
 #include <cstdlib>
 #include <map>
@@ -226,23 +227,6 @@ __device__ __forceinline__ void mask_vec(float (&a)[N], const float* __restrict_
 
 __device__ __forceinline__ float4 mask4(const float* __restrict__ rmask, int B, int H, int g, int srow, int c4) {
     return reinterpret_cast<const float4*>(rmask + ((long)g * B + srow) * H)[c4];
-}
-
-// LSTM forward layout: out[((cb*4 + g)*(H/16) + i)*64 + lane] (float4), element e <-> kb = 4*i + e,
-//   value = U[(4*kb + (lane>>4)) * 4H + g*H + 16*cb + (lane&15)]
-__global__ void pack_lstm_fwd_kernel(const float* __restrict__ U, int H, float* __restrict__ out) {
-    const long total = 4L * H * H;
-    const int G4 = H / 16;
-    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
-        long q = o;
-        const int e = (int)(q & 3); q >>= 2;
-        const int l = (int)(q & 63); q >>= 6;
-        const int i = (int)(q % G4); q /= G4;
-        const int g = (int)(q & 3); q >>= 2;
-        const int cb = (int)q;
-        const int k = 4 * (4 * i + e) + (l >> 4);
-        out[o] = U[(long)k * 4 * H + g * H + 16 * cb + (l & 15)];
-    }
 }
 
 template <int J, int ACT, int PHASE>
@@ -556,19 +540,20 @@ __global__ __launch_bounds__(256) void gru_step_bwd0_wide(StepArgs a_in) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// LSTM forward step (ONE launch per step): workgroup = 16 rows x 16 hidden columns, wave g computes
-// gate g's pre-activation over the whole K; gate values meet in LDS and thread (row, col) finishes
-// c and h.  packed: [cb][gate][K/16 float4 groups][lane]
-// SimpleRNN forward step: same tile with K split over the waves.
+// LSTM forward step (ONE launch per step): workgroup = 16 rows x 16 hidden columns; K is split over the 4 waves like
+// every other step kernel (the wave's K slice of h_prev straight into MFMA operand registers) and feeds the FOUR gate
+// tiles -- 8 independent accumulators per wave; partial tiles meet in LDS and thread (row, col) finishes c and h.
+// The tile products and the cell arithmetic are the cluster kernel's own functions (rnn_cluster_dev.h): the two forms
+// of the scan agree bit for bit.  packed: pack_step_kernel mode 0 with N = 4H (gate g's column block = g H/16 + cb).
+// SimpleRNN forward step: same tile, one product.
 // ---------------------------------------------------------------------------------------------
 template <int J, int ACT, bool RD>
 __device__ __forceinline__ void lstm_step_fwd_body(const StepArgs& a_in) {
     const StepArgs& a = a_in;
     int r0, cb;
     if (!tile_of(a, r0, cb)) return;
-    constexpr int H = 64 * J, LDA = H + 2, GH = 4 * H, G4 = H / 16;
-    __shared__ float ab[(RD ? 4 : 1) * 16 * LDA];
-    __shared__ float red[4 * 256];
+    constexpr int H = 64 * J, GH = 4 * H, NB = H / 64, CBN = H / 16;
+    __shared__ float red[4 * 1024];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nact = min(16, a.bt - r0);
     const int row = tid >> 4, col = 16 * cb + (tid & 15);
@@ -577,60 +562,45 @@ __device__ __forceinline__ void lstm_step_fwd_body(const StepArgs& a_in) {
     const int soG = (a.p0 + r0) * GH * 4, soH = (a.p0 + r0) * H * 4, soP = (a.pprev0 + r0) * H * 4;
     const int vg = ok ? (row * GH + col) * 4 : INVALID_OFF;
     const int vh = ok ? (row * H + col) * 4 : INVALID_OFF;
-    float4 b[G4];
-    if (!a.first) {          // the gate's U slice first, pinned: it must be in flight while h_prev is staged through LDS
-        const float4* pk = reinterpret_cast<const float4*>(a.pk) + (size_t)(cb * 4 + w) * G4 * 64 + lane;
+    float4 b[4][NB];
+    float av[H / 16];
+    const int arow = min(lane & 15, nact - 1), koff = a_koff<H>(lane, w);
+    if (!a.first) {          // the U slices first, pinned, then the A rows: every load in flight before the first wait
 #pragma unroll
-        for (int i = 0; i < G4; ++i) b[i] = pk[i * 64];
+        for (int g = 0; g < 4; ++g) {
+            const float4* pk = reinterpret_cast<const float4*>(a.pk) + (size_t)((g * CBN + cb) * 4 + w) * NB * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) b[g][i] = pk[i * 64];
+        }
+        gload_vec(av, a.Hout + (long)(a.pprev0 + r0 + arow) * H + koff);
     }
-    __builtin_amdgcn_sched_barrier(0);
     float xw[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) xw[g] = bload(rXW, vg + g * H * 4, soG);
     const float cp = bload(rC, a.first ? INVALID_OFF : vh, soP);
+    __builtin_amdgcn_sched_barrier(0);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, unused[4];
     if (!a.first) {
-        const float* src = a.Hout + (long)(a.pprev0 + r0) * H;
+        if constexpr (RD) {      // every gate reads h_prev through its own recurrent-dropout mask
+            float4 b1[1][NB];
+            float am[H / 16], o1[1], u1[1];
 #pragma unroll
-        for (int it = 0; it < (16 * (H / 4)) / 256; ++it) {
-            const int idx = tid + 256 * it;
-            const int rr = idx / (H / 4), c4 = idx % (H / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rr < nact) v = reinterpret_cast<const float4*>(src + (long)rr * H)[c4];
-            if (RD) {
+            for (int g = 0; g < 4; ++g) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (rr < nact) m = mask4(a.rmask, a.B, H, g, r0 + rr, c4);
-                    float* d = ab + g * 16 * LDA + rr * LDA + 4 * c4;
-                    d[0] = v.x * m.x; d[1] = v.y * m.y; d[2] = v.z * m.z; d[3] = v.w * m.w;
-                }
-            } else {
-                float* d = ab + rr * LDA + 4 * c4;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                for (int j = 0; j < H / 16; ++j) am[j] = av[j];
+                mask_vec(am, a.rmask, a.B, H, g, r0 + arow, koff, true);
+#pragma unroll
+                for (int i = 0; i < NB; ++i) b1[0][i] = b[g][i];
+                if (g) __syncthreads();
+                seqrec_cluster::cl_tiles_n<H, 1>(am, b1, red, tid, o1, u1);
+                acc[g] = o1[0];
             }
+        } else {
+            seqrec_cluster::cl_tiles_n<H, 4>(av, b, red, tid, acc, unused);
         }
-        __syncthreads();
-        const float* ap = ab + (RD ? w * 16 * LDA : 0) + (lane & 15) * LDA + (lane >> 4);
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < G4; ++i) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 0], b[i].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 4], b[i].y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 8], b[i].z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i + 12], b[i].w, acc1, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[w * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc0[r] + acc1[r];
-        __syncthreads();
     }
-    const float pi = (a.first ? 0.f : red[tid]) + xw[0];
-    const float pf = (a.first ? 0.f : red[256 + tid]) + xw[1];
-    const float pc = (a.first ? 0.f : red[512 + tid]) + xw[2];
-    const float po = (a.first ? 0.f : red[768 + tid]) + xw[3];
-    const float gi = hard_sigmoid(pi), gf = hard_sigmoid(pf), gg = act_fwd<ACT>(pc), go = hard_sigmoid(po);
-    float c = gf * cp + gi * gg;
-    float h = go * act_fwd<ACT>(c);
-    if (col >= a.H_real) { c = 0.f; h = 0.f; }
+    float gi, gf, gg, go, c, h;
+    lstm_cell_fwd<ACT>(acc[0] + xw[0], acc[1] + xw[1], acc[2] + xw[2], acc[3] + xw[3], cp, col < a.H_real, gi, gf, gg, go, c, h);
     bstore(rH, vh, soH, h);
     bstore(rC, vh, soH, c);
     bstore(rG, vg, soG, gi);
@@ -697,14 +667,14 @@ __global__ void pointwise_bwd_step(StepArgs a_in) {
         const float cn = a.aux[q * H + col];
         const float cp = a.first ? 0.f : a.aux[((long)a.pprev0 + row) * H + col];
         const float dcin = row < a.bnext ? a.tmpc[q * H + col] : 0.f;      // dc carried from step t+1
-        const float ac = act_fwd<ACT>(cn);
-        const float dct = dcin + dh * go * act_grad<ACT>(ac);
+        float di, df, dg, dout, dcp;
+        lstm_cell_bwd<ACT>(dh, dcin, gi, gf, gg, go, cn, cp, di, df, dg, dout, dcp);
         float* o = a.dPre + q * GH + col;
-        o[0] = dct * gg * hard_sigmoid_grad(gi);
-        o[H] = dct * cp * hard_sigmoid_grad(gf);
-        o[2 * H] = dct * gi * act_grad<ACT>(gg);
-        o[3 * H] = dh * ac * hard_sigmoid_grad(go);
-        if (!a.first) a.tmpc[((long)a.pprev0 + row) * H + col] = dct * gf;   // dc for the previous token
+        o[0] = di;
+        o[H] = df;
+        o[2 * H] = dg;
+        o[3 * H] = dout;
+        if (!a.first) a.tmpc[((long)a.pprev0 + row) * H + col] = dcp;   // dc for the previous token
     }
 }
 
@@ -900,11 +870,10 @@ static int pack_u_impl(int cell, int H, const float* U, float* upack, const Samp
     pa.U = U; pa.out = upack;
     int nj;
     if (cell == SEQREC_CELL_LSTM) {
-        // fwd: [cb][gate][K/16 groups][lane] -- wave g streams gate g's 16 columns over the whole K
-        hipLaunchKernelGGL(pack_lstm_fwd_kernel, dim3(256), dim3(256), 0, st, U, H, upack);
         pa.ldu = 4 * H;
-        pa.job[0] = PackStepJob{0, 4 * H, H, 1, 4 * HH};          // bwd: U^T, K = 4H
-        nj = 1;
+        pa.job[0] = PackStepJob{0, H, 4 * H, 0, 0};               // fwd: [U_i U_f U_c U_o], N = 4H column blocks
+        pa.job[1] = PackStepJob{0, 4 * H, H, 1, 4 * HH};          // bwd: U^T, K = 4H
+        nj = 2;
     } else if (cell == SEQREC_CELL_SIMPLERNN) {
         pa.ldu = H;
         pa.job[0] = PackStepJob{0, H, H, 0, 0};
@@ -941,60 +910,111 @@ extern "C" int seqrec_rnn_pack_u_sample(int cell, int H, const float* U, float* 
     return pack_u_impl(cell, H, U, upack, &sj, as_stream(stream));
 }
 
-// ---- launch-graph cache: one instantiated hipGraph per launch SEQUENCE (the ordered kernel functions of a plan:
-// cell, activation, H, direction and T decide it); every replay rewrites all nodes with the batch's arguments
+// ---- launch-graph cache (hidden state of the library, part 2 of 2): per (stream, launch SEQUENCE -- the ordered kernel
+// functions of a plan: cell, activation, H, direction and T decide it) one hipGraph and a small RING of executables
+// instantiated from it.  A replay rewrites every node of an executable with the batch's arguments
+// (hipGraphExecKernelNodeSetParams) and launches it.  Nothing says that an executable whose previous launch is still
+// queued keeps the arguments it was launched with when its nodes are rewritten, so that never happens: every launch
+// records an event behind itself, an executable is only rewritten once its event has completed, a free one is taken
+// from the ring (grown to GRAPH_RING executables, then the host waits for the oldest).  A training loop that enqueues
+// steps without host syncs (bench.py, fit_generator) is the case this is for; tests/test_gpu_ops.py replays two
+// DIFFERENT batches back to back behind a long kernel and compares with the eager issue.
 namespace {
-struct GraphEntry { hipGraph_t graph; hipGraphExec_t exec; std::vector<hipGraphNode_t> nodes; };   // the node handles live in `graph`
-std::map<std::vector<const void*>, GraphEntry> g_graphs;
+constexpr size_t GRAPH_RING = 4;
+struct GraphExec { hipGraphExec_t exec; hipEvent_t done; bool launched; };
+struct GraphEntry { hipGraph_t graph; std::vector<hipGraphNode_t> nodes; std::vector<GraphExec> ring; size_t next; };   // the node handles live in `graph`
+typedef std::pair<hipStream_t, std::vector<const void*>> GraphKey;
+std::map<GraphKey, GraphEntry> g_graphs;
 std::mutex g_graph_mu;
 
+void destroy_entry(GraphEntry& ent) {
+    for (GraphExec& x : ent.ring) {
+        if (x.launched) (void)hipEventSynchronize(x.done);       // never destroy an executable that may still be queued
+        (void)hipEventDestroy(x.done);
+        (void)hipGraphExecDestroy(x.exec);
+    }
+    (void)hipGraphDestroy(ent.graph);
+}
+
+void node_params(Launch& L, void** argv, hipKernelNodeParams& p) {
+    argv[0] = &L.a; argv[1] = &L.i0; argv[2] = &L.i1;
+    p = hipKernelNodeParams{};
+    p.func = const_cast<void*>(L.fn);
+    p.gridDim = dim3(L.grid); p.blockDim = dim3(256); p.sharedMemBytes = 0;
+    p.kernelParams = argv; p.extra = nullptr;
+}
+
+int add_exec(GraphEntry& ent) {
+    GraphExec x{};
+    hipError_t e = hipGraphInstantiate(&x.exec, ent.graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) return (int)e;
+    e = hipEventCreateWithFlags(&x.done, hipEventDisableTiming);
+    if (e != hipSuccess) { (void)hipGraphExecDestroy(x.exec); return (int)e; }
+    x.launched = false;
+    ent.ring.push_back(x);
+    return 0;
+}
+
 int issue_graph(Plan& pl, hipStream_t st) {
-    std::vector<const void*> key(pl.size());
-    for (size_t i = 0; i < pl.size(); ++i) key[i] = pl[i].fn;
+    GraphKey key;
+    key.first = st;
+    key.second.resize(pl.size());
+    for (size_t i = 0; i < pl.size(); ++i) key.second[i] = pl[i].fn;
     std::lock_guard<std::mutex> lk(g_graph_mu);
     auto it = g_graphs.find(key);
+    hipError_t e;
     if (it == g_graphs.end()) {
         // build the chain explicitly (node i depends on node i - 1): the node handles are then known in launch order
-        hipError_t e;
-        hipGraph_t graph;
-        e = hipGraphCreate(&graph, 0);
-        if (e != hipSuccess) return (int)e;
         GraphEntry ent;
+        e = hipGraphCreate(&ent.graph, 0);
+        if (e != hipSuccess) return (int)e;
         ent.nodes.reserve(pl.size());
+        ent.next = 0;
         for (size_t i = 0; i < pl.size(); ++i) {
-            Launch& L = pl[i];
-            void* argv[3] = {&L.a, &L.i0, &L.i1};
-            hipKernelNodeParams p = {};
-            p.func = const_cast<void*>(L.fn);
-            p.gridDim = dim3(L.grid); p.blockDim = dim3(256); p.sharedMemBytes = 0;
-            p.kernelParams = argv; p.extra = nullptr;
+            void* argv[3];
+            hipKernelNodeParams p;
+            node_params(pl[i], argv, p);
             hipGraphNode_t node;
-            e = hipGraphAddKernelNode(&node, graph, i ? &ent.nodes[i - 1] : nullptr, i ? 1 : 0, &p);
-            if (e != hipSuccess) { (void)hipGraphDestroy(graph); return (int)e; }
+            e = hipGraphAddKernelNode(&node, ent.graph, i ? &ent.nodes[i - 1] : nullptr, i ? 1 : 0, &p);
+            if (e != hipSuccess) { (void)hipGraphDestroy(ent.graph); return (int)e; }
             ent.nodes.push_back(node);
         }
-        e = hipGraphInstantiate(&ent.exec, graph, nullptr, nullptr, 0);
-        if (e != hipSuccess) { (void)hipGraphDestroy(graph); return (int)e; }
-        ent.graph = graph;
         if (g_graphs.size() >= 512) {                      // bounded: drop everything, rebuild on demand
-            for (auto& kv : g_graphs) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
+            for (auto& kv : g_graphs) destroy_entry(kv.second);
             g_graphs.clear();
         }
         it = g_graphs.emplace(key, ent).first;
-    } else {
-        GraphEntry& ent = it->second;
-        for (size_t i = 0; i < pl.size(); ++i) {
-            Launch& L = pl[i];
-            void* argv[3] = {&L.a, &L.i0, &L.i1};
-            hipKernelNodeParams p = {};
-            p.func = const_cast<void*>(L.fn);
-            p.gridDim = dim3(L.grid); p.blockDim = dim3(256); p.sharedMemBytes = 0;
-            p.kernelParams = argv; p.extra = nullptr;
-            const hipError_t e = hipGraphExecKernelNodeSetParams(ent.exec, ent.nodes[i], &p);
-            if (e != hipSuccess) return (int)e;
-        }
     }
-    const hipError_t e = hipGraphLaunch(it->second.exec, st);
+    GraphEntry& ent = it->second;
+    // an executable that is not in flight: the next one of the ring if its last launch has completed, else a new one, else wait
+    GraphExec* x = nullptr;
+    for (size_t k = 0; k < ent.ring.size() && !x; ++k) {
+        GraphExec& c = ent.ring[(ent.next + k) % ent.ring.size()];
+        if (!c.launched || hipEventQuery(c.done) == hipSuccess) { x = &c; ent.next = (ent.next + k + 1) % ent.ring.size(); }
+    }
+    if (!x && ent.ring.size() < GRAPH_RING) {
+        const int rc = add_exec(ent);
+        if (rc) return rc;
+        x = &ent.ring.back();
+        ent.next = 0;
+    }
+    if (!x) {
+        x = &ent.ring[ent.next];
+        ent.next = (ent.next + 1) % ent.ring.size();
+        e = hipEventSynchronize(x->done);
+        if (e != hipSuccess) return (int)e;
+    }
+    for (size_t i = 0; i < pl.size(); ++i) {
+        void* argv[3];
+        hipKernelNodeParams p;
+        node_params(pl[i], argv, p);
+        e = hipGraphExecKernelNodeSetParams(x->exec, ent.nodes[i], &p);
+        if (e != hipSuccess) return (int)e;
+    }
+    e = hipGraphLaunch(x->exec, st);
+    if (e != hipSuccess) return (int)e;
+    x->launched = true;
+    e = hipEventRecord(x->done, st);
     return e == hipSuccess ? 0 : (int)e;
 }
 }  // namespace
@@ -1013,8 +1033,22 @@ extern "C" int seqrec_debug_stamps(unsigned long long* host_out, int clear) {
 
 extern "C" int seqrec_graph_cache_clear(void) {
     std::lock_guard<std::mutex> lk(g_graph_mu);
-    for (auto& kv : g_graphs) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
+    for (auto& kv : g_graphs) destroy_entry(kv.second);
     g_graphs.clear();
+    return 0;
+}
+// Frees what the library keeps for `stream`: the cluster scans' exchange flags and the launch graphs captured for it.
+// Synchronises the stream first.  (A stream that is destroyed without this call leaks 16 KB of device memory and its graphs.)
+extern "C" int seqrec_release_stream(void* stream) {
+    hipStream_t st = as_stream(stream);
+    const hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return (int)e;
+    seqrec_cluster_release_stream(st);
+    std::lock_guard<std::mutex> lk(g_graph_mu);
+    for (auto it = g_graphs.begin(); it != g_graphs.end();) {
+        if (it->first.first == st) { destroy_entry(it->second); it = g_graphs.erase(it); }
+        else ++it;
+    }
     return 0;
 }
 
@@ -1031,9 +1065,9 @@ extern "C" int seqrec_rnn_fwd_stepwise(int cell, int act, int H, int H_real, int
     const int J = H / 64;
     const long HH = (long)H * H;
     const int32_t* soh = step_off_host;
-    if (cell == SEQREC_CELL_GRU && !rmask) {          // cluster form: one launch, in-kernel exchange (rnn_cluster.hip)
+    {                                                 // cluster form: one launch, in-kernel exchange (rnn_cluster.hip, rnn_cluster2.hip)
         int rc = 0;
-        if (seqrec_cluster_gru_fwd(act, H, H_real, T, soh, XW, Hout, gates, aux, upack, st, &rc)) return rc;
+        if (seqrec_cluster_fwd(cell, act, H, H_real, T, B, soh, XW, Hout, gates, aux, upack, rmask, st, &rc)) return rc;
     }
     Plan pl;
     pl.reserve(2 * (size_t)T);
@@ -1120,11 +1154,13 @@ static int rnn_bwd_stepwise_impl(int cell, int act, int H, int H_real, int T, in
     const int J = H / 64;
     const long HH = (long)H * H;
     const int32_t* soh = step_off_host;
-    if (cell == SEQREC_CELL_GRU && !rmask) {          // cluster form: one launch, in-kernel exchange (rnn_cluster.hip)
+    // cluster form: one launch, in-kernel exchange (rnn_cluster.hip, rnn_cluster2.hip).  Only the GRU kernel adds the parts
+    // of dHout in its own loads; every other form reads dHout from one array
+    if (!parts || cell == SEQREC_CELL_GRU) {
         int rc = 0;
-        if (seqrec_cluster_gru_bwd(act, H, H_real, T, soh, dHout, Hout, gates, aux, dPre, upack, st, &rc, parts)) return rc;
+        if (seqrec_cluster_bwd(cell, act, H, H_real, T, B, soh, dHout, Hout, gates, aux, dPre, upack, rmask, st, &rc, parts)) return rc;
     }
-    if (parts) {                                      // every other form reads dHout from one array
+    if (parts) {
         const long total = (long)soh[T] * H;
         if (total > 0) {
             hipLaunchKernelGGL(dh_parts_sum_kernel, dim3((unsigned)std::min<long>(2048, (total + 255) / 256)), dim3(256), 0, st, *parts, H,
@@ -1132,6 +1168,10 @@ static int rnn_bwd_stepwise_impl(int cell, int act, int H, int H_real, int T, in
             SEQREC_LAUNCH_CHECK();
         }
         dHout = dh_scratch;
+        if (cell != SEQREC_CELL_GRU) {
+            int rc = 0;
+            if (seqrec_cluster_bwd(cell, act, H, H_real, T, B, soh, dHout, Hout, gates, aux, dPre, upack, rmask, st, &rc, nullptr)) return rc;
+        }
     }
     Plan pl;
     pl.reserve(2 * (size_t)T);

@@ -330,8 +330,9 @@ class ShardedEngine(Engine):
         local = dataclasses.replace(cfg, V_in=shard_size(cfg.V_in, self.rank, self.R),
                                     V_out=shard_size(cfg.V_out, self.rank, self.R))
         Engine.__init__(self, local, device)
-        # (hipGraph replay of the scan, SEQREC_SCAN_GRAPH=1, was measured for this engine too: 1.27 against 1.19 ms per step
-        # in steady state on one rank -- the device-side step-table lookups cost more than the saved host time)
+        # hipGraph replay of the step-wise scan was measured for this engine (round 2: 1.27 against 1.19 ms per step in steady
+        # state on one rank) and is OFF here: the loop is host-bound by its collectives, not by the scan's launches
+        self.use_graph = False
         self.gcfg = cfg
         self.ex = RowExchange(dist, group, self.dev)
         # dense gradients live in ONE flat buffer (+1 slot for the squared norm of the owned row
@@ -385,7 +386,10 @@ class ShardedEngine(Engine):
     def _take(self, src, idx, out=None):
         if out is None:
             out = torch.empty((idx.numel(), src.shape[1]), dtype=src.dtype, device=self.dev)
-        call("seqrec_gather_rows", ptr(src), ptr(idx), ptr(out), idx.numel(), src.shape[1], None, None, 0, self._stream())
+        # index lists of the row exchange crossed PCIe and a collective: bounded gather (an index outside `src` reads a zero
+        # row and sets SEQREC_STATUS_BAD_INDEX, raised by check_status) -- a stale index cannot pull arbitrary memory into a gradient
+        call("seqrec_gather_rows_bounded", ptr(src), src.shape[0], ptr(idx), ptr(out), idx.numel(), src.shape[1], None, None, 0,
+             ptr(self.status), self._stream(), prof_name="seqrec_gather_rows")
         return out
 
     def _gather_from(self, table):
@@ -478,9 +482,8 @@ class ShardedEngine(Engine):
             if c.logq and self.logq_global is not None:
                 parts.append(("lq_tgt", self.logq_global_host[rb.tgt].view(np.int32)))
             # everything the step needs from the host in ONE int32 blob: the batch's index arrays and its routing
-            host = torch.from_numpy(np.concatenate([np.asarray(x, dtype=np.int32) for _, x in parts]))
-            blob = host.to(self.dev, non_blocking=True)      # `host` stays referenced from d: the copy may outlive this call
-            d = {"n": n, "T": rb.T, "B": rb.B, "rb": rb, "blob": blob, "plan": plan, "_host": [host]}
+            blob = self.pinned.put(np.concatenate([np.asarray(x, dtype=np.int32) for _, x in parts]))   # page-locked ring (PinnedRing)
+            d = {"n": n, "T": rb.T, "B": rb.B, "rb": rb, "blob": blob, "plan": plan}
             o = 0
             for name, x in parts:
                 d[name] = blob[o:o + len(x)]
@@ -592,7 +595,8 @@ class ShardedEngine(Engine):
              None, 0, None, st)
         arr, cnt = rows_job if rows_job is not None else (None, 0)
         call("seqrec_opt_apply", len(dk), _lib.ptr_array([P[k] for k in dk]), _lib.ptr_array([self.A[k] for k in dk]), gp, nn,
-             arr, cnt, ptr(self.sq), float(clipnorm if clipnorm else 0.0), lr, eps, ptr(self.scale), None, ptr(div), st)
+             arr, cnt, ptr(self.sq), float(clipnorm if clipnorm else 0.0), lr, eps, ptr(self.scale), None, ptr(div),
+             ptr(self.status), st)
         self.upack_dirty = True
 
     def grads(self, d, step=0, negatives=None):

@@ -117,6 +117,42 @@ class NetConfig:
         return N_GATES[self.cell]
 
 
+class PinnedRing:
+    """Engine-owned staging memory for every host -> device upload that must not block the host (``non_blocking=True``).
+    A copy from PAGEABLE memory may still be reading its source after the call returns; a numpy temporary whose last
+    reference dies at the end of the caller's loop body is then free to be overwritten under the copy.  Here the bytes
+    are first copied into a page-locked slot that the ring owns, the device copy is issued from the slot and an event is
+    recorded behind it on the stream it was issued on; a slot is reused only after its event has completed (the host
+    waits if the ring is full: 64 slots, i.e. 64 uploads in flight)."""
+
+    def __init__(self, device, slots=64):
+        self.dev = device
+        self.slots = [None] * slots        # (pinned uint8 tensor, event or None)
+        self.pos = 0
+
+    def put(self, arr):
+        """numpy array (any dtype) -> device tensor of the same dtype and shape, uploaded asynchronously on the current stream."""
+        a = np.ascontiguousarray(arr)
+        tdt = torch.from_numpy(np.zeros(0, a.dtype)).dtype
+        if a.size == 0:
+            return torch.empty(a.shape, dtype=tdt, device=self.dev)
+        nbytes = a.nbytes
+        i = self.pos
+        self.pos = (i + 1) % len(self.slots)
+        buf, ev = self.slots[i] if self.slots[i] is not None else (None, None)
+        if ev is not None:
+            ev.synchronize()               # the copy issued from this slot len(slots) uploads ago
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(nbytes, 4096), dtype=torch.uint8).pin_memory()
+        host = buf[:nbytes].view(tdt)
+        host.numpy()[:] = a.reshape(-1)
+        out = host.to(self.dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        self.slots[i] = (buf, ev)
+        return out.view(a.shape)
+
+
 class Engine:
     def __init__(self, cfg: NetConfig, device="cuda:0"):
         _lib.load()                                  # fail loudly without the HIP library
@@ -233,6 +269,29 @@ class Engine:
         self.use_graph = self.stepwise and os.environ.get("SEQREC_SCAN_GRAPH", "1") != "0"
         self.sampler = None       # (thresh uint32-as-int32 tensor, alias int32 tensor, logq float tensor)
         self.step_count = 0
+        # conditions only the device sees (SEQREC_STATUS_*: a gradient norm that is not finite, a clip scale of 0, an index
+        # outside its table): kernels OR their bits into this word, check_status() raises on it at the next host sync
+        self.status = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.pinned = PinnedRing(self.dev)
+
+    # ------------------------------------------------------------------ device-side failures
+    def check_status(self):
+        """Raise SeqrecError if a kernel reported a failure since the last check: a refused optimizer step (gradient norm /
+        divisor / clip scale not usable -- the reference would carry NaNs or, at scale 0, silently train nothing), an index
+        outside its table, or an in-kernel wait of a cluster scan that ran out (its outputs are NaN-poisoned).  Synchronises
+        the current stream: called where the host waits anyway (end of an epoch, evaluation, parameter read-back,
+        checkpoint) -- the counterpart of the reference's asserts / exceptions (model.py:136,149)."""
+        bits = int(self.status.item())
+        nerr = int(_lib.load().seqrec_cluster_scan_errors(self._stream()))
+        if bits == 0 and nerr == 0:
+            return
+        msgs = [txt for b, txt in sorted(_lib.STATUS_BITS.items()) if bits & b]
+        if nerr:
+            msgs.append("%s in-kernel wait(s) of a cluster scan ran out (workgroups of a row block not co-resident, e.g. another "
+                        "process holding the GPU): the scan's outputs are NaN-poisoned" % ("some" if nerr < 0 else nerr))
+        self.status.zero_()
+        _lib.load().seqrec_cluster_scan_errors_reset(self._stream())
+        raise _lib.SeqrecError("device-side failure at or before training step %d: %s" % (self.step_count, "; ".join(msgs)))
 
     # ------------------------------------------------------------------ utilities
     def _side(self):
@@ -443,6 +502,7 @@ class Engine:
 
     def get_param(self, name, accum=False, src=None):
         c = self.cfg
+        self.check_status()               # a host sync anyway: never hand out weights of a run that failed on the device
         if src is None:
             src = self.A if accum else self.P
         t = src[name]
@@ -507,12 +567,10 @@ class Engine:
             parts.append(rb.ids.astype(np.int32))
         if rb.tgt is not None:
             parts.append(rb.tgt.astype(np.int32))
-        # the host source of every non-blocking copy stays referenced from the batch dict: the copy may still be reading it
-        # when this function returns (pageable memory: the runtime is free to pin it and transfer later)
-        host = [torch.from_numpy(np.concatenate(parts))]
-        blob = host[0].to(self.dev, non_blocking=True)
+        # every non-blocking upload goes through the engine's page-locked ring (PinnedRing): safe by construction
+        blob = self.pinned.put(np.concatenate(parts))
         o = 0
-        d = {"n": n, "T": rb.T, "B": rb.B, "rb": rb, "_host": host}
+        d = {"n": n, "T": rb.T, "B": rb.B, "rb": rb}
         d["step_off"] = blob[o:o + rb.T + 1]; o += rb.T + 1
         d["prev"] = blob[o:o + n]; o += n
         if rb.ids is not None:
@@ -522,13 +580,11 @@ class Engine:
         if rb.x is not None:
             x = np.zeros((n, self.Fp), np.float32)
             x[:, : rb.x.shape[1]] = rb.x
-            host.append(torch.from_numpy(x))
-            d["x"] = host[-1].to(self.dev, non_blocking=True)
+            d["x"] = self.pinned.put(x)
         if getattr(rb, "xs", None) is not None and c.x_to_y:
             xs = np.zeros((n, self.Fxp), np.float32)
             xs[:, : rb.xs.shape[1]] = rb.xs
-            host.append(torch.from_numpy(xs))
-            d["xs"] = host[-1].to(self.dev, non_blocking=True)
+            d["xs"] = self.pinned.put(xs)
         d["blob"] = blob
         return d
 
@@ -560,10 +616,9 @@ class Engine:
             call("seqrec_pack_batch_host", ptr(ds["flat"]), ptr(ds["starts"]), sess.ctypes.data, so32.ctypes.data, B, T,
                  ptr(d["sess"]), ptr(d["step_off"]), ptr(d["ids"]), ptr(d["tgt"]), ptr(d["prev"]), st)
         else:
-            host = torch.from_numpy(np.concatenate([so32, sess]))
-            blob = host.to(self.dev, non_blocking=True)
+            blob = self.pinned.put(np.concatenate([so32, sess]))
             d = {"n": n, "T": T, "B": B, "rb": rb, "blob": blob, "step_off": blob[: T + 1], "sess": blob[T + 1:],
-                 "ids": out[:n], "tgt": out[n:2 * n], "prev": out[2 * n:3 * n], "_out": out, "_host": [host]}
+                 "ids": out[:n], "tgt": out[n:2 * n], "prev": out[2 * n:3 * n], "_out": out}
             call("seqrec_pack_batch", ptr(ds["flat"]), ptr(ds["starts"]), ptr(d["sess"]), ptr(d["step_off"]), B, T, ptr(d["ids"]),
                  ptr(d["tgt"]), ptr(d["prev"]), st)
         if history:
@@ -1011,7 +1066,7 @@ class Engine:
                 call("seqrec_opt_sqnorm", len(dk), gp, nn, arr, cnt, ptr(cur), ptr(lrows), n, ptr(self.loss_out), st)
             call("seqrec_opt_apply", len(dk), _lib.ptr_array([P[k] for k in dk]) if dk else None,
                  _lib.ptr_array([self.A[k] for k in dk]) if dk else None, gp, nn, arr, cnt, ptr(cur), clip, lr, eps,
-                 ptr(self.scale), ptr(nxt), None, st)
+                 ptr(self.scale), ptr(nxt), None, ptr(self.status), st)
             self._sq_par ^= 1
             self.sq = cur
         else:

@@ -409,7 +409,9 @@ class SeqModel:
             else:
                 l = eng.eval_loss(d)
             tot += l * float(len(idx))
-        return float(tot.item()) / max(N, 1)
+        out = float(tot.item()) / max(N, 1)
+        eng.check_status()                 # the epoch's host sync: raise if a kernel reported a failure (Engine.check_status)
+        return out
 
     def fit(self, x, y, validation_data=None, epochs=10, batch_size=100, verbose=1, callbacks=None, shuffle=True):
         if self.optimizer is None:
@@ -475,6 +477,8 @@ class SeqModel:
                 tot += float(l.item()) * nb
                 n += nb
             logs = {"loss": tot / max(n, 1)}
+            if steps_per_epoch:
+                eng.check_status()
             if validation_data is not None:
                 if hasattr(validation_data, "__next__"):
                     vt = vn = 0.0

@@ -18,16 +18,22 @@ from helpers import make_sessions, pad_batch       # noqa: E402
 
 
 def _poison_empty():
-    """SEQREC_POISON=1 (developer switch): every torch.empty on the GPU comes back filled with NaN / a huge negative int, so a
-    kernel that reads memory nobody wrote shows up as NaN or a wild index instead of depending on what the caching
-    allocator happened to hand out."""
+    """SEQREC_POISON=1: every torch.empty on the GPU comes back filled with 1e30 (SEQREC_POISON=nan: NaN) / a huge negative
+    int, so a kernel that reads memory nobody wrote cannot depend on what the caching allocator happened to hand out.
+    The float poison is a huge FINITE value on purpose: in the Keras clip rule `norm >= clipnorm` is false for NaN (scale 1,
+    the step goes through with NaN weights only if the NaN reaches a weight), while one 1e30 in any gradient makes the
+    squared norm overflow -- the case that turns the step into a no-op (clip scale 0) and that seqrec_opt_apply now
+    refuses with SEQREC_STATUS_BAD_NORM, raised by Engine.check_status().  The int poison stays negative: a negative
+    row index is a filler by contract (zero row / ignored contribution); a positive wild index would be an out-of-bounds
+    WRITE in the scatter, i.e. a GPU fault."""
     real = torch.empty
+    fill = float("nan") if os.environ.get("SEQREC_POISON") == "nan" else 1e30
 
     def empty(*a, **k):
         t = real(*a, **k)
         if t.is_cuda and t.numel():
             if t.dtype.is_floating_point:
-                t.fill_(float("nan"))
+                t.fill_(fill)
             elif t.dtype in (torch.int32, torch.int64):
                 t.fill_(-(2 ** 30))
         return t
@@ -82,26 +88,11 @@ def main():
             d = prepared[s]
             if eng.unified and s == 0:
                 ev = float(eng.eval_loss(d, step=s).item())          # forward only, same negatives, same weights
-            if os.environ.get("SEQREC_DIST_DEBUG"):
-                def cs(t):
-                    return int(t.long().sum().item()) if t.dtype in (torch.int32, torch.int64) else float(t.double().sum().item())
-                xen_dbg, neg_dbg = eng._rows_in(d, s) if eng.unified else (None, None)
-                print("DBG", case["cell"], case["H"], "rank", rank, "step", s, "n", d["n"], file=open(os.path.join(os.environ["SEQREC_DIST_DEBUG"], "rank%d.txt" % rank), "a"), end=" ")
-                print(
-                      {k: cs(d[k]) for k in ("ids", "tgt", "take_idx", "send_idx", "neg_slots", "id_slots", "negid_idx", "back_idx") if k in d},
-                      "xen", None if xen_dbg is None else [cs(xen_dbg[: d["n"]]), cs(xen_dbg[d["n"]:2 * d["n"]]), cs(xen_dbg[2 * d["n"]:])],
-                      "neg", None if neg_dbg is None else cs(neg_dbg),
-                      "W", cs(eng.P["W"]), "U", cs(eng.P["U"]), "TT", cs(eng.TT) if eng.unified else None,
-                      file=open(os.path.join(os.environ["SEQREC_DIST_DEBUG"], "rank%d.txt" % rank), "a"), flush=True)
             l = eng.train_step(d, lr=0.01, eps=1e-8, clipnorm=1.0, step=s)
             losses.append(float(l.item()))
-            # the update's inputs as the device saw them (a second-step loss that equals "no update at all" was seen on a few
-            # boxes: clip scale 0 would do that -- squared norm inf, or a wild token count)
-            sc_, sq_, nt_ = float(eng.scale.item()), float(eng.sq.item()), float(eng.ntok.item()) if eng.unified else 0.0
-            gmax = {k: float(v.abs().max().item()) for k, v in eng.Gd.items()}      # the (summed) dense gradients survive the update
-            print("update", case["cell"], case["H"], "rank", rank, "step", s, "scale", sc_, "sq", sq_, "ntok", nt_, "max |dense grad|", gmax,
-                  flush=True)
-            assert np.isfinite(sc_) and sc_ > 0.0, (case, rank, s, sc_, sq_, nt_)
+            eng.check_status()       # raises if the update was refused (norm / divisor / scale) or an exchange index was out of range
+            sc_ = float(eng.scale.item())
+            assert np.isfinite(sc_) and sc_ > 0.0, (case, rank, s, sc_)
             if eng.unified and s == 0:
                 assert ev == losses[0], (ev, losses[0])
         if eng.unified:

@@ -560,7 +560,7 @@ def test_fused_optimizer_launches_equal_the_separate_kernels():
         scale = torch.zeros(1, device="cuda")
         if fused:
             call("seqrec_opt_sqnorm", len(sizes), gp, nn, arr, cnt, ptr(sq[0:1]), None, 0, None, st())
-            call("seqrec_opt_apply", len(sizes), pp, ap, gp, nn, arr, cnt, ptr(sq[0:1]), 0.05, 0.01, 1e-8, ptr(scale), ptr(sq[1:2]), None, st())
+            call("seqrec_opt_apply", len(sizes), pp, ap, gp, nn, arr, cnt, ptr(sq[0:1]), 0.05, 0.01, 1e-8, ptr(scale), ptr(sq[1:2]), None, None, st())
             assert sq[1].item() == 0.0                       # the other norm slot was cleared for the next step
         else:
             call("seqrec_sqnorm_multi", len(sizes), gp, nn, ptr(sq[0:1]), st())
@@ -702,45 +702,56 @@ def test_stepwise_scan_vs_oracle_and_persistent(cell, H, B, maxlen, act, graph):
         assert L.load().seqrec_graph_cache_clear() == 0
 
 
+def _run_scan_both_ways(lib, cell, act, H, H_real, rb, XWd, up, dHd, rmask, graph=0):
+    """forward + BPTT through the step-wise entry points -> (Hout, gates, aux, dPre) as numpy"""
+    n, G, ci = rb.n_tok, onn.N_GATES[cell], L.CELL[cell]
+    so = rb.step_off
+    Hout = torch.full((n, H), float("nan"), device="cuda"); gates = torch.full((n, G * H), float("nan"), device="cuda")
+    aux = torch.full((n, H), float("nan"), device="cuda")
+    call("seqrec_rnn_fwd_stepwise", ci, L.ACT[act], H, H_real, rb.T, rb.B, None, so.ctypes.data, ptr(XWd), ptr(Hout), ptr(gates),
+         ptr(aux), ptr(up), ptr(rmask), graph, st())
+    dPre = torch.full((n, G * H), float("nan"), device="cuda")
+    ws = torch.full((2 * n * H,), float("nan"), device="cuda")
+    call("seqrec_rnn_bwd_stepwise", ci, L.ACT[act], H, H_real, rb.T, rb.B, None, so.ctypes.data, n, ptr(dHd), ptr(Hout), ptr(gates),
+         ptr(aux), ptr(dPre), ptr(up), ptr(ws), ptr(rmask), graph, st())
+    torch.cuda.synchronize()
+    return Hout.cpu().numpy(), gates.cpu().numpy(), aux.cpu().numpy(), dPre.cpu().numpy()
+
+
+@pytest.mark.parametrize("cell,rd", [("gru", 0), ("gru", 1), ("lstm", 0), ("lstm", 1), ("simplernn", 0), ("simplernn", 1)])
 @pytest.mark.parametrize("H,B,maxlen,act", [(256, 512, 40, "tanh"), (256, 700, 9, "relu"), (128, 333, 25, "tanh"), (64, 40, 12, "linear"),
-                                            (512, 100, 17, "tanh"), (256, 5, 60, "tanh"), (256, 16, 1, "tanh")])
-def test_cluster_scan_equals_stepwise_scan(H, B, maxlen, act):
-    """The one-launch cluster form of the GRU scan (rnn_cluster.hip: in-kernel exchange between the column-slice
-    workgroups of a row block) against the launch-per-product form on the same inputs: same arithmetic element for
-    element, so Hout / gates / r*h_prev agree bit for bit and dPre to the last bits; run twice (flag epochs advance
-    between calls)."""
+                                            (512, 100, 17, "tanh"), (512, 512, 12, "relu"), (256, 5, 60, "tanh"), (256, 16, 1, "tanh")])
+def test_cluster_scan_equals_stepwise_scan(cell, rd, H, B, maxlen, act):
+    """The one-launch cluster form of the scans (rnn_cluster.hip GRU, rnn_cluster2.hip LSTM / SimpleRNN: in-kernel exchange
+    between the column-slice workgroups of a row block; with and without recurrent dropout) against the launch-per-product
+    form on the same inputs: same arithmetic element for element, so Hout / gates / aux agree bit for bit and dPre to the
+    last bits; run twice (flag epochs advance between calls).  The LSTM forward with recurrent dropout at H = 512 has no
+    cluster form (its masks do not fit the registers next to the kernel slices): both runs are step-wise there."""
     lib = L.load()
     rng = np.random.default_rng(H + B + maxlen)
-    rb, XW, U = packed_scan_inputs(rng, "gru", H, B, maxlen)
-    n = rb.n_tok
-    ci = L.CELL["gru"]
+    rb, XW, U = packed_scan_inputs(rng, cell, H, B, maxlen)
+    n, G = rb.n_tok, onn.N_GATES[cell]
+    ci = L.CELL[cell]
     up = torch.empty(int(lib.seqrec_rnn_upack_floats(ci, H)), device="cuda")
     XWd, Ud = dev(XW), dev(U)
     call("seqrec_rnn_pack_u_stepwise", ci, H, ptr(Ud), ptr(up), st())
-    so = rb.step_off
     dHd = dev((rng.normal(size=(n, H)) * 0.5).astype(np.float32))
+    rmask = dev(((rng.random((G, rb.B, H)) > 0.3) / 0.7).astype(np.float32)) if rd else None
     out = {}
     try:
         for mode in (0, 1, 1):
             lib.seqrec_debug_scan_cluster(mode)
-            Hout = torch.full((n, H), float("nan"), device="cuda"); gates = torch.full((n, 3 * H), float("nan"), device="cuda")
-            aux = torch.full((n, H), float("nan"), device="cuda")
-            call("seqrec_rnn_fwd_stepwise", ci, L.ACT[act], H, H - 3, rb.T, rb.B, None, so.ctypes.data, ptr(XWd), ptr(Hout), ptr(gates),
-                 ptr(aux), ptr(up), None, 0, st())
-            dPre = torch.full((n, 3 * H), float("nan"), device="cuda")
-            ws = torch.full((2 * n * H,), float("nan"), device="cuda")
-            call("seqrec_rnn_bwd_stepwise", ci, L.ACT[act], H, H - 3, rb.T, rb.B, None, so.ctypes.data, n, ptr(dHd), ptr(Hout), ptr(gates),
-                 ptr(aux), ptr(dPre), ptr(up), ptr(ws), None, 0, st())
-            torch.cuda.synchronize()
-            got = (Hout.cpu().numpy(), gates.cpu().numpy(), aux.cpu().numpy(), dPre.cpu().numpy())
+            got = _run_scan_both_ways(lib, cell, act, H, H - 3, rb, XWd, up, dHd, rmask)
             if mode == 0:
                 out = got
             else:
                 for name, x, y in zip(("Hout", "gates", "aux", "dPre"), out, got):
+                    if cell == "simplernn" and name in ("gates", "aux"):
+                        continue                                   # unused by this cell
                     assert np.isfinite(y).all(), name
                     if name == "dPre":
                         # same products and sums, but the element-wise epilogues are separate code (FMA contraction may
-                        # differ), and steps with more than 8 row blocks use the wide tile in the step-wise BPTT (one K
+                        # differ), and steps with more than 8 row blocks use the wide tile in the step-wise GRU BPTT (one K
                         # chain per wave instead of four partial chains): last-bit differences
                         assert np.abs(x - y).max() <= 2e-5 * max(1.0, np.abs(x).max()), name
                     else:
@@ -748,6 +759,138 @@ def test_cluster_scan_equals_stepwise_scan(H, B, maxlen, act):
         assert lib.seqrec_cluster_scan_errors(st()) == 0          # no bounded spin ran out
     finally:
         lib.seqrec_debug_scan_cluster(-1)
+
+
+@pytest.mark.parametrize("cell", ["lstm", "simplernn", "gru"])
+def test_cluster_scan_at_c4_size_vs_oracle(cell):
+    """The default (cluster) form straight against the oracle at BASELINE config 4's cell size: H = 512, 512 sessions,
+    up to 49 steps (LSTM: the reference's own cell, model.py:349-352)."""
+    lib = L.load()
+    H, B, maxlen, act = 512, 512, 49, "tanh"
+    rng = np.random.default_rng(11)
+    rb, XW, U = packed_scan_inputs(rng, cell, H, B, maxlen)
+    n = rb.n_tok
+    dH = (rng.normal(size=(n, H)) * 0.5).astype(np.float32)
+    ref = oracle_scan(cell, act, rb, XW, U, dH)
+    up = torch.empty(int(lib.seqrec_rnn_upack_floats(L.CELL[cell], H)), device="cuda")
+    call("seqrec_rnn_pack_u_stepwise", L.CELL[cell], H, ptr(dev(U)), ptr(up), st())
+    Hout, _, _, dPre = _run_scan_both_ways(lib, cell, act, H, H, rb, dev(XW), up, dev(dH), None)
+    assert np.abs(Hout - ref["H"]).max() <= 3e-5 * max(1.0, np.abs(ref["H"]).max())
+    bad = np.abs(dPre - ref["dPre"]) > 1e-4 * max(1.0, np.abs(ref["dPre"]).max())
+    assert np.isfinite(dPre).all() and bad.mean() < 2e-4, (bad.mean(), np.abs(dPre - ref["dPre"]).max())
+    assert lib.seqrec_cluster_scan_errors(st()) == 0
+
+
+def test_graph_replays_queued_back_to_back_keep_their_own_arguments():
+    """Two DIFFERENT batches with the same number of steps (= the same captured launch sequence) through use_graph = 1,
+    enqueued back to back WITHOUT a host sync behind a long-running kernel -- the second call rewrites graph nodes while the
+    first replay is still queued.  Both results must equal the eager issue bit for bit (rnn_step.hip keeps a ring of
+    executables per sequence and rewrites one only after the event behind its last launch has completed).  Three rounds, so
+    that the ring wraps."""
+    lib = L.load()
+    H, act, cell = 256, "tanh", "lstm"
+    ci, G = L.CELL[cell], 4
+    rng = np.random.default_rng(21)
+    up = torch.empty(int(lib.seqrec_rnn_upack_floats(ci, H)), device="cuda")
+    U = (rng.normal(size=(H, G * H)) * (0.6 / np.sqrt(H))).astype(np.float32)
+    call("seqrec_rnn_pack_u_stepwise", ci, H, ptr(dev(U)), ptr(up), st())
+    batches = []
+    for Bn in (70, 33, 120, 20, 64, 97):
+        sess = [rng.integers(0, 50, size=int(rng.integers(2, 14))).tolist() for _ in range(Bn - 1)] + [list(range(14))]   # same T = 13
+        rb = B_.pack_sessions(sess)
+        assert rb.T == 13
+        n = rb.n_tok
+        batches.append(dict(rb=rb, XW=dev((rng.normal(size=(n, G * H)) * 0.7).astype(np.float32)),
+                            dH=dev((rng.normal(size=(n, H)) * 0.5).astype(np.float32))))
+
+    def run(b, graph):
+        rb, n = b["rb"], b["rb"].n_tok
+        so = rb.step_off
+        o = dict(Hout=torch.full((n, H), float("nan"), device="cuda"), gates=torch.full((n, G * H), float("nan"), device="cuda"),
+                 aux=torch.full((n, H), float("nan"), device="cuda"), dPre=torch.full((n, G * H), float("nan"), device="cuda"),
+                 ws=torch.full((2 * n * H,), float("nan"), device="cuda"))
+        call("seqrec_rnn_fwd_stepwise", ci, L.ACT[act], H, H, rb.T, rb.B, None, so.ctypes.data, ptr(b["XW"]), ptr(o["Hout"]),
+             ptr(o["gates"]), ptr(o["aux"]), ptr(up), None, graph, st())
+        call("seqrec_rnn_bwd_stepwise", ci, L.ACT[act], H, H, rb.T, rb.B, None, so.ctypes.data, n, ptr(b["dH"]), ptr(o["Hout"]),
+             ptr(o["gates"]), ptr(o["aux"]), ptr(o["dPre"]), ptr(up), ptr(o["ws"]), None, graph, st())
+        return o
+    try:
+        lib.seqrec_debug_scan_cluster(0)             # the step-wise form is the one that is captured
+        eager = [run(b, 0) for b in batches]
+        torch.cuda.synchronize()
+        big = torch.randn(8192, 8192, device="cuda")
+        for _ in range(3):
+            big = (big @ big) * 1e-4                 # ~10 ms of queued work: the replays below pile up behind it
+        replay = [run(b, 1) for b in batches]        # no sync in between
+        torch.cuda.synchronize()
+        for e, r in zip(eager, replay):
+            for k in ("Hout", "gates", "aux", "dPre"):
+                np.testing.assert_array_equal(e[k].cpu().numpy(), r[k].cpu().numpy(), err_msg=k)
+        assert lib.seqrec_release_stream(st()) == 0  # drops the captured graphs of this stream (and its cluster flags)
+        assert lib.seqrec_graph_cache_clear() == 0
+    finally:
+        lib.seqrec_debug_scan_cluster(-1)
+
+
+def test_cluster_scan_timeout_is_counted_and_poisons_the_output():
+    """A wait of the cluster kernels that runs out (forced: 1 poll) is counted, and the wave writes NaN into the output it
+    owns instead of leaving a plausible-looking stale value (include/seqrec_hip.h: seqrec_cluster_scan_errors)."""
+    lib = L.load()
+    rng = np.random.default_rng(3)
+    cell, H, act = "lstm", 256, "tanh"
+    rb, XW, U = packed_scan_inputs(rng, cell, H, 200, 30)
+    up = torch.empty(int(lib.seqrec_rnn_upack_floats(L.CELL[cell], H)), device="cuda")
+    call("seqrec_rnn_pack_u_stepwise", L.CELL[cell], H, ptr(dev(U)), ptr(up), st())
+    dHd = dev(np.zeros((rb.n_tok, H), np.float32))
+    assert lib.seqrec_cluster_scan_errors_reset(st()) == 0
+    try:
+        lib.seqrec_debug_cluster_spin_limit(1)
+        Hout, _, _, dPre = _run_scan_both_ways(lib, cell, act, H, H, rb, dev(XW), up, dHd, None)
+        assert lib.seqrec_cluster_scan_errors(st()) > 0
+        assert np.isnan(Hout).any()
+    finally:
+        lib.seqrec_debug_cluster_spin_limit(0)
+        lib.seqrec_cluster_scan_errors_reset(st())
+    Hout, _, _, _ = _run_scan_both_ways(lib, cell, act, H, H, rb, dev(XW), up, dHd, None)
+    assert np.isfinite(Hout).all() and lib.seqrec_cluster_scan_errors(st()) == 0
+
+
+def test_opt_apply_refuses_a_degenerate_scale_and_reports_it():
+    """seqrec_opt_apply with a squared norm of inf (what one overflowing gradient value produces: clip scale 0, the whole
+    step a silent no-op), NaN, a negative number, or a zero / non-finite divisor: SEQREC_STATUS_* is set and NOTHING is
+    written (weights, accumulators); a healthy call leaves the status word alone."""
+    rng = np.random.default_rng(8)
+    n = 5000
+    p0 = rng.normal(size=n).astype(np.float32); g0 = rng.normal(size=n).astype(np.float32)
+    for sqv, div, want in ((float("inf"), None, 1), (float("nan"), None, 1), (-1.0, None, 1), (4.0, 0.0, 2), (4.0, float("inf"), 2),
+                           (4.0, float("nan"), 2), (4.0, None, 0), (4.0, 3.0, 0)):
+        p, a, g = dev(p0.copy()), dev(np.zeros(n, np.float32)), dev(g0)
+        sq, scale = dev(np.array([sqv], np.float32)), dev(np.zeros(1, np.float32))
+        dv = None if div is None else dev(np.array([div], np.float32))
+        status = torch.zeros(1, dtype=torch.int32, device="cuda")
+        call("seqrec_opt_apply", 1, L.ptr_array([p]), L.ptr_array([a]), L.ptr_array([g]), L.i64_array([n]), None, 0, ptr(sq), 1.0, 0.01,
+             1e-8, ptr(scale), None, ptr(dv), ptr(status), st())
+        assert int(status.item()) == want, (sqv, div, int(status.item()))
+        if want:
+            np.testing.assert_array_equal(p.cpu().numpy(), p0)
+            assert float(a.abs().sum().item()) == 0.0
+        else:
+            assert np.abs(p.cpu().numpy() - p0).max() > 0
+
+
+def test_gather_rows_bounded_flags_an_index_outside_the_table():
+    rng = np.random.default_rng(2)
+    tab = rng.normal(size=(50, 64)).astype(np.float32)
+    ids = np.array([3, -1, 49, 50, 7, 10 ** 6], np.int32)
+    out = torch.full((6, 64), float("nan"), device="cuda")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    call("seqrec_gather_rows_bounded", ptr(dev(tab)), 50, ptr(dev(ids)), ptr(out), 6, 64, None, None, 0, ptr(status), st())
+    o = out.cpu().numpy()
+    np.testing.assert_array_equal(o[[0, 2, 4]], tab[[3, 49, 7]])
+    assert np.all(o[[1, 3, 5]] == 0) and int(status.item()) == 8
+    status.zero_()
+    call("seqrec_gather_rows_bounded", ptr(dev(tab)), 50, ptr(dev(ids[:3])), ptr(out), 3, 64, None, None, 0, ptr(status), st())
+    assert int(status.item()) == 0
 
 
 @pytest.mark.parametrize("cell,H,B,maxlen", [("gru", 256, 300, 30), ("gru", 128, 77, 12), ("lstm", 64, 50, 9)])

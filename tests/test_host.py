@@ -21,7 +21,7 @@ def test_library_exports_every_symbol_in_the_header():
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(L.EXPORTS) == declared
-    assert lib.seqrec_abi_version() == 3
+    assert lib.seqrec_abi_version() == 4
     assert lib.seqrec_build_arch() == b"gfx950"
     # argument validation happens on the host, before any launch: callable without a GPU
     assert lib.seqrec_gather_rows(None, None, None, -1, 8, None, None, 0, None) == -1
@@ -156,7 +156,8 @@ def test_c_abi_rejects_bad_arguments_before_any_launch():
     assert lib.seqrec_rows_adagrad(None, one, one, one, one, 4, 8, 0, 0.01, 1e-8, one, None) == E_ARG
     assert lib.seqrec_opt_sqnorm(0, None, None, None, 0, one, None, 0, None, None) == E_ARG                                      # nothing to do is an error
     assert lib.seqrec_opt_sqnorm(9, one, one, None, 0, one, None, 0, None, None) == E_ARG                                        # > 8 dense tensors
-    assert lib.seqrec_opt_apply(1, None, None, one, one, None, 0, one, 1.0, 0.01, 1e-8, one, None, None, None) == E_ARG
+    assert lib.seqrec_opt_apply(1, None, None, one, one, None, 0, one, 1.0, 0.01, 1e-8, one, None, None, None, None) == E_ARG
+    assert lib.seqrec_gather_rows_bounded(one, 0, one, one, 4, 8, None, None, 0, None, None) == E_ARG                       # a bound of 0 rows
     assert lib.seqrec_sample_negatives(1, 0, 4, None, None, 10, one, None) == E_ARG
     assert lib.seqrec_sample_gather(1, 0, 4, one, one, 10, one, 0, None, one, one, None, None) == E_ARG           # width 0
     assert lib.seqrec_dropout_mask(1, 2, one, 4, 8, 4, 0.5, one, None) == E_ARG                                   # ld < width
