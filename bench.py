@@ -162,20 +162,41 @@ class BatchStream:
         return self._perm[j * self.batch:(j + 1) * self.batch]
 
 
-def kernel_model(cfgd, n_tok, K, B):
+def kernel_model(cfgd, n_tok, K, B, slabs=None, uniq=None, upack_floats=0):
     """Algorithmic work per launch of every kernel class at n_tok tokens (SURVEY 8d formulas):
-    name -> (bound, flops or bytes)."""
+    name -> (bound, flops or bytes[, extra]).  MFMA kernels: flops of the product.  HBM kernels (the gather /
+    scatter-update side): bytes the launch must move by its interface -- every input read once, every output written once, an
+    in-place accumulate = read + write, rows counted DISTINCT where the kernel touches a row once per distinct id (`uniq`:
+    measured distinct / listed ratio of the input and target lists of this data set; the K negatives are taken as distinct).
+    slabs: split-K slab counts the step actually used (Engine.last_counts) -- a slab operand is an input of the launch that
+    reads it.  extra (dict): secondary figures, e.g. the HBM rate of the rows an MFMA kernel gathers."""
     H, D = cfgd["H"], cfgd["D"]
     G = 3 if cfgd["cell"] == "gru" else (4 if cfgd["cell"] == "lstm" else 1)
+    tied = bool(cfgd.get("tied", False))
+    sl = dict(dX=1, dEneg=1, wgrad=1)
+    sl.update({k: max(1, int(v)) for k, v in (slabs or {}).items()})
+    u_in, u_tg = (uniq or (1.0, 1.0))
+    dense = float(G * H * (D + H + 1))                                    # W, U, b
+    # the step's scatter lists: input rows (E, width D), target rows and negative rows (Eout, width H)
+    lists = [(n_tok, D, sl["dX"]), (n_tok, H, 1), (K, H, sl["dEneg"])]
+    listed = sum(n * w for n, w, _ in lists)                               # row elements listed
+    distinct = n_tok * u_in * D + n_tok * u_tg * H + K * H                 # row elements of distinct rows
+    scatter_b = sum(4.0 * n * w * s for n, w, s in lists) + 4.0 * sum(n for n, _, _ in lists) + 8.0 * listed
+    norm_b = 4.0 * dense * (sl["wgrad"] + 1) + 4.0 * distinct + 8.0 * sum(n for n, _, _ in lists) + 4.0 * n_tok
+    apply_b = 20.0 * dense + 24.0 * distinct + 8.0 * sum(n for n, _, _ in lists)
+    ce_b = 8.0 * n_tok * K + 8.0 * n_tok * H + 16.0 * n_tok + 8.0 * K
+    pack_b = 4.0 * G * H * H + 4.0 * upack_floats + 8.0 * K * H + 4.0 * K
+    batch_b = 20.0 * n_tok + 12.0 * B
     m = {
         "seqrec_rnn_fwd": ("mfma", 2.0 * G * H * H * n_tok),
         "seqrec_rnn_bwd": ("mfma", 2.0 * G * H * H * n_tok),
-        # step-wise scan: one C-ABI call = all its per-step launches; work and time are per CALL
+        # step-wise entry points: one C-ABI call = the whole scan (cluster form: one launch); work and time are per CALL
         "seqrec_rnn_fwd_stepwise": ("mfma", 2.0 * G * H * H * n_tok),
         "seqrec_rnn_bwd_stepwise": ("mfma", 2.0 * G * H * H * n_tok),
         "seqrec_gemm_f32[xw]": ("mfma", 2.0 * n_tok * D * G * H),
-        "seqrec_gemm_f32_fused[xw]": ("mfma", 2.0 * n_tok * D * G * H),      # embedding rows read through the ids
-        "seqrec_gemm_f32_fused[dH]": ("mfma", 2.0 * n_tok * K * H),          # + the target-row term in the final write
+        # embedding rows read through the ids: the gather of north_star's "HBM GB/s for the gather" lives in this launch
+        "seqrec_gemm_f32_fused[xw]": ("mfma", 2.0 * n_tok * D * G * H, {"gather_bytes": 4.0 * D * n_tok}),
+        "seqrec_gemm_f32_fused[dH]": ("mfma", 2.0 * n_tok * K * H, {"gather_bytes": 4.0 * H * n_tok}),     # + the target-row term in the final write
         "seqrec_gemm_f32[logits]": ("mfma", 2.0 * n_tok * K * H),
         "seqrec_gemm_f32[dH]": ("mfma", 2.0 * n_tok * K * H),
         "seqrec_gemm_f32[dEneg]": ("mfma", 2.0 * n_tok * K * H),
@@ -185,10 +206,28 @@ def kernel_model(cfgd, n_tok, K, B):
         "seqrec_gemm_f32[dX]": ("mfma", 2.0 * n_tok * D * G * H),
         "seqrec_gemm_f32[dU]": ("mfma", 2.0 * n_tok * H * G * H / (2 if G == 3 else 1)),   # GRU: two launches
         "seqrec_gemm_f32_grouped[dW+dU]": ("mfma", 2.0 * n_tok * G * H * (D + H)),          # dW and dU in one launch
-        "seqrec_gemm_f32_grouped_slabs[dW+dU]": ("mfma", 2.0 * n_tok * G * H * (D + H)),    # slabs finished by the norm launch
-        "seqrec_gather_rows[E]": ("hbm", 8.0 * D * n_tok),                                   # 4 B read + 4 B written / elt
+        "seqrec_gemm_f32_grouped_slabs[dW+dU]": ("mfma", 2.0 * n_tok * G * H * (D + H),     # slabs finished by the norm launch
+                                                 {"gather_bytes": 4.0 * (D + H) * n_tok}),   # E[ids] and Hout[prev] read through their index
+        # ---- the HBM side: gather / scatter-update kernels against the HBM peak
+        "seqrec_rows_scatter_add_multi": ("hbm", scatter_b),
+        "seqrec_opt_sqnorm_slabs": ("hbm", norm_b),
+        "seqrec_opt_sqnorm": ("hbm", 4.0 * dense + 4.0 * distinct + 8.0 * sum(n for n, _, _ in lists) + 4.0 * n_tok),
+        "seqrec_opt_apply": ("hbm", apply_b),
+        "seqrec_sampled_softmax_ce": ("hbm", ce_b),
+        "seqrec_rnn_pack_u_sample": ("hbm", pack_b),
+        "seqrec_pack_batch_host": ("hbm", batch_b),
+        "seqrec_gather_rows[E]": ("hbm", 8.0 * D * n_tok),                                   # 4 B read + 4 B written / elt (dropout path only)
     }
+    if tied:
+        pass          # same formula: one table takes all three lists
     return m
+
+
+def lib_sha16():
+    """sha256[:16] of the loaded libseqrec_hip.so: stamps what a committed PMC pass was taken on."""
+    import hashlib
+    L = importlib.import_module("seq-recommendations_amd._lib")
+    return hashlib.sha256(open(L.LIB_PATH, "rb").read()).hexdigest()[:16]
 
 
 def _latest_profile(pattern):
@@ -206,9 +245,12 @@ def pmc_traffic(kernel, t_mean, a):
     if a.config != "c3" or a.saturated or not path:
         return None
     pm = json.load(open(path))
-    src = os.path.relpath(path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+    taken_on = pm.pop("_lib_sha16", None)
+    src = os.path.relpath(path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; library %s)" % (taken_on or "unstamped")
+    if taken_on != lib_sha16():
+        return {"bytes_per_call": None, "source": src + " -- NOT this build (%s): dropped" % lib_sha16()}
     # cluster form of the scan: the call IS one launch
-    one = {"seqrec_rnn_fwd_stepwise": "gru_cluster_fwd<4, 0>", "seqrec_rnn_bwd_stepwise": "gru_cluster_bwd<4, 0>"}.get(kernel)
+    one = {"seqrec_rnn_fwd_stepwise": "gru_cluster_fwd<4, 0", "seqrec_rnn_bwd_stepwise": "gru_cluster_bwd<4, 0"}.get(kernel)
     ent = next((v for k, v in pm.items() if one and one in k), None)
     if ent is not None and os.environ.get("SEQREC_SCAN_CLUSTER", "1") != "0":
         return {"bytes_per_call": round((ent["fetch_kib_x2"] + ent["write_kib"]) * 1024.0), "source": src}
@@ -238,10 +280,14 @@ def pmc_mfma_util(kernel, a):
     if not frag:
         return None
     pm = json.load(open(path))
+    taken_on = pm.pop("_lib_sha16", None)
+    src = os.path.relpath(path, ROOT) + " (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; library %s)" % (taken_on or "unstamped")
+    if taken_on != lib_sha16():
+        return {"source": src + " -- NOT this build (%s): dropped" % lib_sha16()}
     out = {k[k.index("gru_"):k.index(">") + 1]: v["mfma_util"] for k, v in pm.items() if frag in k}
     if not out:
         return None
-    out["source"] = os.path.relpath(path, ROOT) + " (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE)"
+    out["source"] = src
     return out
 
 
@@ -498,7 +544,7 @@ def main(argv=None):
     # how the scan's launches are issued is decided per box (fast host core: eager; slow one: rewritten hipGraph) on
     # untimed training steps -- Engine.autotune_scan; SEQREC_SCAN_GRAPH=0/1 pins it
     scan_issue = None
-    cluster = cd["cell"] == "gru" and os.environ.get("SEQREC_SCAN_CLUSTER", "1") != "0"      # one launch per scan call: nothing to tune
+    cluster = os.environ.get("SEQREC_SCAN_CLUSTER", "1") != "0"      # every cell has a cluster form: one launch per scan call, nothing to tune
     if cluster:
         scan_issue = {"scan_issue": "one launch per call"}
     elif not sharded and "SEQREC_SCAN_GRAPH" not in os.environ and a.tune_steps > 0:
@@ -519,12 +565,17 @@ def main(argv=None):
         step += 1
     sync()
     first_timed = len(tok_seen)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]     # one event per step: the median next to the mean
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(a.steps):
         loss = train(step)
+        marks[i + 1].record()
         step += 1
     sync()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    ms_median = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -558,14 +609,26 @@ def main(argv=None):
             prof = E.profile_stop()
             n_prof = float(np.mean([t[0] for t in tok_seen[mark:]]))
             t_prof = float(np.mean([t[1] for t in tok_seen[mark:]]))
-            model = kernel_model(cd, n_prof, K, a.batch)
+            # distinct / listed rows of the input and target lists, measured on 8 batches of this data set (host)
+            ui, ut = [], []
+            for j in range(8):
+                sel_j = stream.sel(j)
+                ids_j = np.concatenate([flat[starts[x]:starts[x + 1] - 1] for x in sel_j])
+                tgt_j = np.concatenate([flat[starts[x] + 1:starts[x + 1]] for x in sel_j])
+                ui.append(len(np.unique(ids_j)) / max(len(ids_j), 1)); ut.append(len(np.unique(tgt_j)) / max(len(tgt_j), 1))
+            uniq = (float(np.mean(ui)), float(np.mean(ut)))
+            model = kernel_model(cd, n_prof, K, a.batch, slabs=getattr(eng, "last_counts", None), uniq=uniq,
+                                 upack_floats=int(eng.upack.numel()))
             tot = sum(ms for _, ms in prof.values())
             for name, (cnt, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
                 per = ms / cnt
                 ent = {"launches_per_step": cnt / a.profile_steps, "avg_us": round(per * 1e3, 2),
                        "share": round(ms / tot, 4)}
                 if name in model:
-                    bound, work = model[name]
+                    bound, work = model[name][:2]
+                    extra = model[name][2] if len(model[name]) > 2 else {}
+                    if "gather_bytes" in extra:      # rows this MFMA kernel reads through an index: their HBM-side rate
+                        ent.update(gather_bytes=round(extra["gather_bytes"]), gather_GBps=round(extra["gather_bytes"] / (per * 1e-3) / 1e9, 1))
                     if bound == "mfma":
                         ach = work / (per * 1e-3) / 1e12
                         ent.update(bound="mfma", achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
@@ -573,7 +636,7 @@ def main(argv=None):
                     else:
                         ach = work / (per * 1e-3) / 1e9
                         ent.update(bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                                   frac=round(ach / PEAK_HBM_GBS, 5))
+                                   frac=round(ach / PEAK_HBM_GBS, 5), bytes=round(work))
                 kern[name] = ent
             dom = next((k for k in kern if "bound" in kern[k]), None)
             if dom:
@@ -581,7 +644,7 @@ def main(argv=None):
                 tr = pmc_traffic(dom, t_prof, a)
                 roof = {"kernel": dom, "bound": e["bound"], "achieved": e["achieved"], "peak": e["peak"], "unit": e["unit"],
                         "frac": e["frac"], "traffic": tr["bytes_per_call"] if tr else None,
-                        "traffic_unit": "HBM-side bytes per call (FETCH_SIZE x2 + WRITE_SIZE)" if tr else None,
+                        "traffic_unit": "HBM-side bytes per call (FETCH_SIZE x2 + WRITE_SIZE)" if tr and tr["bytes_per_call"] else None,
                         "traffic_source": tr["source"] if tr else None, "pmc_mfma_util": pmc_mfma_util(dom, a),
                         "avg_us": e["avg_us"], "share_of_step": e["share"], "tokens_per_call": round(n_prof, 1)}
         except Exception as e:                                   # noqa: BLE001
@@ -664,12 +727,14 @@ def main(argv=None):
         except Exception as e:                                   # noqa: BLE001
             notes.append("cpu_baseline leg failed: %r" % (e,))
 
+    eng.check_status()          # a device-side failure anywhere in the run (refused update, exchange timeout, bad index) fails the bench
     if rank == 0:
         mode = ("resident: %d pre-built batches cycled" % len(resident)) if resident else \
             "fresh batches: %d-session train set in HBM, batch built on the device inside the timed region, reshuffled per epoch" % n_train
         out = {
             "metric": "sessions/sec", "value": round(sessions_per_s, 1), "unit": "sessions/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step_median": round(ms_median, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cd["desc"] + (" (saturated: 50 items/session)" if a.saturated else " (MSNBC-shaped lengths)"),
                        "global_batch": a.batch * world, "seq_len": 50, "tokens_per_step_per_gpu": round(n_tok_mean, 1),
@@ -679,11 +744,11 @@ def main(argv=None):
                        "parallelism": ("dp%d+row-sharded-tables" % world) if sharded else "single"},
             "tokens_per_s": round(tokens_per_s, 1), "final_loss": round(last_loss, 5), "recall_at_20": recall,
             "recall_after_steps": step if recall is not None else None,
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "kernels": kern,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "kernels": kern, "lib_sha16": lib_sha16(),
         }
         # the cluster scan kernels wait in bounded spins; a healthy run has none that ran out
         out["config"]["scan"] = dict(scan_issue or {}, form="cluster (one launch, in-kernel exchange)" if
-                                     os.environ.get("SEQREC_SCAN_CLUSTER", "1") != "0" and cd.get("cell", "gru") == "gru" else "step-wise",
+                                     os.environ.get("SEQREC_SCAN_CLUSTER", "1") != "0" else "step-wise",
                                      exchange_timeouts=int(importlib.import_module("seq-recommendations_amd._lib").load().seqrec_cluster_scan_errors(
                                          torch.cuda.current_stream().cuda_stream)))
         if notes:

@@ -208,6 +208,7 @@ template <int N> __device__ __forceinline__ void ld_mask(float (&m)[N], const fl
 template <int ACT>
 __device__ __forceinline__ void lstm_cell_fwd(float pi, float pf, float pc, float po, float cp, bool live, float& gi, float& gf, float& gg,
                                               float& go, float& c, float& h) {
+#pragma clang fp contract(off)      // a*b + c*d may contract either way: without this the two forms round c differently
     gi = hard_sigmoid(pi); gf = hard_sigmoid(pf); gg = act_fwd<ACT>(pc); go = hard_sigmoid(po);
     c = gf * cp + gi * gg;
     h = go * act_fwd<ACT>(c);
@@ -217,6 +218,7 @@ __device__ __forceinline__ void lstm_cell_fwd(float pi, float pf, float pc, floa
 template <int ACT>
 __device__ __forceinline__ void lstm_cell_bwd(float dh, float dcin, float gi, float gf, float gg, float go, float cn, float cp,
                                               float& di, float& df, float& dg, float& dout, float& dc_prev) {
+#pragma clang fp contract(off)
     const float ac = act_fwd<ACT>(cn);
     const float dct = dcin + dh * go * act_grad<ACT>(ac);
     di = dct * gg * hard_sigmoid_grad(gi);

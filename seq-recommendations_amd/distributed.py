@@ -609,6 +609,39 @@ class ShardedEngine(Engine):
             out = {k: v / np.float32(nt) for k, v in out.items()}
         return loss, out
 
+    def failure_report(self):
+        """After check_status() raised: where the non-finite value sits.  For every buffer the last unified step wrote, the number
+        of non-finite entries and the largest finite magnitude over the region the step used -- the first buffer of the step's
+        dataflow with a non-zero count is where the failure entered (test / support aid; synchronises)."""
+        if not self.unified or not hasattr(self, "_last"):
+            return {}
+        L, c = self._last, self.cfg
+        n, K, w = L["n"], c.K, self.Hp
+
+        def stat(t):
+            t = t.detach().float().reshape(-1)
+            fin = torch.isfinite(t)
+            mx = float(t[fin].abs().max().item()) if bool(fin.any()) else 0.0
+            return (int((~fin).sum().item()), mx)
+        ws, out = self.ws, {}
+        reg = {"xen[in]": ("xen", 0, n * w), "xen[tgt]": ("xen", n * w, 2 * n * w), "xen[neg]": ("xen", 2 * n * w, (2 * n + K) * w),
+               "XW": ("XW", 0, n * self.GHp), "Hout": ("Hout", 0, n * w), "gates": ("gates", 0, n * self.GHp), "aux": ("aux", 0, n * w),
+               "ln(dlogits)": ("ln", 0, n * K), "dlt": ("dlt", 0, n), "loss_rows": ("loss_rows", 0, n), "dHd": ("dHd", 0, n * w),
+               "dPre": ("dPre", 0, n * self.GHp), "gall[dX]": ("gall", 0, n * w), "gall[dEtgt]": ("gall", n * w, 2 * n * w),
+               "gall[dEneg]": ("gall", 2 * n * w, (2 * n + K) * w), "backbuf": ("backbuf", 0, L["n_tot"] * w),
+               "sendbuf": ("sendbuf", 0, L["m_tot"] * w)}
+        for name, (buf, lo, hi) in reg.items():
+            if buf in ws:
+                out[name] = stat(ws[buf][lo:hi])
+        out["gback"] = stat(L["gback"])
+        for k in sorted(self.Gd):
+            out["Gd[%s]" % k] = stat(self.Gd[k])
+        rows = L["send_idx"].long()
+        rows = rows[rows >= 0]
+        out["TG[touched rows]"] = stat(self.TG[rows])
+        out["sq"], out["ntok"], out["scale"] = float(self.sq.item()), float(self.ntok.item()), float(self.scale.item())
+        return out
+
     def _wait_ready(self, d):
         ev = d.get("ready")
         if ev is not None:
@@ -774,6 +807,7 @@ class ShardedEngine(Engine):
         job, cnt = _lib.rows_jobs([dict(table=self.TT, accum=self.TA, gtab=self.TG, slot=self.TS, rows=send_idx, vals=gback,
                                         ldv=w, row_scale=None, n=plan.m_tot, width=w, base=0)])
         call("seqrec_rows_scatter_add_multi", job, cnt, st)
+        self._last = {"gback": gback, "send_idx": send_idx, "n": n, "m_tot": plan.m_tot, "n_tot": plan.n_tot}    # what a failure report names
         if not apply_update:
             return None
         call("seqrec_fill_f32", ptr(self.sq), 0.0, 1, st)

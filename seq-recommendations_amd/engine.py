@@ -1027,6 +1027,10 @@ class Engine:
                 wg_slabs = (descs, len(wgrad), int(ns.value), wsp)
             else:
                 call("seqrec_gemm_f32_grouped", len(wgrad), 0, 0, _lib.gemm_descs(wgrad), sk, ptr(wsp), st, tag="dW+dU")
+        self.last_counts = {"wgrad": wg_slabs[2] if wg_slabs is not None else 1}      # split-K slab counts of this step (bench.py's byte models)
+        for j in sparse_jobs:
+            if j.get("n_slabs", 0) > 1:
+                self.last_counts["dX" if j["name"] == "E" and j["rows"] is d.get("ids") else "dEneg"] = j["n_slabs"]
         if join_side:
             torch.cuda.current_stream(self.dev).wait_event(self._ev_join)
         # ---- row-sparse contributions: one launch for (up to 4) scatter lists

@@ -90,7 +90,11 @@ def main():
                 ev = float(eng.eval_loss(d, step=s).item())          # forward only, same negatives, same weights
             l = eng.train_step(d, lr=0.01, eps=1e-8, clipnorm=1.0, step=s)
             losses.append(float(l.item()))
-            eng.check_status()       # raises if the update was refused (norm / divisor / scale) or an exchange index was out of range
+            try:
+                eng.check_status()   # raises if the update was refused (norm / divisor / scale) or an exchange index was out of range
+            except Exception:
+                print("FAILURE REPORT rank %d case %s step %d: %s" % (rank, case, s, eng.failure_report()), flush=True)
+                raise
             sc_ = float(eng.scale.item())
             assert np.isfinite(sc_) and sc_ > 0.0, (case, rank, s, sc_)
             if eng.unified and s == 0:

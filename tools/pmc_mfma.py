@@ -31,8 +31,11 @@ def main():
             continue
         res[k] = {"calls": cnt[k], "mfma_busy_cycles_per_call": round(busy / cnt[k]), "gui_active_cycles_per_call": round(gui / cnt[k]),
                   "mfma_util": round((busy / 1024.0) / (gui / 8.0), 4)}
+    import hashlib, os
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "seq-recommendations_amd", "libseqrec_hip.so")
+    res["_lib_sha16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]      # bench.py drops figures taken on another build
     json.dump(res, open(out, "w"), indent=1)
-    for k, v in sorted(res.items(), key=lambda kv: -kv[1]["mfma_util"]):
+    for k, v in sorted(((k, v) for k, v in res.items() if isinstance(v, dict)), key=lambda kv: -kv[1]["mfma_util"]):
         print("%-90s util %.3f  calls %d" % (k, v["mfma_util"], v["calls"]))
 
 

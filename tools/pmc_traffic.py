@@ -34,8 +34,11 @@ def main():
         f = fa[k][1] / fa[k][0] if k in fa and fa[k][0] else 0.0
         w = wa[k][1] / wa[k][0] if k in wa and wa[k][0] else 0.0
         res[k] = {"calls": n, "fetch_kib_raw": round(f, 2), "fetch_kib_x2": round(2 * f, 2), "write_kib": round(w, 2)}
+    import hashlib, os
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "seq-recommendations_amd", "libseqrec_hip.so")
+    res["_lib_sha16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]      # bench.py drops figures taken on another build
     json.dump(res, open(out, "w"), indent=1)
-    print("wrote", out, len(res), "kernels")
+    print("wrote", out, len(res) - 1, "kernels")
 
 
 if __name__ == "__main__":
