@@ -58,7 +58,8 @@ extern "C" {
 /* 3: seqrec_rows_job grew (n_slabs, slab_stride); new entry points seqrec_gemm_f32_slabs, seqrec_gemm_f32_grouped_slabs,
  *    seqrec_opt_sqnorm_slabs, seqrec_pack_batch_host, seqrec_rnn_pack_u_sample, seqrec_rnn_bwd_stepwise_parts */
 /* 4: seqrec_opt_apply takes a status word; new entry points seqrec_gather_rows_bounded, seqrec_release_stream,
- *    seqrec_cluster_scan_errors_reset, seqrec_debug_cluster_spin_limit; the packed layout of the step-wise LSTM forward
+ *    seqrec_cluster_scan_errors_reset, seqrec_debug_cluster_spin_limit, seqrec_exchange_pack / _unpack / _grad_pack,
+ *    seqrec_sampled_softmax_ce_rows_idx; the packed layout of the step-wise LSTM forward
  *    kernel changed (seqrec_rnn_pack_u_stepwise and the scans of one library always agree) */
 #define SEQREC_ABI_VERSION 4
 
@@ -264,6 +265,12 @@ int seqrec_sampled_softmax_ce_rows(float* ln, int64_t ld, const float* hd, int H
                                    const float* lq_tgt, const float* lq_neg, const int32_t* tgt,
                                    const int32_t* neg, int64_t n, int K, float inv_denom,
                                    float* loss_rows, float* dlt, void* stream);
+/*      the same with the target rows read THROUGH an index -- row i of the target table is table[tgt_row[i] * table_ld + :]
+ *      (the received rows of the exchange buffer; no staging copy) */
+int seqrec_sampled_softmax_ce_rows_idx(float* ln, int64_t ld, const float* hd, int H, const float* table, int64_t table_ld,
+                                       const int32_t* tgt_row, const float* lq_tgt, const float* lq_neg, const int32_t* tgt,
+                                       const int32_t* neg, int64_t n, int K, float inv_denom, float* loss_rows, float* dlt,
+                                       void* stream);
 /* ---- out[0] (+)= sum_i x[i], one workgroup, fixed summation order (deterministic) */
 int seqrec_reduce_sum(const float* x, int64_t n, float* out, int accumulate, void* stream);
 
@@ -282,6 +289,29 @@ int seqrec_fill_i32(int32_t* x, int32_t v, int64_t n, void* stream);
  *      buffers bit-exactly (no float arithmetic ever touches them). */
 int seqrec_index_affine_i32(int32_t* dst, const int32_t* dst_pos, const int32_t* src, const int32_t* src_pos,
                             int64_t n, int32_t mul, int32_t add, void* stream);
+
+/* ---- row exchange of the multi-GPU step (distributed.py; SURVEY 8e: tables row-sharded, rows moved by all-to-all; no
+ *      reference counterpart).  One launch on each side of the step's two collectives:
+ *      exchange_pack (owner, before all-to-all #1): sendbuf[j,:] for the m_tot owner-side rows -- kinds[j] >= 0: table row
+ *        kinds[j] (>= table_rows: zero row + SEQREC_STATUS_BAD_INDEX); -1: an id row; -2: a negative row.  The rank's n_neg
+ *        stratified draws (seqrec_sample_negatives(seed, step, n_neg, ...), per_peer per requester) are drawn here: draw i
+ *        -> table row row_offset + id, copied to sendbuf[neg_slots[i]]; id row r of peer p (id_rows[p * n_id_rows / R + r])
+ *        carries the draws' global ids id * id_mul + id_add bit-cast into the float buffer.  rows_eff[j] (m_tot) receives
+ *        the table row every owner-side row stands for (-1: none) -- the scatter list of the returning gradients.
+ *      exchange_unpack (requester, after it): Eneg[k,:] = recv[neg_rows[k],:], neg[k] = ((int32*)recv)[negid_idx[k]],
+ *        lq_neg[k] = logq[neg[k]] (nullable).
+ *      exchange_grad_pack (requester, before all-to-all #2): out[j,:] for the n_tot requester-side rows, b = back_idx[j]:
+ *        b < 0 zero; b < n: sum of the dx_slabs split-K slabs of dX row b; b < 2n: dlt[b-n] * Hd[b-n,:]; else the sum of the
+ *        dn_slabs slabs of dEneg row b - 2n (seqrec_gemm_f32_slabs products: no reduce launch, no staging copy). */
+int seqrec_exchange_pack(const float* table, int64_t table_rows, int width, const int32_t* kinds, int64_t m_tot,
+                         uint64_t seed, uint64_t step, int n_neg, const uint32_t* thresh, const int32_t* alias, int V_local,
+                         int32_t row_offset, const int32_t* neg_slots, const int32_t* id_rows, int n_id_rows, int per_peer,
+                         int32_t id_mul, int32_t id_add, float* sendbuf, int32_t* rows_eff, uint32_t* status, void* stream);
+int seqrec_exchange_unpack(const float* recv, int width, const int32_t* neg_rows, const int32_t* negid_idx, int K,
+                           const float* logq, float* Eneg, int32_t* neg, float* lq_neg, void* stream);
+int seqrec_exchange_grad_pack(const int32_t* back_idx, int64_t n_tot, int n, int K, int width, const float* dX, int dx_slabs,
+                              int64_t dx_stride, const float* Hd, const float* dlt, const float* dEneg, int dn_slabs,
+                              int64_t dn_stride, float* out, void* stream);
 
 /* ---- row-sparse gradient path for the item tables (E, Eout, Wk, bout) -- the exact sparse
  *      equivalent of Keras' dense Adagrad (experiments_methods.py:41): a row with zero gradient is

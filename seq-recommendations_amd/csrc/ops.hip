@@ -104,10 +104,10 @@ __device__ __forceinline__ void sampled_softmax_ce_row(float* __restrict__ ln, l
                                                        const float* __restrict__ logq, const float* __restrict__ lq_n,
                                                        const int* __restrict__ tgt, const int* __restrict__ neg, long row, int K,
                                                        float inv_denom, float* __restrict__ loss_rows, float* __restrict__ dlt,
-                                                       int lane) {
+                                                       int lane, const int* __restrict__ trow = nullptr, long et_ld = 0) {
     const int t = tgt[row];
     const float* h = hd + row * H;
-    const float* et = Eout + (ROWS ? row : (long)t) * H;
+    const float* et = ROWS ? Eout + (trow ? (long)trow[row] : row) * (et_ld ? et_ld : (long)H) : Eout + (long)t * H;
     float d = 0.f;
     for (int j = lane; j < H; j += 64) d += h[j] * et[j];
     float lt = wave_sum(d);
@@ -152,10 +152,11 @@ __global__ void sampled_softmax_ce_kernel(float* __restrict__ ln, long ld, const
                                           const float* __restrict__ Eout, const float* __restrict__ bout,
                                           const float* __restrict__ logq, const float* __restrict__ lq_n,
                                           const int* __restrict__ tgt, const int* __restrict__ neg, long n, int K,
-                                          float inv_denom, float* __restrict__ loss_rows, float* __restrict__ dlt) {
+                                          float inv_denom, float* __restrict__ loss_rows, float* __restrict__ dlt,
+                                          const int* __restrict__ trow, long et_ld) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row < n) sampled_softmax_ce_row<ROWS>(ln, ld, hd, H, Eout, bout, logq, lq_n, tgt, neg, row, K, inv_denom, loss_rows, dlt, lane);
+    if (row < n) sampled_softmax_ce_row<ROWS>(ln, ld, hd, H, Eout, bout, logq, lq_n, tgt, neg, row, K, inv_denom, loss_rows, dlt, lane, trow, et_ld);
 }
 
 __global__ void reduce_sum_kernel(const float* __restrict__ x, long n, float* __restrict__ out, int accumulate) {
@@ -794,7 +795,7 @@ __device__ __forceinline__ void sampled_softmax_ce_reg_row(float* __restrict__ l
                                                            const float* __restrict__ logq, const float* __restrict__ lq_n,
                                                            const int* __restrict__ tgt, const int* __restrict__ neg, long row, int K,
                                                            float inv_denom, float* __restrict__ loss_rows, float* __restrict__ dlt,
-                                                           int vec, int lane) {
+                                                           int vec, int lane, const int* __restrict__ trow = nullptr, long et_ld = 0) {
     // lane owns logits k = 256*i + 4*lane + e (e < 4): one 16-byte access per lane per chunk when the
     // row is 16-byte aligned (vec), else four dword accesses with the same mapping
     constexpr int NC = KR / 4;
@@ -856,7 +857,7 @@ __device__ __forceinline__ void sampled_softmax_ce_reg_row(float* __restrict__ l
         }
     }
     const float* h = hd + row * H;
-    const float* et = Eout + (ROWS ? row : (long)t) * H;
+    const float* et = ROWS ? Eout + (trow ? (long)trow[row] : row) * (et_ld ? et_ld : (long)H) : Eout + (long)t * H;
     float d = 0.f;
     for (int j = lane; j < H; j += 64) d += h[j] * et[j];
     float lt = wave_sum(d);
@@ -900,18 +901,19 @@ __global__ void sampled_softmax_ce_reg_kernel(float* __restrict__ ln, long ld, c
                                               const float* __restrict__ Eout, const float* __restrict__ bout,
                                               const float* __restrict__ logq, const float* __restrict__ lq_n,
                                               const int* __restrict__ tgt, const int* __restrict__ neg, long n, int K,
-                                              float inv_denom, float* __restrict__ loss_rows, float* __restrict__ dlt, int vec) {
+                                              float inv_denom, float* __restrict__ loss_rows, float* __restrict__ dlt,
+                                              const int* __restrict__ trow, long et_ld, int vec) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row < n)
         sampled_softmax_ce_reg_row<ROWS, KR>(ln, ld, hd, H, Eout, bout, logq, lq_n, tgt, neg, row, K, inv_denom, loss_rows, dlt,
-                                             vec, lane);
+                                             vec, lane, trow, et_ld);
 }
 
 template <bool ROWS>
 int launch_sampled(float* ln, long ld, const float* hd, int H, const float* Eout, const float* bout, const float* logq,
                    const float* lq_n, const int* tgt, const int* neg, long n, int K, float inv_denom, float* loss_rows,
-                   float* dlt, hipStream_t st) {
+                   float* dlt, hipStream_t st, const int* trow = nullptr, long et_ld = 0) {
     // one wave per row; with few rows (an MSNBC-shaped batch has ~2.5 k) single-wave workgroups spread evenly over the
     // 256 CUs (10 per CU) where 4-wave workgroups leave some CUs with 3 and some with 2 (tuning switch: SEQREC_CE_BLOCK)
     static const int ce_block = getenv("SEQREC_CE_BLOCK") ? atoi(getenv("SEQREC_CE_BLOCK")) : 64;
@@ -920,7 +922,7 @@ int launch_sampled(float* ln, long ld, const float* hd, int H, const float* Eout
     // bit 0: 16-byte accesses to the logit rows are legal; bit 1: to the candidate id / log-Q vectors
     const int vec = ((((reinterpret_cast<uintptr_t>(ln) & 15) == 0) && (ld % 4 == 0)) ? 1 : 0) |
                     ((((reinterpret_cast<uintptr_t>(neg) & 15) == 0) && (!lq_n || (reinterpret_cast<uintptr_t>(lq_n) & 15) == 0)) ? 2 : 0);
-#define SS_ARGS ln, ld, hd, H, Eout, bout, logq, lq_n, tgt, neg, n, K, inv_denom, loss_rows, dlt
+#define SS_ARGS ln, ld, hd, H, Eout, bout, logq, lq_n, tgt, neg, n, K, inv_denom, loss_rows, dlt, trow, et_ld
 #define SS_ARGSV SS_ARGS, vec
     if (K <= 64 * 8) hipLaunchKernelGGL((sampled_softmax_ce_reg_kernel<ROWS, 8>), grid, block, 0, st, SS_ARGSV);
     else if (K <= 64 * 16) hipLaunchKernelGGL((sampled_softmax_ce_reg_kernel<ROWS, 16>), grid, block, 0, st, SS_ARGSV);
@@ -954,6 +956,19 @@ extern "C" int seqrec_sampled_softmax_ce_rows(float* ln, int64_t ld, const float
     if (!ln || !hd || !Etgt || !tgt || (K > 0 && !neg) || !loss_rows || !dlt) return SEQREC_E_ARG;
     return launch_sampled<true>(ln, (long)ld, hd, H, Etgt, nullptr, lq_tgt, lq_neg, tgt, neg, (long)n, K, inv_denom,
                                 loss_rows, dlt, as_stream(stream));
+}
+
+// the same with the target rows read THROUGH an index: row i of the target table is table[tgt_row[i] * table_ld + :] (the
+// received rows of the exchange buffer, no staging copy)
+extern "C" int seqrec_sampled_softmax_ce_rows_idx(float* ln, int64_t ld, const float* hd, int H, const float* table, int64_t table_ld,
+                                                  const int32_t* tgt_row, const float* lq_tgt, const float* lq_neg,
+                                                  const int32_t* tgt, const int32_t* neg, int64_t n, int K, float inv_denom,
+                                                  float* loss_rows, float* dlt, void* stream) {
+    if (n < 0 || K < 0 || H <= 0 || ld < K || table_ld < H) return SEQREC_E_ARG;
+    if (n == 0) return 0;
+    if (!ln || !hd || !table || !tgt_row || !tgt || (K > 0 && !neg) || !loss_rows || !dlt) return SEQREC_E_ARG;
+    return launch_sampled<true>(ln, (long)ld, hd, H, table, nullptr, lq_tgt, lq_neg, tgt, neg, (long)n, K, inv_denom,
+                                loss_rows, dlt, as_stream(stream), tgt_row, (long)table_ld);
 }
 
 extern "C" int seqrec_reduce_sum(const float* x, int64_t n, float* out, int accumulate, void* stream) {

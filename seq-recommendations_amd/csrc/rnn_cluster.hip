@@ -24,19 +24,6 @@ __device__ unsigned long long seqrec_cluster::g_cl_spins[8];
 
 namespace {
 
-// Diagnostic build only (-DSEQREC_CLUSTER_STAMP, tools/cluster_stamps.py): workgroup (group 0, column block 1) sums the
-// s_memrealtime (100 MHz) spent between marked points of a step; no stamp exists in the product build.
-#ifdef SEQREC_CLUSTER_STAMP
-__device__ unsigned long long g_cl_stamp[32];
-#define CS_DECL unsigned long long cs_prev = __builtin_amdgcn_s_memrealtime(); unsigned long long cs_acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; int cs_steps = 0
-#define CS(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); cs_acc[i] += t_ - cs_prev; cs_prev = t_; } while (0)
-#define CS_FLUSH(base_) do { if (gl == 0 && c == 1 && threadIdx.x == 0) { for (int i_ = 0; i_ < 12; ++i_) g_cl_stamp[(base_) + i_] = cs_acc[i_]; g_cl_stamp[(base_) + 12] = cs_steps; } } while (0)
-#else
-#define CS_DECL
-#define CS(i)
-#define CS_FLUSH(base_)
-#endif
-
 // one or two 16x16 tile products with K split over the 4 waves (rnn_step.hip tile_16x16_reg, same order of sums)
 template <int K, int NT>
 __device__ __forceinline__ void cl_tiles(const float (&a)[K / 16], const float4 (&b0)[K / 64], const float4 (&b1)[K / 64],
@@ -393,7 +380,7 @@ extern "C" void seqrec_debug_cluster_spins(unsigned long long* out, int reset) {
 #endif
 #ifdef SEQREC_CLUSTER_STAMP
 extern "C" void seqrec_debug_cluster_stamps(unsigned long long* out) {
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cl_stamp), sizeof(unsigned long long) * 32);
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(seqrec_cluster::g_cl_stamp), sizeof(unsigned long long) * 32);
 }
 #endif
 

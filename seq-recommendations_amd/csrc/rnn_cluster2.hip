@@ -8,9 +8,10 @@
 // K-permuted order, partial tiles summed in the same order, the cell formulas from ONE shared definition), so the two
 // forms agree bit for bit in Hout / gates / c and to the last bits in dPre.
 // LSTM BPTT: K = 4H (2048 at H = 512), the wave's slice of a dPre row is H floats -- too long for registers next to the
-// wave's slice of U^T (128 VGPRs at H = 512).  It is streamed in PIECES of 32 floats per lane through a two-deep LDS-DMA
-// ring (8 KB per wave and piece): piece p + 1 is in flight while the 32 MFMAs of piece p run.
+// wave's slice of U^T (128 VGPRs at H = 512).  It is streamed in PIECES of 16 floats per lane (4 KB per wave) through a
+// four-slot LDS-DMA ring: three pieces are in flight while the 16 MFMAs of the fourth run.
 #include "rnn_cluster_dev.h"
+#include <type_traits>
 
 using namespace seqrec_cluster;
 
@@ -30,6 +31,9 @@ namespace {
 template <int N> __device__ __forceinline__ void mul_vec(float (&o)[N], const float (&a)[N], const float (&m)[N]) {
 #pragma unroll
     for (int i = 0; i < N; ++i) o[i] = a[i] * m[i];
+}
+template <int I, int N, class F> __device__ __forceinline__ void cl_static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); cl_static_for<I + 1, N>(f); }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -165,6 +169,7 @@ __global__ __launch_bounds__(256, 2) void lstm_cluster_fwd(ClusterArgs a) {
     }
     const unsigned base = a.epoch;
     float cprev = 0.f;
+    CS_DECL;
     float n_x[4] = {0.f, 0.f, 0.f, 0.f};
     auto prefetch_xw = [&](int t) {
         const int p0 = a.so[t], nact = min(16, a.so[t + 1] - p0 - r0);
@@ -186,11 +191,14 @@ __global__ __launch_bounds__(256, 2) void lstm_cluster_fwd(ClusterArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) xw[g] = n_x[g];
         float acc[4] = {0.f, 0.f, 0.f, 0.f}, unused[4];
+        CS(0);
         if (t > 0) {
             if (!cl_wait_w<CB>(fl, base + (unsigned)t, a.error, a.spin_limit)) { if (ok) a.Hout[q * H + col] = __builtin_nanf(""); return; }
+            CS(1);
             if (t == 1) wt = !cl_same_xcd<CB>(fl);
             float av[H / 16];
             ld_rows_dma<H>(av, a.Hout + ((long)a.so[t - 1] + r0) * H, H, nact, w * (H / 4), stage, lane);
+            CS(2);
             if constexpr (RD) {
                 // every gate reads h_{t-1} through its own mask: four masked copies of the A operand, one tile each
                 float4 b1[1][NB];
@@ -207,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void lstm_cluster_fwd(ClusterArgs a) {
             } else {
                 cl_tiles_n<H, 4>(av, b, red, tid, acc, unused);
             }
+            CS(3);
         }
         float gi, gf, gg, go, cn, hn;
         lstm_cell_fwd<ACT>(acc[0] + xw[0], acc[1] + xw[1], acc[2] + xw[2], acc[3] + xw[3], cprev, col < a.H_real, gi, gf, gg, go, cn, hn);
@@ -224,7 +233,10 @@ __global__ __launch_bounds__(256, 2) void lstm_cluster_fwd(ClusterArgs a) {
             cl_publish_n<5>(fl + c, base + (unsigned)t + 1u, wt);
             prefetch_xw(t + 1);
         }
+        CS(4);
+        if (t > 0) CS_STEP();
     }
+    CS_FLUSH(0);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -236,13 +248,15 @@ template <int J, int ACT, bool RD>
 __global__ __launch_bounds__(256, 2) void lstm_cluster_bwd(ClusterArgs a) {
     constexpr int H = 64 * J, GH = 4 * H, CB = H / 16, K = 4 * H;
     constexpr int SLQ = K / 16;                          // floats of a lane's run of its A row: H / 4
-    constexpr int CHF = SLQ < 32 ? SLQ : 32;             // floats per piece
-    constexpr int NPC = SLQ / CHF;                       // pieces per step: 1, 1, 2, 4 at H = 64 ... 512
+    constexpr int CHF = SLQ < 16 ? SLQ : 16;             // floats per lane and piece (64-byte source segments)
+    constexpr int NPC = SLQ / CHF;                       // pieces per step: 1, 2, 4, 8 at H = 64 ... 512
+    constexpr int RING = NPC < 4 ? NPC : 4;              // ring slots: up to 3 pieces in flight ahead of the one in the MFMAs
+    constexpr int NI = 16 / (64 / CHF);                  // DMA instructions per piece
     constexpr int IMG = 16 * 4 * CHF;                    // floats of a piece image
     CL_PROLOGUE(CB);
-    __shared__ float smem[1024 + 4 * (NPC > 1 ? 2 : 1) * IMG];
+    __shared__ float smem[1024 + 4 * RING * IMG];
     float* red = smem;
-    float* ring = smem + 1024 + w * ((NPC > 1 ? 2 : 1) * IMG);
+    float* ring = smem + 1024 + w * (RING * IMG);
     float4 b[K / 64];
     {
         const float4* pb = reinterpret_cast<const float4*>(a.pk_b);      // U^T, K = 4H: wave w owns gate block w
@@ -274,7 +288,9 @@ __global__ __launch_bounds__(256, 2) void lstm_cluster_bwd(ClusterArgs a) {
     };
     if (tg > 0) prefetch(tg - 1);
     const int kslice0 = w * (K / 4);
+    CS_DECL;
     for (int t = tg - 1; t >= 0; --t) {
+        CS(0);
         const int p0 = a.so[t], bt = a.so[t + 1] - p0;
         const int bnext = t + 1 < a.T ? a.so[t + 2] - a.so[t + 1] : 0;
         const int nact = min(16, bt - r0);
@@ -298,24 +314,30 @@ __global__ __launch_bounds__(256, 2) void lstm_cluster_bwd(ClusterArgs a) {
             st_f32(a.dPre + q * GH + 2 * H + col, dg, wt);
             st_f32(a.dPre + q * GH + 3 * H + col, dout, wt);
         }
+        CS(1);
         cl_publish_n<0>(fl + c, ++count, wt);
         prefetch(t - 1);
+        CS(2);
         if (!cl_wait_w<CB>(fl, count, a.error, a.spin_limit)) { if (ok) a.dPre[q * GH + col] = __builtin_nanf(""); return; }
+        CS(3);
         if (first_x) { wt = !cl_same_xcd<CB>(fl); first_x = false; }
         // dPre rows of the step, wave w's gate block, in pieces through the two-deep ring
         const float* rows = a.dPre + ((long)p0 + r0) * GH;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        dma_piece_issue<SLQ, CHF>(rows, GH, nact, kslice0, 0, ring, lane);
+        // RING - 1 pieces ahead: the wave's slice of a step is H x 16 rows x 4 B = 32 KB at H = 512 and an L2 round trip is
+        // ~0.9 us -- with one piece ahead the loop ran at the latency of a piece per piece (4.7 us per step), not at the MFMAs' pace
 #pragma unroll
-        for (int pc = 0; pc < NPC; ++pc) {
-            if (pc + 1 < NPC) dma_piece_issue<SLQ, CHF>(rows, GH, nact, kslice0, pc + 1, ring + ((pc + 1) & 1) * IMG, lane);
-            // the ring slot of piece pc + 1 was last read two pieces ago (program order of one wave; its LDS reads have
-            // returned: the MFMAs that consumed them were issued) -- and the prefetch loads above are older than every
-            // piece: the counter is in order, so "all but the newest piece" means piece pc has landed
-            if (pc + 1 < NPC) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(16 / (64 / CHF)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int pc = 0; pc < RING - 1 && pc < NPC; ++pc) dma_piece_issue<SLQ, CHF>(rows, GH, nact, kslice0, pc, ring + pc * IMG, lane);
+        cl_static_for<0, NPC>([&](auto PC) {
+            constexpr int pc = decltype(PC)::value;
+            // slot (pc + RING - 1) % RING was read by piece pc - 1: its LDS reads have returned (dma_piece_read waits for them)
+            if constexpr (pc + RING - 1 < NPC) dma_piece_issue<SLQ, CHF>(rows, GH, nact, kslice0, pc + RING - 1, ring + ((pc + RING - 1) % RING) * IMG, lane);
+            // the counter is in order and only DMA loads are outstanding here (the polls drained everything older): "all but
+            // the younger pieces" means piece pc has landed
+            constexpr int younger = (pc + RING - 1 < NPC ? pc + RING - 1 : NPC - 1) - pc;
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(younger * NI) : "memory");
             f32x4 av[CHF / 4];
-            dma_piece_read<CHF>(av, ring + (pc & 1) * IMG, lane);
+            dma_piece_read<CHF>(av, ring + (pc % RING) * IMG, lane);
 #pragma unroll
             for (int i = 0; i < CHF / 4; ++i) {
                 const float4 bb = b[pc * (CHF / 4) + i];
@@ -324,8 +346,8 @@ __global__ __launch_bounds__(256, 2) void lstm_cluster_bwd(ClusterArgs a) {
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][2], bb.z, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][3], bb.w, acc1, 0, 0, 0);
             }
-            // (slot pc & 1 is rewritten by piece pc + 2: its reads have returned -- dma_piece_read waits for them)
-        }
+        });
+        CS(4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[w * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc0[r] + acc1[r];
         __syncthreads();
@@ -338,7 +360,10 @@ __global__ __launch_bounds__(256, 2) void lstm_cluster_bwd(ClusterArgs a) {
             dh_carry = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
         }
         // (the next write of `red` is behind the next step's publish barrier)
+        CS(5);
+        CS_STEP();
     }
+    CS_FLUSH(16);
 }
 
 #define KERNEL_TABLE(NAME, KERN)                                                                                     \
@@ -383,6 +408,12 @@ KERNEL_TABLE(lstm_fwd_kernel, lstm_cluster_fwd)
 #undef RD8
 
 }  // namespace
+
+#ifdef SEQREC_CLUSTER_STAMP
+extern "C" void seqrec_debug_cluster_stamps2(unsigned long long* out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(seqrec_cluster::g_cl_stamp), sizeof(unsigned long long) * 32);
+}
+#endif
 
 bool seqrec_cluster_other_fwd(int cell, int act, int H, int H_real, int T, int B, const int32_t* soh, const float* XW, float* Hout,
                               float* gates, float* aux, const float* upack, const float* rmask, hipStream_t st, int* rc) {

@@ -35,6 +35,21 @@ int cluster_group_cap(const void* kernel, int CB);
 // the launch loop shared by every cluster scan: slices of at most cluster_group_cap() row blocks on the same stream
 int launch_sliced(const void* fn, ClusterArgs& a, int CB, int n_row_blocks, int T, hipStream_t st);
 
+// Diagnostic build only (-DSEQREC_CLUSTER_STAMP, tools/cluster_stamps.py): workgroup (group 0, column block 1) sums the
+// s_memrealtime (100 MHz) spent between marked points of a step; no stamp exists in the product build.
+#ifdef SEQREC_CLUSTER_STAMP
+static __device__ unsigned long long g_cl_stamp[32];      // one per translation unit (rnn_cluster.hip / rnn_cluster2.hip)
+#define CS_DECL unsigned long long cs_prev = __builtin_amdgcn_s_memrealtime(); unsigned long long cs_acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; int cs_steps = 0
+#define CS(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); cs_acc[i] += t_ - cs_prev; cs_prev = t_; } while (0)
+#define CS_STEP() ++cs_steps
+#define CS_FLUSH(base_) do { if (gl == 0 && a.g_base == 0 && c == 1 && threadIdx.x == 0) { for (int i_ = 0; i_ < 12; ++i_) seqrec_cluster::g_cl_stamp[(base_) + i_] = cs_acc[i_]; seqrec_cluster::g_cl_stamp[(base_) + 12] = cs_steps; } } while (0)
+#else
+#define CS_DECL
+#define CS(i)
+#define CS_STEP()
+#define CS_FLUSH(base_)
+#endif
+
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_f32(float* p, float v, bool wt) {          // wt: write-through (device scope)
     if (wt) asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");

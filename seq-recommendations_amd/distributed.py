@@ -41,7 +41,7 @@ import torch
 
 from . import _lib
 from ._lib import ptr
-from .engine import Engine, call, INT32_MAX, SPLITK_TARGET_WGS
+from .engine import Engine, call, INT32_MAX, SPLITK_TARGET_WGS, _ceil4, _pad_h
 
 
 class HostStagedDist:
@@ -114,7 +114,7 @@ class SegPlan:
       own_extra int32[R,extra]  rows of the extras in the owner-side buffer
       back_src  int32[n_tot]  request index of every requester-side row (-1 at the extras)"""
     __slots__ = ("n", "extra", "n_tot", "m_tot", "req_split", "own_split", "req_pos", "req_extra", "own_rows",
-                 "own_extra", "back_src", "host", "got_pad")
+                 "own_extra", "back_src", "host", "got_pad", "n_global")
 
 
 class RowExchange:
@@ -192,14 +192,17 @@ class RowExchange:
         p.own_extra = (rc_end[:, None] + extra * ar_r[:, None] + ar_e[None, :]).to(torch.int32)
         return p
 
-    def plan_seg_many(self, reqs, extra=0, device_fields=True, group="default"):
+    def plan_seg_many(self, reqs, extra=0, device_fields=True, group="default", tokens=None):
         """plan_seg for M batches at once: reqs = [(owner int array [n_b], want int array [n_b]), ...] (host numpy).
         TWO collectives and ONE host synchronisation for all M batches instead of two + two per batch: the per-peer
         request counts of every batch travel in one all-to-all (then one device -> host copy), the requested local
         rows of every batch in a second one.  All index arithmetic is host numpy; each plan's tensors are created
         on self.dev.  Returns the same SegPlan objects plan_seg would build batch by batch.  device_fields=False leaves
         the index tensors to the caller (plan.host holds them as numpy, plan.got_pad the received rows + a -1 sentinel:
-        own_rows = got_pad[host['own_src']]), so that ONE blob per batch crosses PCIe (ShardedEngine.prepare)."""
+        own_rows = got_pad[host['own_src']]), so that ONE blob per batch crosses PCIe (ShardedEngine.prepare).
+        tokens (optional, one int per batch): this rank's token count of every batch; the counts of all ranks ride in the
+        same first collective and plan.n_global is their sum -- the step's gradient divisor, known on the host before the
+        step is enqueued."""
         R, dist, dev = self.R, self.dist, self.dev
         grp = self.group if isinstance(group, str) else group          # planning may run on its own communicator
         M = len(reqs)
@@ -208,10 +211,14 @@ class RowExchange:
         perms = [np.argsort(o, kind="stable") for o in owners]
         SC = np.stack([np.bincount(o, minlength=R) for o in owners]).astype(np.int64) if M else np.zeros((0, R), np.int64)
         # counts: row j of the send matrix goes to peer j -> I receive, from peer i, its counts towards me per batch
-        sc_dev = torch.from_numpy(np.ascontiguousarray(SC.T)).to(dev)                    # [R, M]
+        tk = np.zeros(M, np.int64) if tokens is None else np.asarray(tokens, dtype=np.int64)
+        sc_ext = np.concatenate([SC.T, np.tile(tk[None, :], (R, 1))], axis=1)            # [R, 2M]: counts towards peer j | my tokens
+        sc_dev = torch.from_numpy(np.ascontiguousarray(sc_ext)).to(dev)
         rc_dev = torch.empty_like(sc_dev)
         dist.all_to_all_single(rc_dev, sc_dev, group=grp)
-        RC = rc_dev.cpu().numpy().T.copy()                                               # [M, R]   (the ONE host sync)
+        rc_ext = rc_dev.cpu().numpy()                                                    # (the ONE host sync)
+        RC = rc_ext[:, :M].T.copy()                                                      # [M, R]
+        n_global = rc_ext[:, M:].sum(axis=0)                                             # [M] tokens of every rank, summed
         # wants: for peer j the concatenation over batches of the local rows I ask it for
         segs = [[wants[b][perms[b]][SC[b, :j].sum():SC[b, :j + 1].sum()] for b in range(M)] for j in range(R)]
         send = np.concatenate([x for j in range(R) for x in segs[j]]) if M else np.zeros(0, np.int32)
@@ -256,6 +263,7 @@ class RowExchange:
             else:
                 p.req_pos = p.req_extra = p.back_src = p.own_extra = p.own_rows = None
             p.got_pad = got_pad
+            p.n_global = int(n_global[b])
             plans.append(p)
         return plans
 
@@ -316,8 +324,10 @@ class ShardedEngine(Engine):
     def __init__(self, cfg, device, dist, group=None):
         if cfg.input != "embed" or cfg.output != "sampled":
             raise ValueError("ShardedEngine shards item tables: it needs input='embed', output='sampled'")
-        if cfg.out_bias or cfg.drop_in or cfg.drop_out or cfg.drop_rec:
-            raise NotImplementedError("ShardedEngine: output bias / dropout are not wired into the sharded step")
+        if cfg.out_bias:
+            raise NotImplementedError("ShardedEngine: a per-item output bias is not sharded (the BASELINE configs have none)")
+        if (cfg.drop_in or cfg.drop_out or cfg.drop_rec) and _ceil4(cfg.D) != _pad_h(cfg.H):
+            raise NotImplementedError("ShardedEngine: dropout is wired into the unified step (D == H after padding) only")
         if cfg.merge != "atomic":
             raise NotImplementedError("ShardedEngine: the sorted (bitwise-reproducible) row-gradient merge is single-GPU only")
         self.dist, self.group = dist, group
@@ -333,6 +343,8 @@ class ShardedEngine(Engine):
         # hipGraph replay of the step-wise scan was measured for this engine (round 2: 1.27 against 1.19 ms per step in steady
         # state on one rank) and is OFF here: the loop is host-bound by its collectives, not by the scan's launches
         self.use_graph = False
+        # dropout masks are keyed by (local batch row, step): every rank draws from its own stream
+        self.drop_seed = cfg.seed + 1000003 * (self.rank + 1)
         self.gcfg = cfg
         self.ex = RowExchange(dist, group, self.dev)
         # dense gradients live in ONE flat buffer (+1 slot for the squared norm of the owned row
@@ -347,7 +359,9 @@ class ShardedEngine(Engine):
             o += nk
         self.n_dense = tot
         self.sq = self.gflat[tot:tot + 1]
-        self.ntok = self.gflat[tot + 1:tot + 2]      # global token count of the step (after the all-reduce)
+        self.ntok = self.gflat[tot + 1:tot + 2]      # split path: global token count of the step (after the all-reduce)
+        # unified path: [row-gradient norm (all-reduced) | dense norm (fixed order) | their sum | global token count of the step]
+        self.norms = torch.zeros(4, dtype=torch.float32, device=self.dev)
         # the dense all-reduce runs on its own stream and (RCCL) its own communicator, under the row-gradient exchange
         self.side = torch.cuda.Stream(device=self.dev)
         self.dense_group = group
@@ -465,7 +479,8 @@ class ShardedEngine(Engine):
             o_in, o_tg = ids % R, tgt % R
             off = np.zeros_like(o_tg) if c.tied else (self.gcfg.V_in - o_tg + R - 1) // R     # E rows held by the owner
             reqs.append((np.concatenate([o_in, o_tg]), np.concatenate([ids // R, tgt // R + off])))
-        plans = self.ex.plan_seg_many(reqs, extra=Kr + nid, device_fields=False, group=self.plan_group)
+        plans = self.ex.plan_seg_many(reqs, extra=Kr + nid, device_fields=False, group=self.plan_group,
+                                      tokens=[rb.n_tok for rb in rbs])
         q = np.arange(Kr)
         ds = []
         for rb, plan in zip(rbs, plans):
@@ -474,23 +489,29 @@ class ShardedEngine(Engine):
             back = h["back"].copy()
             back[re_[:, :Kr].reshape(-1)] = 2 * n + np.arange(R * Kr)
             parts = [("step_off", rb.step_off), ("prev", rb.prev), ("ids", rb.ids), ("tgt", rb.tgt),
-                     ("neg_slots", oe[:, :Kr].reshape(-1)),
-                     ("id_slots", (oe[:, Kr + q // w] * w + (q % w)[None, :]).reshape(-1)),
-                     ("take_idx", np.concatenate([h["req_pos"], re_[:, :Kr].reshape(-1)])),
+                     ("neg_slots", oe[:, :Kr].reshape(-1)),                          # owner side: rows of my draws
+                     ("id_rows", oe[:, Kr:Kr + nid].reshape(-1)),                    # owner side: rows that carry their ids
+                     ("take_in", h["req_pos"][:n]), ("take_tgt", h["req_pos"][n:]),  # requester side: my input / target rows
+                     ("neg_rows", re_[:, :Kr].reshape(-1)),                          # requester side: the K negative rows
                      ("negid_idx", (re_[:, Kr + q // w] * w + (q % w)[None, :]).reshape(-1)),
-                     ("back_idx", back), ("arange", np.arange(n)), ("own_src", h["own_src"])]
+                     ("back_idx", back), ("own_src", h["own_src"]),
+                     ("ntok", np.array([plan.n_global], np.float32).view(np.int32))]
             if c.logq and self.logq_global is not None:
                 parts.append(("lq_tgt", self.logq_global_host[rb.tgt].view(np.int32)))
             # everything the step needs from the host in ONE int32 blob: the batch's index arrays and its routing
             blob = self.pinned.put(np.concatenate([np.asarray(x, dtype=np.int32) for _, x in parts]))   # page-locked ring (PinnedRing)
-            d = {"n": n, "T": rb.T, "B": rb.B, "rb": rb, "blob": blob, "plan": plan}
+            d = {"n": n, "T": rb.T, "B": rb.B, "rb": rb, "blob": blob, "plan": plan, "n_global": plan.n_global}
             o = 0
             for name, x in parts:
                 d[name] = blob[o:o + len(x)]
                 o += len(x)
-            if "lq_tgt" in d:
-                d["lq_tgt"] = d["lq_tgt"].view(torch.float32)
-            d["send_idx"] = plan.got_pad[d.pop("own_src").long()]       # owner-side local rows (-1 at the extras; negatives written per step)
+            for k in ("lq_tgt", "ntok"):
+                if k in d:
+                    d[k] = d[k].view(torch.float32)
+            # owner-side row kinds for seqrec_exchange_pack: the requested local row, -1 at the id rows, -2 at the rows of my draws
+            kinds = plan.got_pad[d.pop("own_src").long()]
+            kinds[d["neg_slots"].long()] = -2
+            d["send_idx"] = kinds
             ds.append(d)
         return ds
 
@@ -504,7 +525,7 @@ class ShardedEngine(Engine):
             return self._step_unified(d, lr, eps, clipnorm, step, apply_update)
         return self._step_split(d, lr, eps, clipnorm, step, apply_update)
 
-    def _cell_and_loss(self, d, X, Etgt, Eneg, neg, dX, dEtgt, dEneg, train=True, reduce_dense=True):
+    def _cell_and_loss_split(self, d, X, Etgt, Eneg, neg, dX, dEtgt, dEneg, train=True, reduce_dense=True):
         """Everything between the two exchanges: x.W, scan, sampled softmax CE, BPTT, dense weight
         gradients; writes the three row-gradient blocks."""
         c, P = self.cfg, self.P
@@ -536,7 +557,7 @@ class ShardedEngine(Engine):
         # -- backward
         ar = d["arange"]
         dHd = self.buf("dHd", n, Hp)
-        self.gemm(1, 0, n, Hp, K, ln, K, Eneg, Hp, dHd, Hp, splitk=self._splitk(n, Hp, K), tag="dH",
+        self.gemm(1, 0, n, Hp, K, ln, K, Eneg, Hp, dHd, Hp, splitk=self._splitk(n, Hp, K, fill=True), tag="dH",
                   fuse=_lib.gemm_fuse(add_table=Etgt, add_index=ar, add_scale=dlt, add_ld=Hp))
         self.gemm(0, 0, K, Hp, n, ln, K, Hd, Hp, dEneg, Hp, splitk=self._splitk(K, Hp, n), tag="dEneg")
         call("seqrec_gather_rows", ptr(Hd), ptr(ar), ptr(dEtgt), n, Hp, ptr(dlt), None, 0, st)
@@ -551,19 +572,123 @@ class ShardedEngine(Engine):
         if c.use_bias:                       # db = ones^T . dPre in the same grouped launch (M = 1)
             wgrad.append((1, GHp, n, self._ones(n), self.ONES_LD, dPre, GHp, Gd["b"], GHp))
         tiles = sum(((w_[0] + 63) // 64) * ((w_[1] + 63) // 64) for w_ in wgrad)
-        sk = self._splitk_tiles(tiles, n)
+        sk = self._splitk_tiles(tiles, n, fill=True)
         wsp = self.buf("gemm_ws", sum(sk * w_[0] * w_[1] for w_ in wgrad)) if sk > 1 else None
         call("seqrec_gemm_f32_grouped", len(wgrad), 0, 0, _lib.gemm_descs(wgrad), sk, ptr(wsp), st, tag="dW+dU")
         if self.unified and reduce_dense:
             self._start_dense_allreduce()        # the dense gradients are final: reduce them under everything that follows
-        self.gemm(1, 1, n, Dp, GHp, dPre, GHp, P["W"], GHp, dX, Dp, splitk=self._splitk(n, Dp, GHp), tag="dX")
+        self.gemm(1, 1, n, Dp, GHp, dPre, GHp, P["W"], GHp, dX, Dp, splitk=self._splitk(n, Dp, GHp, fill=True), tag="dX")
+
+    def _cell_unified(self, d, recv, Eneg, neg, lq_neg, step, train=True, reduce_dense=True):
+        """Everything between the two exchanges of the unified step -- the plain engine's kernel sequence (Engine.train_step) on
+        rows that arrived by all-to-all: the input rows and the target rows are read THROUGH their positions in the receive
+        buffer (gathered-A GEMMs, indexed CE, row-add epilogue of dH: no staging copy), dX and dEneg are left as split-K
+        slabs for the gradient-routing launch, dropout as in the plain engine.  Returns what that launch needs."""
+        c, P, Gd = self.cfg, self.P, self.Gd
+        st = self._stream()
+        n, Hp, GHp, Dp, K, w = d["n"], self.Hp, self.GHp, self.Dp, c.K, self.Hp
+        drops = self._drop_masks(d, step) if train else {}
+        XW = self.buf("XW", n, GHp)
+        xidx = d["take_in"]
+        if "in" in drops:                    # input dropout acts on the rows themselves: materialise them once
+            X = self.buf("X", n, Dp)
+            self._take(recv, xidx, X)
+            call("seqrec_mul", ptr(X), ptr(drops["in"]), ptr(X), n * Dp, st)
+            xidx = None
+            self.gemm(1, 0, n, GHp, Dp, X, Dp, P["W"], GHp, XW, GHp, bias=P.get("b"), tag="xw")
+        else:
+            X = recv
+            self.gemm(1, 0, n, GHp, Dp, recv, w, P["W"], GHp, XW, GHp, bias=P.get("b"), tag="xw", fuse=_lib.gemm_fuse(a_index=xidx))
+        Hout = self.buf("Hout", n, Hp); gates = self.buf("gates", n, GHp); aux = self.buf("aux", n, Hp)
+        self._scan_fwd(d, XW, Hout, gates, aux, drops.get("rec"))
+        Hd = Hout
+        if "out" in drops:
+            Hd = self.buf("Hd", n, Hp)
+            call("seqrec_mul", ptr(Hout), ptr(drops["out"]), ptr(Hd), n * Hp, st)
+        ln = self.buf("ln", n, K)
+        self.gemm(1, 1, n, K, Hp, Hd, Hp, Eneg, Hp, ln, K, tag="logits")
+        dlt = self.buf("dlt", n)
+        loss_rows = self.buf("loss_rows", n)
+        # gradients stay SUMS (inv_denom 1): the global token count divides them in the update (seqrec_opt_apply grad_div)
+        call("seqrec_sampled_softmax_ce_rows_idx", ptr(ln), K, ptr(Hd), Hp, ptr(recv), w, ptr(d["take_tgt"]), ptr(d.get("lq_tgt")),
+             ptr(lq_neg), ptr(d["tgt"]), ptr(neg), n, K, 1.0, ptr(loss_rows), ptr(dlt), st, prof_name="seqrec_sampled_softmax_ce")
+        r = {"Hd": Hd, "dlt": dlt, "loss_rows": loss_rows, "Hout": Hout}
+        if not train:
+            call("seqrec_loss_reduce", ptr(loss_rows), n, ptr(self.loss_out), st)
+            return r
+        # -- backward
+        dHd = self.buf("dHd", n, Hp)
+        self.gemm(1, 0, n, Hp, K, ln, K, Eneg, Hp, dHd, Hp, splitk=self._splitk(n, Hp, K, fill=True), tag="dH",
+                  fuse=_lib.gemm_fuse(add_table=recv, add_index=d["take_tgt"], add_scale=dlt, add_ld=w))
+        r["dEneg"] = self.gemm_slabs(0, 0, K, Hp, n, ln, K, Hd, Hp, "dEneg_slabs", self._splitk(K, Hp, n), tag="dEneg")
+        if "out" in drops:
+            call("seqrec_mul", ptr(dHd), ptr(drops["out"]), ptr(dHd), n * Hp, st)
+        dPre = self.buf("dPre", n, GHp)
+        self._scan_bwd(d, dHd, Hout, gates, aux, dPre, drops.get("rec"))
+        wgrad = []
+        if "rec" in drops:
+            # dU_g = (A_g * m_g)^T . dPre_g with the gate's time-invariant mask expanded to tokens (Engine.train_step)
+            B_ = d["B"]
+            d["rb"].ensure_tokens()
+            rowidx = self.buf("tok_row", n, dtype=torch.int32)
+            rowidx.copy_(self.pinned.put(d["rb"].tok_row.astype(np.int32)))
+            Hprev = self.buf("Hprev", n, Hp)
+            call("seqrec_gather_rows", ptr(Hout), ptr(d["prev"]), ptr(Hprev), n, Hp, None, None, 0, st)
+            mt = self.buf("mask_tok", n, Hp); Am = self.buf("A_masked", n, Hp)
+            for g in range(self.G):
+                call("seqrec_gather_rows", ptr(drops["rec"][g * B_:(g + 1) * B_]), ptr(rowidx), ptr(mt), n, Hp, None, None, 0, st)
+                src = aux if (c.cell == "gru" and g == 2) else Hprev
+                call("seqrec_mul", ptr(src), ptr(mt), ptr(Am), n * Hp, st)
+                self.gemm(0, 0, Hp, Hp, n, Am, Hp, dPre[:, g * Hp:], GHp, Gd["U"][:, g * Hp:], GHp, splitk=self._splitk(Hp, Hp, n), tag="dU")
+        elif c.cell == "gru":            # h_{t-1} = Hout read through the prev links inside the GEMM
+            wgrad += [(Hp, 2 * Hp, n, Hout, Hp, dPre, GHp, Gd["U"], GHp, d["prev"]),
+                      (Hp, Hp, n, aux, Hp, dPre[:, 2 * Hp:], GHp, Gd["U"][:, 2 * Hp:], GHp)]
+        else:
+            wgrad.append((Hp, GHp, n, Hout, Hp, dPre, GHp, Gd["U"], GHp, d["prev"]))
+        if xidx is None:
+            wgrad.append((Dp, GHp, n, X, Dp, dPre, GHp, Gd["W"], GHp))
+        else:                               # the input rows read through their positions in the receive buffer
+            wgrad.append((Dp, GHp, n, recv, w, dPre, GHp, Gd["W"], GHp, xidx))
+        if c.use_bias:                       # db = ones^T . dPre in the same grouped launch (M = 1)
+            wgrad.append((1, GHp, n, self._ones(n), self.ONES_LD, dPre, GHp, Gd["b"], GHp))
+        tiles = sum(((w_[0] + 63) // 64) * ((w_[1] + 63) // 64) for w_ in wgrad)
+        sk = self._splitk_tiles(tiles, n, fill=True)
+        wsp = self.buf("gemm_ws", sum(sk * w_[0] * w_[1] for w_ in wgrad)) if sk > 1 else None
+        call("seqrec_gemm_f32_grouped", len(wgrad), 0, 0, _lib.gemm_descs(wgrad), sk, ptr(wsp), st, tag="dW+dU")
+        if reduce_dense:
+            self._start_dense_allreduce()        # the dense gradients are final: reduce them under everything that follows
+        if "in" in drops:
+            dX = self.buf("dX", n, Dp)
+            self.gemm(1, 1, n, Dp, GHp, dPre, GHp, P["W"], GHp, dX, Dp, splitk=self._splitk(n, Dp, GHp, fill=True), tag="dX")
+            call("seqrec_mul", ptr(dX), ptr(drops["in"]), ptr(dX), n * Dp, st)
+            r["dX"] = (dX, 1, n * Dp)
+        else:
+            sk_x = self._splitk_tiles(((n + 63) // 64) * ((Dp + 63) // 64), GHp, min_k=self._slab_min_k, fill=True)
+            r["dX"] = self.gemm_slabs(1, 1, n, Dp, GHp, dPre, GHp, P["W"], GHp, "dX_slabs", sk_x, tag="dX")
+        return r
 
     def _start_dense_allreduce(self):
+        """Unified path: the dense all-reduce AND the dense gradient norm run on the side stream (its own communicator under
+        RCCL) while the main stream routes the row gradients; the norm is taken in a fixed order (per-block partials added
+        in index order) from the all-reduced -- hence identical -- gradients, so it is bit-identical on every rank."""
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.dev))
+        main_st = self._cur_st                   # the engine's helpers launch on the remembered stream: restore it below
         with torch.cuda.stream(self.side):
             self.side.wait_event(ev)
-            self._dense_work = self.dist.all_reduce(self.gflat[: self.n_dense], group=self.dense_group, async_op=True)
+            work = self.dist.all_reduce(self.gflat[: self.n_dense], group=self.dense_group, async_op=True)
+            if self.unified:
+                if work is not None:
+                    work.wait()                  # orders the side stream behind the collective (no host wait under RCCL)
+                dk = sorted(self.Gd)
+                npart = int(_lib.load().seqrec_opt_sqnorm_ordered_floats(len(dk), 0, 0))
+                call("seqrec_opt_sqnorm_ordered", len(dk), _lib.ptr_array([self.Gd[k] for k in dk]),
+                     _lib.i64_array([self.Gd[k].numel() for k in dk]), None, 0, ptr(self.buf("sq_partials_dense", npart)), npart,
+                     ptr(self.norms[1:2]), 0, None, 0, None, self._stream())
+                self._dense_work = None
+            else:
+                self._dense_work = work
+        self._cur_st = main_st
 
     def _dense_update(self, lr, eps, clipnorm, rows_job=None, n_local=None):
         """After the owned row norms were added into self.sq.  Unified path (n_local given): the dense gradients are
@@ -604,7 +729,7 @@ class ShardedEngine(Engine):
         like the trained quantities (the unified step keeps sums and divides on the device in the update)."""
         loss, out = Engine.grads(self, d, step=step, negatives=negatives)
         if self.unified:
-            nt = float(self._global_tokens(d).item())
+            nt = float(d["n_global"])
             loss = float(self.loss_sum.item()) * self.R / nt
             out = {k: v / np.float32(nt) for k, v in out.items()}
         return loss, out
@@ -624,12 +749,12 @@ class ShardedEngine(Engine):
             mx = float(t[fin].abs().max().item()) if bool(fin.any()) else 0.0
             return (int((~fin).sum().item()), mx)
         ws, out = self.ws, {}
-        reg = {"xen[in]": ("xen", 0, n * w), "xen[tgt]": ("xen", n * w, 2 * n * w), "xen[neg]": ("xen", 2 * n * w, (2 * n + K) * w),
-               "XW": ("XW", 0, n * self.GHp), "Hout": ("Hout", 0, n * w), "gates": ("gates", 0, n * self.GHp), "aux": ("aux", 0, n * w),
-               "ln(dlogits)": ("ln", 0, n * K), "dlt": ("dlt", 0, n), "loss_rows": ("loss_rows", 0, n), "dHd": ("dHd", 0, n * w),
-               "dPre": ("dPre", 0, n * self.GHp), "gall[dX]": ("gall", 0, n * w), "gall[dEtgt]": ("gall", n * w, 2 * n * w),
-               "gall[dEneg]": ("gall", 2 * n * w, (2 * n + K) * w), "backbuf": ("backbuf", 0, L["n_tot"] * w),
-               "sendbuf": ("sendbuf", 0, L["m_tot"] * w)}
+        nsx = self.last_slabs.get("dX_slabs", (None, 1))[1]
+        nsn = self.last_slabs.get("dEneg_slabs", (None, 1))[1]
+        reg = {"sendbuf": ("sendbuf", 0, L["m_tot"] * w), "Eneg": ("Eneg", 0, K * w), "XW": ("XW", 0, n * self.GHp), "Hout": ("Hout", 0, n * w),
+               "gates": ("gates", 0, n * self.GHp), "aux": ("aux", 0, n * w), "ln(dlogits)": ("ln", 0, n * K), "dlt": ("dlt", 0, n),
+               "loss_rows": ("loss_rows", 0, n), "dHd": ("dHd", 0, n * w), "dPre": ("dPre", 0, n * self.GHp),
+               "dX slabs": ("dX_slabs", 0, nsx * n * w), "dEneg slabs": ("dEneg_slabs", 0, nsn * K * w), "backbuf": ("backbuf", 0, L["n_tot"] * w)}
         for name, (buf, lo, hi) in reg.items():
             if buf in ws:
                 out[name] = stat(ws[buf][lo:hi])
@@ -639,7 +764,8 @@ class ShardedEngine(Engine):
         rows = L["send_idx"].long()
         rows = rows[rows >= 0]
         out["TG[touched rows]"] = stat(self.TG[rows])
-        out["sq"], out["ntok"], out["scale"] = float(self.sq.item()), float(self.ntok.item()), float(self.scale.item())
+        out["norms[rows, dense, sum]"] = [float(x) for x in self.norms[:3].tolist()]
+        out["scale"] = float(self.scale.item())
         return out
 
     def _wait_ready(self, d):
@@ -654,38 +780,38 @@ class ShardedEngine(Engine):
         return nt
 
     def _rows_in(self, d, step):
-        """Forward exchange of the unified path (collective 1): -> (xen [2n + K, w] = input rows, target
-        rows, negative rows; neg int32[K] global ids of the negatives)."""
+        """Forward exchange of the unified path (collective 1).  ONE launch packs the owner-side buffer (requested rows, this
+        rank's stratified draws for every requester and their global ids: seqrec_exchange_pack), the all-to-all moves it, ONE
+        launch lifts the K negative rows / ids / log-Q out of the receive buffer; input and target rows stay where they
+        arrived.  -> (recv [n_tot, w], Eneg [K, w], neg int32[K], lq_neg or None, rows_eff int32[m_tot])."""
         c, R = self.cfg, self.R
         st = self._stream()
-        n, w, K = d["n"], self.Hp, c.K
+        w, K = self.Hp, c.K
         Kr = K // R
+        nid = -(-Kr // w)
         plan = d["plan"]
         th, al, _ = self.sampler
-        # -- my stratified draws for every requester, placed into the batch's routing list
-        negl = self.buf("negl", R * Kr, dtype=torch.int32)
-        call("seqrec_sample_negatives", int(c.seed), int(step) * R + self.rank, R * Kr, ptr(th), ptr(al), c.V_out, ptr(negl), st)
-        send_idx = d["send_idx"]
-        call("seqrec_index_affine_i32", ptr(send_idx), ptr(d["neg_slots"]), ptr(negl), None, R * Kr, 1, self.off_out, st)
         sendbuf = self.buf("sendbuf", plan.m_tot, w)
-        self._take(self.TT, send_idx, sendbuf)                                  # id rows (index -1) come out zero
-        call("seqrec_index_affine_i32", ptr(sendbuf), ptr(d["id_slots"]), ptr(negl), None, R * Kr, R, self.rank, st)
+        rows_eff = self.buf("rows_eff", plan.m_tot, dtype=torch.int32)
+        call("seqrec_exchange_pack", ptr(self.TT), self.TT.shape[0], w, ptr(d["send_idx"]), plan.m_tot, int(c.seed), int(step) * R + self.rank,
+             R * Kr, ptr(th), ptr(al), c.V_out, self.off_out, ptr(d["neg_slots"]), ptr(d["id_rows"]), R * nid, Kr, R, self.rank,
+             ptr(sendbuf), ptr(rows_eff), ptr(self.status), st)
         recv = self.ex.fetch_seg(plan, sendbuf)                                 # collective 1
-        xen = self.buf("xen", 2 * n + K, w)
-        self._take(recv, d["take_idx"], xen)
+        Eneg = self.buf("Eneg", K, w)
         neg = self.buf("neg", K, dtype=torch.int32)
-        call("seqrec_index_affine_i32", ptr(neg), None, ptr(recv), ptr(d["negid_idx"]), K, 1, 0, st)
-        return xen, neg
+        lq_neg = self.buf("lq_neg", K) if (c.logq and self.logq_global is not None) else None
+        call("seqrec_exchange_unpack", ptr(recv), w, ptr(d["neg_rows"]), ptr(d["negid_idx"]), K,
+             ptr(self.logq_global if lq_neg is not None else None), ptr(Eneg), ptr(neg), ptr(lq_neg), st)
+        return recv, Eneg, neg, lq_neg, rows_eff
 
     def eval_loss(self, d, negatives=None, step=0):
         """Sampled-softmax CE of this rank's batch (no update), scaled like train_step's return value."""
         if not self.unified:
             raise NotImplementedError("sharded evaluation needs the unified tables (D == H)")
-        n = d["n"]
         self._wait_ready(d)
-        xen, neg = self._rows_in(d, step)
-        self._cell_and_loss(d, xen[:n], xen[n:2 * n], xen[2 * n:], neg, None, None, None, train=False)
-        return self.loss_sum * float(self.R) / self._global_tokens(d)
+        recv, Eneg, neg, lq_neg, _ = self._rows_in(d, step)
+        self._cell_unified(d, recv, Eneg, neg, lq_neg, step, train=False)
+        return self.loss_sum * (float(self.R) / d["n_global"])
 
     def rank_counts(self, d):
         """Global rank of every target of THIS rank's tokens (Recall@K = mean(rank < K)): hidden rows and
@@ -696,10 +822,10 @@ class ShardedEngine(Engine):
         c, R, st = self.cfg, self.R, self._stream()
         n, w = d["n"], self.Hp
         self._wait_ready(d)
-        xen, _ = self._rows_in(d, 0)
-        Hd = self._hidden(d, xen[:n])
+        recv = self._rows_in(d, 0)[0]
+        Hd = self._hidden(d, recv)
         thr = self.buf("thr", n)
-        call("seqrec_target_score", ptr(Hd), w, ptr(xen[n:2 * n]), None, ptr(d["arange"]), n, ptr(thr), st)
+        call("seqrec_target_score", ptr(Hd), w, ptr(recv), None, ptr(d["take_tgt"]), n, ptr(thr), st)
         nm = torch.tensor([n], dtype=torch.int64, device=self.dev)
         self.dist.all_reduce(nm, op=self.dist.ReduceOp.MAX, group=self.group)
         nmax = int(nm.item())
@@ -738,8 +864,7 @@ class ShardedEngine(Engine):
         c, R, st = self.cfg, self.R, self._stream()
         n, w = d["n"], self.Hp
         self._wait_ready(d)
-        xen, _ = self._rows_in(d, 0)
-        Hd = self._hidden(d, xen[:n])
+        Hd = self._hidden(d, self._rows_in(d, 0)[0])
         if rows is not None:
             idx = torch.as_tensor(np.asarray(rows) if not torch.is_tensor(rows) else rows, dtype=torch.int32).to(self.dev)
             Hd = self._take(Hd, idx)
@@ -780,40 +905,54 @@ class ShardedEngine(Engine):
         out_i = torch.gather(ci, 1, out_c.long().clamp_(min=0))          # candidate column -> global item id
         return out_i[:m].contiguous(), out_v[:m].contiguous()
 
-    def _hidden(self, d, X):
+    def _hidden(self, d, recv):
+        """Hidden rows of this rank's tokens from the receive buffer of _rows_in (input rows read through their positions)."""
         P = self.P
         n, Hp, GHp, Dp = d["n"], self.Hp, self.GHp, self.Dp
         XW = self.buf("XW", n, GHp)
-        self.gemm(1, 0, n, GHp, Dp, X, Dp, P["W"], GHp, XW, GHp, bias=P.get("b"), tag="xw")
+        self.gemm(1, 0, n, GHp, Dp, recv, self.Hp, P["W"], GHp, XW, GHp, bias=P.get("b"), tag="xw",
+                  fuse=_lib.gemm_fuse(a_index=d["take_in"]))
         Hout = self.buf("Hout", n, Hp); gates = self.buf("gates", n, GHp); aux = self.buf("aux", n, Hp)
         self._scan_fwd(d, XW, Hout, gates, aux)
         return Hout
 
     def _step_unified(self, d, lr, eps, clipnorm, step, apply_update):
+        """Collectives: all-to-all (rows in), all-reduce (dense gradients, side stream, under what follows), all-to-all (row
+        gradients out), all-reduce (ONE float: the owned rows' squared gradient norm).  Launches besides the cell's own:
+        exchange_pack, exchange_unpack, exchange_grad_pack, the combined scatter, norm (+ batch loss) in a fixed order,
+        the 2-term sum, the update."""
         c, R = self.cfg, self.R
         st = self._stream()
         n, w, K = d["n"], self.Hp, c.K
-        Kr = K // R
         plan = d["plan"]
-        send_idx = d["send_idx"]
-        xen, neg = self._rows_in(d, step)
-        gall = self.buf("gall", 2 * n + K, w)
-        self._cell_and_loss(d, xen[:n], xen[n:2 * n], xen[2 * n:], neg, gall[:n], gall[n:2 * n], gall[2 * n:],
-                            reduce_dense=apply_update)
-        # -- row gradients travel the same routes back; one scatter list into the unified gradient table
+        recv, Eneg, neg, lq_neg, rows_eff = self._rows_in(d, step)
+        r = self._cell_unified(d, recv, Eneg, neg, lq_neg, step, reduce_dense=apply_update)
+        # -- row gradients travel the same routes back: the routing launch reads dX / dEneg as split-K slabs and dlt * Hd in place
         backbuf = self.buf("backbuf", plan.n_tot, w)
-        self._take(gall, d["back_idx"], backbuf)
+        (dX, nsx, ssx), (dEn, nsn, ssn) = r["dX"], r["dEneg"]
+        call("seqrec_exchange_grad_pack", ptr(d["back_idx"]), plan.n_tot, n, K, w, ptr(dX), nsx, ssx, ptr(r["Hd"]), ptr(r["dlt"]),
+             ptr(dEn), nsn, ssn, ptr(backbuf), st)
         gback = self.ex.push_seg(plan, backbuf)                                 # collective 2
-        job, cnt = _lib.rows_jobs([dict(table=self.TT, accum=self.TA, gtab=self.TG, slot=self.TS, rows=send_idx, vals=gback,
+        job, cnt = _lib.rows_jobs([dict(table=self.TT, accum=self.TA, gtab=self.TG, slot=self.TS, rows=rows_eff, vals=gback,
                                         ldv=w, row_scale=None, n=plan.m_tot, width=w, base=0)])
         call("seqrec_rows_scatter_add_multi", job, cnt, st)
-        self._last = {"gback": gback, "send_idx": send_idx, "n": n, "m_tot": plan.m_tot, "n_tot": plan.n_tot}    # what a failure report names
+        self._last = {"gback": gback, "send_idx": rows_eff, "n": n, "m_tot": plan.m_tot, "n_tot": plan.n_tot}    # what a failure report names
         if not apply_update:
             return None
-        call("seqrec_fill_f32", ptr(self.sq), 0.0, 1, st)
-        call("seqrec_rows_sqnorm_multi", job, cnt, ptr(self.sq), st)
-        self._dense_update(lr, eps, clipnorm, (job, cnt), n_local=n)            # collective 3 (+ the overlapped dense one)
-        return self.loss_sum * float(self.R) / self.ntok    # this rank's share, scaled so the mean over ranks is the global loss
+        # -- norm of the owned row gradients (+ this rank's batch loss) in a fixed order, summed over the ranks
+        npart = int(_lib.load().seqrec_opt_sqnorm_ordered_floats(0, 1, plan.m_tot))
+        call("seqrec_opt_sqnorm_ordered", 0, None, None, job, cnt, ptr(self.buf("sq_partials", npart)), npart, ptr(self.norms[0:1]), 0,
+             ptr(r["loss_rows"]), n, ptr(self.loss_out), st)
+        self.dist.all_reduce(self.norms[0:1], group=self.group)                 # collective 3: one float
+        torch.cuda.current_stream(self.dev).wait_stream(self.side)              # dense gradients reduced, their norm in norms[1]
+        call("seqrec_reduce_sum", ptr(self.norms), 2, ptr(self.norms[2:3]), 0, st)
+        dk = sorted(self.Gd)
+        call("seqrec_opt_apply", len(dk), _lib.ptr_array([self.P[k] for k in dk]), _lib.ptr_array([self.A[k] for k in dk]),
+             _lib.ptr_array([self.Gd[k] for k in dk]), _lib.i64_array([self.Gd[k].numel() for k in dk]), job, cnt, ptr(self.norms[2:3]),
+             float(clipnorm if clipnorm else 0.0), lr, eps, ptr(self.scale), None, ptr(d["ntok"]), ptr(self.status), st)
+        self.sq = self.norms[2:3]
+        self.upack_dirty = True
+        return self.loss_sum * (float(self.R) / d["n_global"])    # this rank's share, scaled so the mean over ranks is the global loss
 
     def _step_split(self, d, lr, eps, clipnorm, step, apply_update):
         """D != H: the two tables have different row widths, one exchange per table."""
@@ -836,7 +975,7 @@ class ShardedEngine(Engine):
         Eneg = got[:, :Hp].contiguous()
         neg = got[:, Hp].contiguous().view(torch.int32)
         dX = self.buf("dX", n, Dp); dEtgt = self.buf("dEtgt", n, Hp); dEneg = self.buf("dEneg", K, Hp)
-        self._cell_and_loss(d, X, Etgt, Eneg, neg, dX, dEtgt, dEneg)
+        self._cell_and_loss_split(d, X, Etgt, Eneg, neg, dX, dEtgt, dEneg)
         Gt = self.Gt
         jobs = []
         g_in, r_in = self.ex.push(d["plan_in"], dX, self._take)

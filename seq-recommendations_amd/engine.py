@@ -34,6 +34,7 @@ import os as _os
 # backward shapes: 512 -> 1024 takes dEneg from 53 to 45 us and dH from 46 to 43 us)
 SPLITK_TARGET_WGS = int(_os.environ.get("SEQREC_SPLITK_WGS", "512"))
 SPLITK_MIN_K = int(_os.environ.get("SEQREC_SPLITK_MIN_K", "512"))
+SPLITK_FILL_WGS = int(_os.environ.get("SEQREC_SPLITK_FILL", "1152"))
 
 # Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg):
 # _PROF = {"events": [(name, tag, start_event, end_event), ...]} while enabled, else None.
@@ -273,6 +274,7 @@ class Engine:
         # outside its table): kernels OR their bits into this word, check_status() raises on it at the next host sync
         self.status = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.pinned = PinnedRing(self.dev)
+        self.drop_seed = cfg.seed       # RNG stream of the dropout masks (distributed.ShardedEngine: one per rank)
 
     # ------------------------------------------------------------------ device-side failures
     def check_status(self):
@@ -379,26 +381,26 @@ class Engine:
         ws = 0
         for m in range(128, n + 64, 64):
             m = min(m, n)
-            use = [self._splitk(m, Hp, c.K if c.output == "sampled" else c.V_out) * m * Hp]            # dH
+            use = [self._splitk(m, Hp, c.K if c.output == "sampled" else c.V_out, fill=True) * m * Hp]            # dH
             if c.output == "sampled":
                 use.append(self._splitk(c.K, Hp, m) * c.K * Hp)                                          # dEneg
             else:
                 use.append(self._splitk(Hp, c.V_out, m) * Hp * c.V_out)                                  # dWout
             kin = self.Dp if c.input == "embed" else (self.Fp if c.input == "dense" else 0)
             if kin:
-                use.append(self._splitk(m, kin, GHp) * m * kin)                                          # dX
+                use.append(self._splitk(m, kin, GHp, fill=True) * m * kin)                                          # dX
             shapes = [(Hp, GHp), (kin, GHp), (1, GHp)]                                                   # grouped dU, dW, db
             tiles = sum(((a + 63) // 64) * ((b + 63) // 64) for a, b in shapes if a)
-            sk = self._splitk_tiles(tiles, m)
+            sk = self._splitk_tiles(tiles, m, fill=True)
             use.append(sk * sum(a * b for a, b in shapes))
             ws = max(ws, max(use))
         need["gemm_ws"] = ws
         if self._slab_scatter and c.merge != "sorted":      # the slab forms of dX / dEneg keep their own buffers up to the scatter
             if c.input == "embed":
-                need["dX_slabs"] = max(1, GHp // self._slab_min_k) * n * self.Dp
+                need["dX_slabs"] = max(1, min(32, GHp // self._slab_min_k)) * n * self.Dp
             if c.output == "sampled":
                 if self._slab_dh:
-                    need["dH_slabs"] = max(self._splitk(m, Hp, c.K) * m * Hp for m in range(64, n + 64, 64))
+                    need["dH_slabs"] = max(self._splitk(m, Hp, c.K, fill=True) * m * Hp for m in range(64, n + 64, 64))
                 need["dEneg_slabs"] = max(self._splitk(c.K, Hp, m) for m in range(64, n + 64, 64)) * c.K * Hp
         for name, sz in need.items():
             self.buf(name, int(max(sz, 1)))
@@ -443,14 +445,22 @@ class Engine:
         return ws, int(ns.value), M * N
 
     @staticmethod
-    def _splitk(M, N, K):
+    def _splitk(M, N, K, fill=False):
         """Split K until about SPLITK_TARGET_WGS workgroups are in flight, never below SPLITK_MIN_K per slab: every split
         costs a slab round trip + a share of the reduce launch (tools/bench_gemm2.py: dH 3, dEneg 4, dX 1, dW+dU 5 at c3)."""
-        return Engine._splitk_tiles(((M + 63) // 64) * ((N + 63) // 64), K)
+        return Engine._splitk_tiles(((M + 63) // 64) * ((N + 63) // 64), K, fill=fill)
 
     @staticmethod
-    def _splitk_tiles(tiles, K, min_k=None):
-        return int(max(1, min(32, SPLITK_TARGET_WGS // max(tiles, 1), K // (min_k or SPLITK_MIN_K))))
+    def _splitk_tiles(tiles, K, min_k=None, fill=False):
+        """fill: products with 256 or more tiles that would not be split at all (c4: dH 320, dX 320, dW+dU 544 tiles of 64 x 64 on
+        1 280 workgroup slots -- one thin round, 1.25-2.1 workgroups per CU) are split until ~SPLITK_FILL_WGS slots are taken
+        (same-box A/B at c4, tools/ab_c4.sh: dH 142 -> 105 us, dX 71 -> 54, dW+dU 210 -> 176; dEneg -- 504 tiles, 8 MB per
+        slab for the scatter to re-read -- is the one product that loses and does not ask for it)."""
+        mk = min_k or SPLITK_MIN_K
+        sk = SPLITK_TARGET_WGS // max(tiles, 1)
+        if fill and tiles >= 256:
+            sk = max(sk, SPLITK_FILL_WGS // tiles)
+        return int(max(1, min(32, sk, K // mk)))
 
     # ------------------------------------------------------------------ parameters (Keras layouts)
     def _gate_pad(self, w, rows_p):
@@ -649,14 +659,14 @@ class Engine:
                 ids_host = rb.ids if rb.ids is not None else d["ids"].cpu().numpy()     # device-packed batch
                 rk = torch.from_numpy(key * c.V_in + ids_host.astype(np.int64)).to(self.dev)
                 m = self.buf("in_scale", n)
-                call("seqrec_dropout_mask", c.seed, sid, ptr(rk), n, 1, 1, float(c.drop_in), ptr(m), st)
+                call("seqrec_dropout_mask", self.drop_seed, sid, ptr(rk), n, 1, 1, float(c.drop_in), ptr(m), st)
             else:
                 w = c.D if c.input == "embed" else c.V_in
                 ld = self.Dp if c.input == "embed" else self.Fp
                 rk = torch.from_numpy(key).to(self.dev)
                 m = self.buf("in_mask", n, ld)
                 m.zero_()
-                call("seqrec_dropout_mask", c.seed, sid, ptr(rk), n, w, ld, float(c.drop_in), ptr(m), st)
+                call("seqrec_dropout_mask", self.drop_seed, sid, ptr(rk), n, w, ld, float(c.drop_in), ptr(m), st)
             out["in"] = m
             out["_rk_in"] = rk
         if c.drop_rec > 0:
@@ -668,7 +678,7 @@ class Engine:
             rkd = torch.from_numpy(rk).to(self.dev)
             m = self.buf("rec_mask", G * B, self.Hp)
             m.zero_()
-            call("seqrec_dropout_mask", c.seed, sid, ptr(rkd), G * B, c.H, self.Hp, float(c.drop_rec), ptr(m), st)
+            call("seqrec_dropout_mask", self.drop_seed, sid, ptr(rkd), G * B, c.H, self.Hp, float(c.drop_rec), ptr(m), st)
             out["rec"] = m
             out["_rk_rec"] = rkd
         if c.drop_out > 0:
@@ -676,7 +686,7 @@ class Engine:
             rk = torch.from_numpy(key).to(self.dev)
             m = self.buf("out_mask", n, self.Hp)
             m.zero_()
-            call("seqrec_dropout_mask", c.seed, sid, ptr(rk), n, c.H, self.Hp, float(c.drop_out), ptr(m), st)
+            call("seqrec_dropout_mask", self.drop_seed, sid, ptr(rk), n, c.H, self.Hp, float(c.drop_out), ptr(m), st)
             out["out"] = m
             out["_rk_out"] = rk
         return out
@@ -903,14 +913,14 @@ class Engine:
                     call("seqrec_rows_scatter_add", ptr(Gd["Wyy"]), ptr(sl), ptr(d["ids"]), ptr(dl), Vp, None, n, Vp, 0, st)
                 if c.yy_bias and tr["byy"]:
                     call("seqrec_colsum", ptr(dl), n, c.V_out, Vp, ptr(Gd["byy"]), 0, ptr(cs_ws), st)
-            self.gemm(1, 1, n, Hp, c.V_out, dl, Vp, P["Wout"], Vp, dHd, Hp, splitk=self._splitk(n, Hp, c.V_out), tag="dH")
+            self.gemm(1, 1, n, Hp, c.V_out, dl, Vp, P["Wout"], Vp, dHd, Hp, splitk=self._splitk(n, Hp, c.V_out, fill=True), tag="dH")
         else:
             K = c.K
             tname = "E" if c.tied else "Eout"
             Et = P[tname]
             dln, dlt, neg, Eneg = r["dln"], r["dlt"], r["neg"], r["Eneg"]
             # dH = dlogits . Eneg + dlt * Eout[tgt]: the target-row term rides in the GEMM's final write
-            sk_h = self._splitk(n, Hp, K)
+            sk_h = self._splitk(n, Hp, K, fill=True)
             if self._slab_dh and self.stepwise and sk_h > 1 and "out" not in drops:
                 # dH's only reader is the BPTT: its split-K slabs and the target-row term go there as parts (the cluster scan
                 # adds them where it reads dHout -- no reduce launch; other scan forms sum them into dHd first)
@@ -996,11 +1006,11 @@ class Engine:
                 if self._slab_scatter and c.merge != "sorted" and "in" not in drops:
                     # dX too is read by the scatter alone: split K until the chip is full (160 tiles of 64x64 at c3: 3 slabs of
                     # K = 256 measured best of 1 / 2 / 3 / 4 / 6), slabs unreduced
-                    sk_x = self._splitk_tiles(((n + 63) // 64) * ((self.Dp + 63) // 64), GHp, min_k=self._slab_min_k)
+                    sk_x = self._splitk_tiles(((n + 63) // 64) * ((self.Dp + 63) // 64), GHp, min_k=self._slab_min_k, fill=True)
                     dX, ns_x, ss_x = self.gemm_slabs(1, 1, n, self.Dp, GHp, dPre, GHp, P["W"], GHp, "dX_slabs", sk_x, tag="dX")
                 else:
                     dX = self.buf("dX", n, self.Dp)
-                    self.gemm(1, 1, n, self.Dp, GHp, dPre, GHp, P["W"], GHp, dX, self.Dp, splitk=self._splitk(n, self.Dp, GHp), tag="dX")
+                    self.gemm(1, 1, n, self.Dp, GHp, dPre, GHp, P["W"], GHp, dX, self.Dp, splitk=self._splitk(n, self.Dp, GHp, fill=True), tag="dX")
                     if "in" in drops:
                         call("seqrec_mul", ptr(dX), ptr(drops["in"]), ptr(dX), n * self.Dp, st)
                 base_i = (n + c.K) if c.tied else 0
@@ -1015,7 +1025,7 @@ class Engine:
         if wgrad:
             # the weight gradients A^T . dPre all reduce over the tokens: one grouped split-K launch
             tiles = sum(((w_[0] + 63) // 64) * ((w_[1] + 63) // 64) for w_ in wgrad)
-            sk = self._splitk_tiles(tiles, n)
+            sk = self._splitk_tiles(tiles, n, fill=True)
             wsz = sum(sk * w_[0] * w_[1] for w_ in wgrad)
             wsp = self.buf("gemm_ws", wsz) if sk > 1 else None
             if (self._slab_wgrad and apply_update and sk > 1 and c.merge != "sorted" and not self.priors and len(sparse_jobs) <= 4

@@ -15,6 +15,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import nn as onn, rng as orng          # noqa: E402
 from helpers import make_sessions, pad_batch       # noqa: E402
+from engine_helpers import oracle_drop             # noqa: E402
 
 
 def _poison_empty():
@@ -52,7 +53,10 @@ def main():
     for case in (dict(cell="gru", V=1501, H=128, Dm=64, K=64 * R, tied=False),      # D != H: one exchange per table
                  dict(cell="gru", V=1201, H=128, Dm=128, K=160 * R, tied=False),    # unified tables, ids span 2 id rows
                  dict(cell="lstm", V=900, H=64, Dm=64, K=32 * R, tied=True),
-                 dict(cell="lstm", V=1100, H=512, Dm=512, K=48 * R, tied=False)):       # c4's cell: LSTM 512, row-sharded
+                 dict(cell="lstm", V=1100, H=512, Dm=512, K=48 * R, tied=False),        # c4's cell: LSTM 512, row-sharded
+                 # dropout in the sharded step: the reference's main run trains with z_to_y_drop = 0.3 (experiments_server.py:108-114)
+                 dict(cell="lstm", V=1000, H=128, Dm=128, K=40 * R, tied=False, drop=dict(drop_out=0.3)),
+                 dict(cell="gru", V=950, H=128, Dm=128, K=40 * R, tied=True, drop=dict(drop_in=0.1, drop_rec=0.2, drop_out=0.3))):
         V, H, Dm, K, tied, cell = case["V"], case["H"], case["Dm"], case["K"], case["tied"], case["cell"]
         G = onn.N_GATES[cell]
         rs = np.random.default_rng(4)                       # identical on every rank: the GLOBAL model
@@ -62,8 +66,9 @@ def main():
             p["Eout"] = rs.normal(0, 0.3, (V, H))
         p = {k: v.astype(np.float32) for k, v in p.items()}
         probs = Sm.log_uniform_probs(V)
+        dropkw = case.get("drop", {})
         cfg = E.NetConfig(cell=cell, act="relu", H=H, V_in=V, V_out=V, input="embed", D=Dm, output="sampled", K=K, tied=tied,
-                          logq=True, seed=9)
+                          logq=True, seed=9, **dropkw)
         eng = D.ShardedEngine(cfg, "cuda:0", D.HostStagedDist(dist))
         for k in ("W", "U", "b"):
             eng.set_param(k, p[k])
@@ -97,13 +102,12 @@ def main():
                 raise
             sc_ = float(eng.scale.item())
             assert np.isfinite(sc_) and sc_ > 0.0, (case, rank, s, sc_)
-            if eng.unified and s == 0:
+            if eng.unified and s == 0 and not dropkw:
                 assert ev == losses[0], (ev, losses[0])
         if eng.unified:
             # sharded Recall@K support: global rank of every target, counted shard by shard
             rk = eng.rank_counts(d).cpu().numpy()
-            xen, _ = eng._rows_in(d, 0)
-            hd = eng._hidden(d, xen[: d["n"]]).cpu().numpy()[:, :H]
+            hd = eng._hidden(d, eng._rows_in(d, 0)[0]).cpu().numpy()[:, :H]
             tname = "E" if tied else "Eout"
             info = [None] * R
             dist.all_gather_object(info, (rk, hd, d["tgt"].cpu().numpy(), eng.get_param(tname)))
@@ -158,7 +162,10 @@ def main():
                 gsum, lsum = {}, 0.0
                 for r in range(R):
                     neg = np.concatenate([draws[j][r * Kr:(r + 1) * Kr].astype(np.int64) * R + j for j in range(R)]).astype(np.int32)
-                    out = net.forward(pad_batch(per_rank[r]), negatives=neg, logq=logq)
+                    import dataclasses
+                    batch_r = pad_batch(per_rank[r])
+                    drop_r = oracle_drop(dataclasses.replace(cfg, seed=cfg.seed + 1000003 * (r + 1)), per_rank[r], batch_r, s)   # rank r's mask stream
+                    out = net.forward(batch_r, negatives=neg, logq=logq, drop=drop_r)
                     g = net.backward()
                     wgt = n_r[r] / N
                     lsum += out["loss"] * wgt
