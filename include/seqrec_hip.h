@@ -403,8 +403,10 @@ int seqrec_opt_sqnorm_ordered(int n_dense, const float* const* grads, const int6
 int seqrec_opt_apply(int n_dense, float* const* params, float* const* accums, const float* const* grads,
                      const int64_t* numel, const seqrec_rows_job* jobs_host, int n_jobs, const float* sq,
                      float clipnorm, float lr, float eps, float* scale_out, float* zero_next,
-                     const float* grad_div, uint32_t* status, void* stream);
-/*      status (nullable device word): *sq not a finite number >= 0, *grad_div not a finite number > 0 or a clip scale that
+                     const float* grad_div, uint32_t* status, const float* sq_extra, void* stream);
+/*      sq_extra (nullable device scalar): a second part of the squared norm, added to *sq (multi-GPU: the all-reduced norm of
+ *      the row gradients + the fixed-order norm of the dense gradients, kept apart until here).
+ *      status (nullable device word): *sq not a finite number >= 0, *grad_div not a finite number > 0 or a clip scale that
  *      is 0 / not finite set SEQREC_STATUS_BAD_NORM / _BAD_DIVISOR / _BAD_SCALE and the launch changes NOTHING (weights,
  *      accumulators and gradient tables stay as they are; *scale_out still receives the scale): an overflowing or
  *      uninitialised gradient value can neither poison the weights nor turn the step into a silent no-op (scale 0).

@@ -82,7 +82,7 @@ _SIGS = {
     "seqrec_opt_sqnorm": [I, P, P, P, I, P, P, L, P, P],
     "seqrec_opt_sqnorm_slabs": [I, P, P, I, P, I, P, P, I, P, P, L, P, P],
     "seqrec_loss_reduce": [P, L, P, P],
-    "seqrec_opt_apply": [I, P, P, P, P, P, I, P, F, F, F, P, P, P, P, P],
+    "seqrec_opt_apply": [I, P, P, P, P, P, I, P, F, F, F, P, P, P, P, P, P],
     "seqrec_prior_grad": [P, P, L, C.c_float, P, P, P],
     "seqrec_pack_batch": [P, P, P, P, I, I, P, P, P, P],
     "seqrec_pack_batch_host": [P, P, P, P, I, I, P, P, P, P, P, P],

@@ -621,10 +621,10 @@ __global__ void opt_sqnorm_partial_kernel(OptPlan pl, float* __restrict__ partia
 }
 __global__ void opt_apply_kernel(OptPlan pl, const float* __restrict__ sq, float clipnorm, float lr, float eps,
                                  float* __restrict__ scale_out, float* __restrict__ zero_next, const float* __restrict__ grad_div,
-                                 unsigned* __restrict__ status) {
+                                 unsigned* __restrict__ status, const float* __restrict__ sq_extra) {
     // grad_div (nullable device scalar): the gradients in memory are SUMS still to be divided by it (the global token
     // count of a multi-GPU step, known only after the all-reduce): norm and update use g / grad_div
-    const float sqv = sq[0], gd = grad_div ? grad_div[0] : 1.f;
+    const float sqv = sq_extra ? sq[0] + sq_extra[0] : sq[0], gd = grad_div ? grad_div[0] : 1.f;
     const float inv_div = 1.f / gd;
     const float nrm = sqrtf(sqv) * inv_div;
     const float sc = ((clipnorm > 0.f && nrm >= clipnorm) ? clipnorm / nrm : 1.f) * inv_div;   // Keras clip_norm (== clip_scale_kernel)
@@ -1515,7 +1515,7 @@ extern "C" int seqrec_opt_sqnorm_ordered(int n_dense, const float* const* grads,
 extern "C" int seqrec_opt_apply(int n_dense, float* const* params, float* const* accums, const float* const* grads,
                                 const int64_t* numel, const seqrec_rows_job* jobs_host, int n_jobs, const float* sq,
                                 float clipnorm, float lr, float eps, float* scale_out, float* zero_next,
-                                const float* grad_div, uint32_t* status, void* stream) {
+                                const float* grad_div, uint32_t* status, const float* sq_extra, void* stream) {
     OptPlan pl;
     long maxn;
     const int rc = fill_opt_plan(n_dense, params, accums, grads, numel, jobs_host, n_jobs, true, pl, maxn);
@@ -1523,7 +1523,7 @@ extern "C" int seqrec_opt_apply(int n_dense, float* const* params, float* const*
     if (!sq || !scale_out) return SEQREC_E_ARG;
     const unsigned gx = (unsigned)std::max<long>(n_dense ? 256 : 1, (maxn + 3) / 4);
     hipLaunchKernelGGL(opt_apply_kernel, dim3(gx, n_dense + n_jobs), dim3(256), 0, as_stream(stream), pl, sq, clipnorm, lr, eps,
-                       scale_out, zero_next, grad_div, status);
+                       scale_out, zero_next, grad_div, status, sq_extra);
     SEQREC_LAUNCH_CHECK();
     return 0;
 }

@@ -48,11 +48,37 @@ class HostStagedDist:
     """torch.distributed look-alike that stages device tensors through the host and a gloo group.
     Debug / test transport only: RCCL refuses two ranks on one device, so the multi-rank logic of
     ShardedEngine and bench.py is exercised on a ONE-GPU box with several processes sharing cuda:0
-    (tests/dist_gpu_worker.py, SEQREC_BENCH_BACKEND=gloo-staged).  Never used by the product path."""
+    (tests/dist_gpu_worker.py, SEQREC_BENCH_BACKEND=gloo-staged).  Never used by the product path.
+    Every device <-> host hop goes through PAGE-LOCKED staging tensors (no pageable multi-MB copies while four
+    processes share the GPU), and with verify=True every host -> device hop is read back and compared: a transport
+    that corrupts data says so itself instead of showing up as a wrong training result."""
 
-    def __init__(self, dist):
+    def __init__(self, dist, verify=False):
         self.d = dist
         self.ReduceOp = dist.ReduceOp
+        self.verify = verify
+
+    def _down(self, t):
+        """device tensor -> page-locked host tensor (synchronous)"""
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        h.copy_(t.detach())
+        return h
+
+    def _up(self, dst, h, what):
+        """host tensor -> device tensor (synchronous), optionally verified by a read-back"""
+        if not h.is_pinned():
+            p = torch.empty(h.shape, dtype=h.dtype, pin_memory=True)
+            p.copy_(h)
+            h = p
+        dst.copy_(h)
+        if self.verify:
+            back = torch.empty(h.shape, dtype=h.dtype, pin_memory=True)
+            back.copy_(dst)
+            same = back.view(torch.uint8).reshape(-1) == h.view(torch.uint8).reshape(-1) if h.numel() else torch.ones(0, dtype=torch.bool)
+            if not bool(same.all()):
+                bad = int((~same).sum())
+                raise RuntimeError("HostStagedDist: host -> device copy of %s (%d bytes) arrived with %d differing bytes: the TEST "
+                                   "TRANSPORT corrupted data (not the engine)" % (what, h.numel() * h.element_size(), bad))
 
     def get_world_size(self, group=None):
         return self.d.get_world_size()
@@ -61,10 +87,10 @@ class HostStagedDist:
         return self.d.get_rank()
 
     def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None, group=None):
-        o = torch.empty(out.shape, dtype=out.dtype)
-        self.d.all_to_all_single(o, inp.detach().cpu().contiguous(), output_split_sizes=output_split_sizes,
+        o = torch.zeros(out.shape, dtype=out.dtype, pin_memory=True)
+        self.d.all_to_all_single(o, self._down(inp).contiguous(), output_split_sizes=output_split_sizes,
                                  input_split_sizes=input_split_sizes)
-        out.copy_(o)
+        self._up(out, o, "all_to_all result")
 
     class _Done:
         def wait(self):
@@ -74,21 +100,21 @@ class HostStagedDist:
         return None                      # one gloo group: the staged transport is synchronous anyway
 
     def all_reduce(self, t, op=None, group=None, async_op=False):
-        c = t.detach().cpu()
+        c = self._down(t)
         self.d.all_reduce(c, op=self.d.ReduceOp.SUM if op is None else op)
-        t.copy_(c)
+        self._up(t, c, "all_reduce result")
         return HostStagedDist._Done() if async_op else None
 
     def all_gather(self, outs, t, group=None):
-        cs = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
-        self.d.all_gather(cs, t.detach().cpu())
+        cs = [torch.zeros(o.shape, dtype=o.dtype, pin_memory=True) for o in outs]
+        self.d.all_gather(cs, self._down(t))
         for o, c in zip(outs, cs):
-            o.copy_(c)
+            self._up(o, c, "all_gather result")
 
     def broadcast(self, t, src=0, group=None):
-        c = t.detach().cpu()
+        c = self._down(t)
         self.d.broadcast(c, src=src)
-        t.copy_(c)
+        self._up(t, c, "broadcast result")
 
     def barrier(self, group=None):
         self.d.barrier()
@@ -360,8 +386,9 @@ class ShardedEngine(Engine):
         self.n_dense = tot
         self.sq = self.gflat[tot:tot + 1]
         self.ntok = self.gflat[tot + 1:tot + 2]      # split path: global token count of the step (after the all-reduce)
-        # unified path: [row-gradient norm (all-reduced) | dense norm (fixed order) | their sum | global token count of the step]
+        # unified path: [row-gradient norm, slot A (all-reduced) | dense norm (fixed order) | row-gradient norm, slot B | unused]
         self.norms = torch.zeros(4, dtype=torch.float32, device=self.dev)
+        self._norm_par = 0
         # the dense all-reduce runs on its own stream and (RCCL) its own communicator, under the row-gradient exchange
         self.side = torch.cuda.Stream(device=self.dev)
         self.dense_group = group
@@ -721,7 +748,7 @@ class ShardedEngine(Engine):
         arr, cnt = rows_job if rows_job is not None else (None, 0)
         call("seqrec_opt_apply", len(dk), _lib.ptr_array([P[k] for k in dk]), _lib.ptr_array([self.A[k] for k in dk]), gp, nn,
              arr, cnt, ptr(self.sq), float(clipnorm if clipnorm else 0.0), lr, eps, ptr(self.scale), None, ptr(div),
-             ptr(self.status), st)
+             ptr(self.status), None, st)
         self.upack_dirty = True
 
     def grads(self, d, step=0, negatives=None):
@@ -764,7 +791,7 @@ class ShardedEngine(Engine):
         rows = L["send_idx"].long()
         rows = rows[rows >= 0]
         out["TG[touched rows]"] = stat(self.TG[rows])
-        out["norms[rows, dense, sum]"] = [float(x) for x in self.norms[:3].tolist()]
+        out["norms[rows A, dense, rows B]"] = [float(x) for x in self.norms[:3].tolist()]
         out["scale"] = float(self.scale.item())
         return out
 
@@ -939,18 +966,21 @@ class ShardedEngine(Engine):
         self._last = {"gback": gback, "send_idx": rows_eff, "n": n, "m_tot": plan.m_tot, "n_tot": plan.n_tot}    # what a failure report names
         if not apply_update:
             return None
-        # -- norm of the owned row gradients (+ this rank's batch loss) in a fixed order, summed over the ranks
-        npart = int(_lib.load().seqrec_opt_sqnorm_ordered_floats(0, 1, plan.m_tot))
-        call("seqrec_opt_sqnorm_ordered", 0, None, None, job, cnt, ptr(self.buf("sq_partials", npart)), npart, ptr(self.norms[0:1]), 0,
-             ptr(r["loss_rows"]), n, ptr(self.loss_out), st)
-        self.dist.all_reduce(self.norms[0:1], group=self.group)                 # collective 3: one float
-        torch.cuda.current_stream(self.dev).wait_stream(self.side)              # dense gradients reduced, their norm in norms[1]
-        call("seqrec_reduce_sum", ptr(self.norms), 2, ptr(self.norms[2:3]), 0, st)
+        # -- norm of the owned row gradients (+ this rank's batch loss), summed over the ranks.  Two slots alternate (norms[0] /
+        # norms[2]): this step's update launch clears the slot of the NEXT step (zero_next), nobody touches it meanwhile.  Any
+        # summation order will do here -- the all-reduce hands every rank the same sum.
+        cur = self.norms[0:1] if self._norm_par == 0 else self.norms[2:3]
+        nxt = self.norms[2:3] if self._norm_par == 0 else self.norms[0:1]
+        self._norm_par ^= 1
+        call("seqrec_opt_sqnorm", 0, None, None, job, cnt, ptr(cur), ptr(r["loss_rows"]), n, ptr(self.loss_out), st)
+        self.dist.all_reduce(cur, group=self.group)                             # collective 3: one float
+        torch.cuda.current_stream(self.dev).wait_stream(self.side)              # dense gradients reduced, their fixed-order norm in norms[1]
         dk = sorted(self.Gd)
         call("seqrec_opt_apply", len(dk), _lib.ptr_array([self.P[k] for k in dk]), _lib.ptr_array([self.A[k] for k in dk]),
-             _lib.ptr_array([self.Gd[k] for k in dk]), _lib.i64_array([self.Gd[k].numel() for k in dk]), job, cnt, ptr(self.norms[2:3]),
-             float(clipnorm if clipnorm else 0.0), lr, eps, ptr(self.scale), None, ptr(d["ntok"]), ptr(self.status), st)
-        self.sq = self.norms[2:3]
+             _lib.ptr_array([self.Gd[k] for k in dk]), _lib.i64_array([self.Gd[k].numel() for k in dk]), job, cnt, ptr(cur),
+             float(clipnorm if clipnorm else 0.0), lr, eps, ptr(self.scale), ptr(nxt), ptr(d["ntok"]), ptr(self.status),
+             ptr(self.norms[1:2]), st)
+        self.sq = cur
         self.upack_dirty = True
         return self.loss_sum * (float(self.R) / d["n_global"])    # this rank's share, scaled so the mean over ranks is the global loss
 

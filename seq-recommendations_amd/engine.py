@@ -124,11 +124,17 @@ class PinnedRing:
     reference dies at the end of the caller's loop body is then free to be overwritten under the copy.  Here the bytes
     are first copied into a page-locked slot that the ring owns, the device copy is issued from the slot and an event is
     recorded behind it on the stream it was issued on; a slot is reused only after its event has completed (the host
-    waits if the ring is full: 64 slots, i.e. 64 uploads in flight)."""
+    waits if the ring is full: 64 slots, i.e. 64 uploads in flight).  The slots are carved out of ONE page-locked arena
+    (16 MB, allocated at the first upload: a hipHostMalloc per slot cost ~3 ms each inside the first 64 steps); an upload
+    larger than a slot gets a page-locked buffer of its own."""
+    SLOT_BYTES = 256 * 1024
 
     def __init__(self, device, slots=64):
         self.dev = device
-        self.slots = [None] * slots        # (pinned uint8 tensor, event or None)
+        self.n = slots
+        self.arena = None
+        self.big = [None] * slots          # per-slot dedicated buffer for uploads larger than SLOT_BYTES
+        self.events = [None] * slots
         self.pos = 0
 
     def put(self, arr):
@@ -139,18 +145,23 @@ class PinnedRing:
             return torch.empty(a.shape, dtype=tdt, device=self.dev)
         nbytes = a.nbytes
         i = self.pos
-        self.pos = (i + 1) % len(self.slots)
-        buf, ev = self.slots[i] if self.slots[i] is not None else (None, None)
-        if ev is not None:
-            ev.synchronize()               # the copy issued from this slot len(slots) uploads ago
-        if buf is None or buf.numel() < nbytes:
-            buf = torch.empty(max(nbytes, 4096), dtype=torch.uint8).pin_memory()
-        host = buf[:nbytes].view(tdt)
+        self.pos = (i + 1) % self.n
+        if self.events[i] is not None:
+            self.events[i].synchronize()   # the copy issued from this slot `slots` uploads ago
+        if nbytes <= self.SLOT_BYTES:
+            if self.arena is None:
+                self.arena = torch.empty(self.n * self.SLOT_BYTES, dtype=torch.uint8).pin_memory()
+            buf = self.arena[i * self.SLOT_BYTES: i * self.SLOT_BYTES + nbytes]
+        else:
+            if self.big[i] is None or self.big[i].numel() < nbytes:
+                self.big[i] = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+            buf = self.big[i][:nbytes]
+        host = buf.view(tdt)
         host.numpy()[:] = a.reshape(-1)
         out = host.to(self.dev, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.dev))
-        self.slots[i] = (buf, ev)
+        self.events[i] = ev
         return out.view(a.shape)
 
 
@@ -1080,7 +1091,7 @@ class Engine:
                 call("seqrec_opt_sqnorm", len(dk), gp, nn, arr, cnt, ptr(cur), ptr(lrows), n, ptr(self.loss_out), st)
             call("seqrec_opt_apply", len(dk), _lib.ptr_array([P[k] for k in dk]) if dk else None,
                  _lib.ptr_array([self.A[k] for k in dk]) if dk else None, gp, nn, arr, cnt, ptr(cur), clip, lr, eps,
-                 ptr(self.scale), ptr(nxt), None, ptr(self.status), st)
+                 ptr(self.scale), ptr(nxt), None, ptr(self.status), None, st)
             self._sq_par ^= 1
             self.sq = cur
         else:

@@ -69,7 +69,7 @@ def main():
         dropkw = case.get("drop", {})
         cfg = E.NetConfig(cell=cell, act="relu", H=H, V_in=V, V_out=V, input="embed", D=Dm, output="sampled", K=K, tied=tied,
                           logq=True, seed=9, **dropkw)
-        eng = D.ShardedEngine(cfg, "cuda:0", D.HostStagedDist(dist))
+        eng = D.ShardedEngine(cfg, "cuda:0", D.HostStagedDist(dist, verify=True))
         for k in ("W", "U", "b"):
             eng.set_param(k, p[k])
         eng.set_param("E", p["E"][rank::R])

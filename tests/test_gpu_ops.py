@@ -560,7 +560,7 @@ def test_fused_optimizer_launches_equal_the_separate_kernels():
         scale = torch.zeros(1, device="cuda")
         if fused:
             call("seqrec_opt_sqnorm", len(sizes), gp, nn, arr, cnt, ptr(sq[0:1]), None, 0, None, st())
-            call("seqrec_opt_apply", len(sizes), pp, ap, gp, nn, arr, cnt, ptr(sq[0:1]), 0.05, 0.01, 1e-8, ptr(scale), ptr(sq[1:2]), None, None, st())
+            call("seqrec_opt_apply", len(sizes), pp, ap, gp, nn, arr, cnt, ptr(sq[0:1]), 0.05, 0.01, 1e-8, ptr(scale), ptr(sq[1:2]), None, None, None, st())
             assert sq[1].item() == 0.0                       # the other norm slot was cleared for the next step
         else:
             call("seqrec_sqnorm_multi", len(sizes), gp, nn, ptr(sq[0:1]), st())
@@ -869,7 +869,7 @@ def test_opt_apply_refuses_a_degenerate_scale_and_reports_it():
         dv = None if div is None else dev(np.array([div], np.float32))
         status = torch.zeros(1, dtype=torch.int32, device="cuda")
         call("seqrec_opt_apply", 1, L.ptr_array([p]), L.ptr_array([a]), L.ptr_array([g]), L.i64_array([n]), None, 0, ptr(sq), 1.0, 0.01,
-             1e-8, ptr(scale), None, ptr(dv), ptr(status), st())
+             1e-8, ptr(scale), None, ptr(dv), ptr(status), None, st())
         assert int(status.item()) == want, (sqv, div, int(status.item()))
         if want:
             np.testing.assert_array_equal(p.cpu().numpy(), p0)

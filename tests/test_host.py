@@ -156,7 +156,7 @@ def test_c_abi_rejects_bad_arguments_before_any_launch():
     assert lib.seqrec_rows_adagrad(None, one, one, one, one, 4, 8, 0, 0.01, 1e-8, one, None) == E_ARG
     assert lib.seqrec_opt_sqnorm(0, None, None, None, 0, one, None, 0, None, None) == E_ARG                                      # nothing to do is an error
     assert lib.seqrec_opt_sqnorm(9, one, one, None, 0, one, None, 0, None, None) == E_ARG                                        # > 8 dense tensors
-    assert lib.seqrec_opt_apply(1, None, None, one, one, None, 0, one, 1.0, 0.01, 1e-8, one, None, None, None, None) == E_ARG
+    assert lib.seqrec_opt_apply(1, None, None, one, one, None, 0, one, 1.0, 0.01, 1e-8, one, None, None, None, None, None) == E_ARG
     assert lib.seqrec_gather_rows_bounded(one, 0, one, one, 4, 8, None, None, 0, None, None) == E_ARG                       # a bound of 0 rows
     assert lib.seqrec_sample_negatives(1, 0, 4, None, None, 10, one, None) == E_ARG
     assert lib.seqrec_sample_gather(1, 0, 4, one, one, 10, one, 0, None, one, one, None, None) == E_ARG           # width 0

@@ -54,7 +54,7 @@ def run(tag, ids, tgt, neg, cold):
         ev[r][1].record()
         call("seqrec_opt_sqnorm", len(dense), gp, nn, arr, cnt, ptr(sq), ptr(lrows), n, ptr(loss_out), st)
         ev[r][2].record()
-        call("seqrec_opt_apply", len(dense), pp, ap_, gp, nn, arr, cnt, ptr(sq), 1.0, 0.01, 1e-8, ptr(scale), None, None, None, st)
+        call("seqrec_opt_apply", len(dense), pp, ap_, gp, nn, arr, cnt, ptr(sq), 1.0, 0.01, 1e-8, ptr(scale), None, None, None, None, st)
         ev[r][3].record()
     torch.cuda.synchronize()
     t = np.array([[ev[r][i].elapsed_time(ev[r][i + 1]) * 1e3 for i in range(3)] for r in range(5, reps)])
