@@ -59,7 +59,7 @@ extern "C" {
  *    seqrec_opt_sqnorm_slabs, seqrec_pack_batch_host, seqrec_rnn_pack_u_sample, seqrec_rnn_bwd_stepwise_parts */
 /* 4: seqrec_opt_apply takes a status word; new entry points seqrec_gather_rows_bounded, seqrec_release_stream,
  *    seqrec_cluster_scan_errors_reset, seqrec_debug_cluster_spin_limit, seqrec_exchange_pack / _unpack / _grad_pack,
- *    seqrec_sampled_softmax_ce_rows_idx; the packed layout of the step-wise LSTM forward
+ *    seqrec_sampled_softmax_ce_rows_idx, seqrec_route_*_host; the packed layout of the step-wise LSTM forward
  *    kernel changed (seqrec_rnn_pack_u_stepwise and the scans of one library always agree) */
 #define SEQREC_ABI_VERSION 4
 
@@ -312,6 +312,18 @@ int seqrec_exchange_unpack(const float* recv, int width, const int32_t* neg_rows
 int seqrec_exchange_grad_pack(const int32_t* back_idx, int64_t n_tot, int n, int K, int width, const float* dX, int dx_slabs,
                               int64_t dx_stride, const float* Hd, const float* dlt, const float* dEneg, int dn_slabs,
                               int64_t dn_stride, float* out, void* stream);
+
+/*      HOST routines (no device work, `_host` pointers throughout): the routing arithmetic of a batch of the unified step
+ *      (distributed.py RowExchange.plan_unified) -- per-peer request counts; the per-peer lists of requested local rows and
+ *      every request's position in owner-sorted order; the batch's whole int32 index blob (field order in csrc/route.hip),
+ *      written in place into the caller's (page-locked) upload buffer.  route_blob returns the words written (< 0: error). */
+int seqrec_route_count_host(const int32_t* ids_host, const int32_t* tgt_host, int64_t n, int R, int64_t* counts_host);
+int seqrec_route_fill_host(const int32_t* ids_host, const int32_t* tgt_host, int64_t n, int R, int64_t V_in, int tied,
+                           const int64_t* counts_host, const int64_t* base_host, int32_t* send_host, int32_t* req_rank_host);
+int64_t seqrec_route_blob_host(const int32_t* step_off_host, int T, const int32_t* prev_host, const int32_t* ids_host,
+                               const int32_t* tgt_host, int64_t n, int R, int Kr, int nid, int w, const int64_t* sc_host,
+                               const int64_t* rc_host, const int32_t* req_rank_host, const int64_t* got_off_host,
+                               int64_t got_sentinel, float ntok, const float* lq_tgt_host, int32_t* blob_host, int64_t blob_len);
 
 /* ---- row-sparse gradient path for the item tables (E, Eout, Wk, bout) -- the exact sparse
  *      equivalent of Keras' dense Adagrad (experiments_methods.py:41): a row with zero gradient is

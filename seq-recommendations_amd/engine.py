@@ -140,10 +140,18 @@ class PinnedRing:
     def put(self, arr):
         """numpy array (any dtype) -> device tensor of the same dtype and shape, uploaded asynchronously on the current stream."""
         a = np.ascontiguousarray(arr)
-        tdt = torch.from_numpy(np.zeros(0, a.dtype)).dtype
         if a.size == 0:
-            return torch.empty(a.shape, dtype=tdt, device=self.dev)
-        nbytes = a.nbytes
+            return torch.empty(a.shape, dtype=torch.from_numpy(np.zeros(0, a.dtype)).dtype, device=self.dev)
+
+        def fill(dst):
+            dst[:] = a.reshape(-1)
+        return self.put_fill(a.size, a.dtype, fill).view(a.shape)
+
+    def put_fill(self, count, dtype, fill):
+        """The same without a staging copy on the caller's side: fill(numpy view of `count` elements of `dtype`) writes the
+        upload straight into the page-locked slot (the native planner does: csrc/route.hip)."""
+        tdt = torch.from_numpy(np.zeros(0, dtype)).dtype
+        nbytes = int(count) * np.dtype(dtype).itemsize
         i = self.pos
         self.pos = (i + 1) % self.n
         if self.events[i] is not None:
@@ -157,12 +165,12 @@ class PinnedRing:
                 self.big[i] = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
             buf = self.big[i][:nbytes]
         host = buf.view(tdt)
-        host.numpy()[:] = a.reshape(-1)
+        fill(host.numpy())
         out = host.to(self.dev, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.dev))
         self.events[i] = ev
-        return out.view(a.shape)
+        return out
 
 
 class Engine:

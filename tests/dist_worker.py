@@ -97,6 +97,57 @@ def many_plan_checks(D, ex, rank, R):
                 assert torch.equal(getattr(pm, f).long(), getattr(ps, f).long()), (f, extra)
 
 
+def unified_plan_checks(D, ex, rank, R):
+    """RowExchange.plan_unified (native host planner, csrc/route.hip) must produce exactly the index blob the numpy
+    arithmetic of plan_seg_many + the unified step's derived arrays gives -- untied and tied tables, with and without the
+    log-Q vector, including a batch whose requests all go to one owner."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import make_sessions
+    Bt = importlib.import_module("seq-recommendations_amd.batching")
+    gr = np.random.default_rng(900 + rank)
+    V, w, Kr = 1201, 8, 11
+    nid = -(-Kr // w)
+    lqh = gr.normal(size=V).astype(np.float32)
+    for tied in (False, True):
+        rbs = []
+        for b in range(4):
+            sess = make_sessions(gr, 9 + 3 * rank + b, V, 2, 9)
+            if b == 2:
+                sess = [[(x // R) * R for x in s_] for s_ in sess]           # every row lives on owner 0
+            rbs.append(Bt.pack_sessions(sess))
+        for lq in (None, lqh):
+            got = ex.plan_unified(rbs, V, tied, Kr, nid, w, lq_host=lq)
+            # reference: the numpy planner + the derived arrays of the unified step
+            reqs = []
+            for rb in rbs:
+                ids, tgt = rb.ids.astype(np.int64), rb.tgt.astype(np.int64)
+                off = np.zeros_like(tgt) if tied else (V - tgt % R + R - 1) // R
+                reqs.append((np.concatenate([ids % R, tgt % R]), np.concatenate([ids // R, tgt // R + off])))
+            ref = ex.plan_seg_many(reqs, extra=Kr + nid, device_fields=False, tokens=[rb.n_tok for rb in rbs])
+            q = np.arange(Kr)
+            for rb, (blob, parts, plan), pr in zip(rbs, got, ref):
+                n, h = rb.n_tok, pr.host
+                oe, re_ = h["own_extra"], h["req_extra"]
+                back = h["back"].copy()
+                back[re_[:, :Kr].reshape(-1)] = 2 * n + np.arange(R * Kr)
+                want = {"step_off": rb.step_off, "prev": rb.prev, "ids": rb.ids, "tgt": rb.tgt, "neg_slots": oe[:, :Kr].reshape(-1),
+                        "id_rows": oe[:, Kr:Kr + nid].reshape(-1), "take_in": h["req_pos"][:n], "take_tgt": h["req_pos"][n:],
+                        "neg_rows": re_[:, :Kr].reshape(-1), "negid_idx": (re_[:, Kr + q // w] * w + (q % w)[None, :]).reshape(-1),
+                        "back_idx": back, "own_src": h["own_src"],
+                        "ntok": np.array([pr.n_global], np.float32).view(np.int32)}
+                if lq is not None:
+                    want["lq_tgt"] = lq[rb.tgt].view(np.int32)
+                assert [nm for nm, _, _ in parts] == list(want), [nm for nm, _, _ in parts]
+                bl = blob.numpy()
+                for nm, o, cnt in parts:
+                    assert cnt == len(want[nm]), (nm, cnt, len(want[nm]))
+                    assert np.array_equal(bl[o:o + cnt], np.asarray(want[nm], dtype=np.int64).astype(np.int32)), (nm, tied, lq is not None)
+                assert (plan.n_tot, plan.m_tot, plan.req_split, plan.own_split, plan.n_global) == \
+                    (pr.n_tot, pr.m_tot, pr.req_split, pr.own_split, pr.n_global)
+                assert torch.equal(plan.got_pad, pr.got_pad)
+
+
 def main():
     dist.init_process_group("gloo")
     rank, R = dist.get_rank(), dist.get_world_size()
@@ -140,6 +191,7 @@ def main():
         assert torch.allclose(gshard, D.shard_rows(ref, rank, R), atol=1e-12), "push mismatch (case %d)" % case
     seg_plan_checks(D, ex, E, rank, R)
     many_plan_checks(D, ex, rank, R)
+    unified_plan_checks(D, ex, rank, R)
     x = torch.arange(R * 3, dtype=torch.float32).view(R, 3) + 100 * rank
     y = ex.swap_fixed(x)
     for i in range(R):
