@@ -118,6 +118,17 @@ class NetConfig:
         return N_GATES[self.cell]
 
 
+def status_messages(bits, scan_errors):
+    """What a device status word (SEQREC_STATUS_* bits) and a cluster-scan error count say, as text; [] = healthy."""
+    msgs = [txt for b, txt in sorted(_lib.STATUS_BITS.items()) if bits & b]
+    if bits & ~sum(_lib.STATUS_BITS):
+        msgs.append("unknown status bits 0x%x" % (bits & ~sum(_lib.STATUS_BITS)))
+    if scan_errors:
+        msgs.append("%s in-kernel wait(s) of a cluster scan ran out (workgroups of a row block not co-resident, e.g. another "
+                    "process holding the GPU): the scan's outputs are NaN-poisoned" % ("some" if scan_errors < 0 else scan_errors))
+    return msgs
+
+
 class PinnedRing:
     """Engine-owned staging memory for every host -> device upload that must not block the host (``non_blocking=True``).
     A copy from PAGEABLE memory may still be reading its source after the call returns; a numpy temporary whose last
@@ -304,12 +315,9 @@ class Engine:
         checkpoint) -- the counterpart of the reference's asserts / exceptions (model.py:136,149)."""
         bits = int(self.status.item())
         nerr = int(_lib.load().seqrec_cluster_scan_errors(self._stream()))
-        if bits == 0 and nerr == 0:
+        msgs = status_messages(bits, nerr)
+        if not msgs:
             return
-        msgs = [txt for b, txt in sorted(_lib.STATUS_BITS.items()) if bits & b]
-        if nerr:
-            msgs.append("%s in-kernel wait(s) of a cluster scan ran out (workgroups of a row block not co-resident, e.g. another "
-                        "process holding the GPU): the scan's outputs are NaN-poisoned" % ("some" if nerr < 0 else nerr))
         self.status.zero_()
         _lib.load().seqrec_cluster_scan_errors_reset(self._stream())
         raise _lib.SeqrecError("device-side failure at or before training step %d: %s" % (self.step_count, "; ".join(msgs)))

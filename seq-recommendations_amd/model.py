@@ -86,10 +86,12 @@ class BaseModel:
 
 
 class MultinomialModel(BaseModel):
+    """Count baseline (reference model.py:127-143, same constructor keywords): smoothed unigram probabilities."""
+
     def __init__(self, n_classes, model_name="multinomial_model", k=1.0):
-        BaseModel.__init__(self, n_classes, model_name)
-        self.model = np.zeros((1, self.n_classes))
+        super().__init__(n_classes, model_name)
         self.k = k
+        self.model = np.zeros((1, n_classes))                    # row vector of item probabilities once fitted
 
     def fit_model(self, seqs, normalize=True):
         self.model = utils.multinomial_probabilities(seqs, self.n_classes, self.k, normalize)
@@ -99,13 +101,15 @@ class MultinomialModel(BaseModel):
 
 
 class MarkovModel(BaseModel):
+    """Count baseline (reference model.py:146-167, same constructor keywords): first-order transition probabilities."""
+
     def __init__(self, n_classes, model_name="markov_model", order=1, k=1.0):
-        BaseModel.__init__(self, n_classes, model_name)
-        assert order == 1, "ERROR: only first-order Markov chains are supported for now."
-        self.model = np.zeros((self.n_classes, self.n_classes))
-        self.initial_probs = np.zeros(self.n_classes)
-        self.order = order
-        self.k = k
+        super().__init__(n_classes, model_name)
+        if order != 1:
+            raise ValueError("MarkovModel: order %r is not available, the transition matrix is first-order" % (order,))
+        self.order, self.k = order, k
+        self.initial_probs = np.zeros(n_classes)
+        self.model = np.zeros((n_classes, n_classes))
 
     def fit_model(self, seqs, freq=False):
         self.model, self.initial_probs = utils.transition_matrix(seqs, self.n_classes, self.k, freq=freq, end_state=False)

@@ -215,3 +215,16 @@ def test_packing_properties_hypothesis():
             np.testing.assert_array_equal(rf.tgt, rb.tgt)
 
     check()
+
+
+def test_device_status_word_decodes_to_a_raise_message():
+    """Engine.check_status() raises SeqrecError with these texts when a kernel set a SEQREC_STATUS_* bit or a cluster scan
+    counted a wait that ran out (the GPU side: tests/test_gpu_engine.py::test_device_side_failure_raises_instead_of_training_on)."""
+    E = importlib.import_module("seq-recommendations_amd.engine")
+    assert E.status_messages(0, 0) == []
+    m = E.status_messages(1 | 8, 0)
+    assert len(m) == 2 and "gradient norm" in m[0] and "row index" in m[1]
+    assert "clip scale" in E.status_messages(4, 0)[0] and "divisor" in E.status_messages(2, 0)[0]
+    m = E.status_messages(0, 3)
+    assert len(m) == 1 and "3 in-kernel wait" in m[0] and "NaN-poisoned" in m[0]
+    assert "unknown status bits" in E.status_messages(64, 0)[0]
