@@ -485,7 +485,18 @@ __device__ __forceinline__ void gemm2_body(const Map& map, float* smem) {
 #pragma unroll
         for (int i = 0; i < BM / 64; ++i) nid[i] = __float_as_int(lds_read_b32<0>(ids_a + (unsigned)((t * 16 + sa.koff[i]) * 4)));
     };
-    auto lgkm0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); };
+    // Every inline-asm LDS read below is invisible to hipcc's bookkeeping in TWO ways: it inserts no wait for the result, and
+    // it considers the destination register free again as soon as its (last) reader is scheduled -- or at once when nothing
+    // reads it.  The LDS unit writes the register when the data returns, whatever the compiler has put there meanwhile.  So
+    // every wait is TIED to the registers it covers ("+v": the value is redefined at the wait, hence live from the read to
+    // the wait, and every reader depends on the wait).
+    auto tie_ids = [&]() {
+        if constexpr (AIDX_K) {
+#pragma unroll
+            for (int i = 0; i < BM / 64; ++i) asm volatile("" : "+v"(nid[i]));
+        }
+    };
+    auto lgkm0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tie_ids(); __builtin_amdgcn_sched_barrier(0); };
     if (gather) {
         for (int i = tid; i < nk * 16; i += 256) ids_s[i] = kbeg + i < kend ? g.a_idx[kbeg + i] : -1;
         __syncthreads();
@@ -509,6 +520,11 @@ __device__ __forceinline__ void gemm2_body(const Map& map, float* smem) {
                 if (k0 + sb.koff[i] >= kend) sb.p[i] = zero16;
         }
         const bool dma = !(ABL(2) && kt_i >= 3);
+        if (gather) {
+            // the ids of this tile were requested by an inline-asm ds_read one issue ago: the wait is tied to their registers
+#pragma unroll
+            for (int i = 0; i < BM / 64; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nid[i]) :: "memory");
+        }
 #pragma unroll
         for (int i = 0; i < BM / 64; ++i) {
             const float* src = sa.p[i];
@@ -521,13 +537,32 @@ __device__ __forceinline__ void gemm2_body(const Map& map, float* smem) {
             if (dma) glds16_to(sb.p[i], dmaB + sw + 4096u * i);
             sb.p[i] += sb.step[i];
         }
-        if (gather) read_ids(kt_i + 1);
+        // (no read behind the last tile: round 3 -- in the K-tail variant of this code that read's result had no reader, hipcc
+        // handed its register to the address arithmetic that follows, and the LDS data arriving later overwrote it: one wave's
+        // operands garbage whenever other processes' traffic stretched the LDS latency; tools/mp_stress.py)
+        if (gather && kt_i + 1 < nk) read_ids(kt_i + 1);
         ++kt_i;
         sw = sw == 2 * SB ? 0u : sw + SB;
     };
 
     // ---------------- operand fragments: two register sets (static indices: steps are instantiated per parity)
     float a[2][TM][8], b[2][TN][8];
+    // the same wait with the fragment registers of set P redefined behind it: the MFMAs that read them carry a data
+    // dependency on the wait (an asm load is not in hipcc's wait bookkeeping; position alone orders nothing for the optimiser)
+    auto lgkm0_frags = [&](auto Pc) {
+        constexpr int P = decltype(Pc)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(a[P][i][j]));
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(b[P][i][j]));
+        tie_ids();
+        __builtin_amdgcn_sched_barrier(0);
+    };
     auto read_a = [&](auto Pc, unsigned so) {
         constexpr int P = decltype(Pc)::value;
         const unsigned ra0s = ra0 + so, ra1s = ra1 + so;      // one address add per operand half, immediates for the rest
@@ -623,7 +658,7 @@ __device__ __forceinline__ void gemm2_body(const Map& map, float* smem) {
     GSTAMP(2);
     read_a(std::integral_constant<int, 0>{}, 0u);
     read_b(std::integral_constant<int, 0>{}, 0u);
-    lgkm0();
+    lgkm0_frags(std::integral_constant<int, 0>{});
     unsigned sr = SB;             // byte offset of the ring stage the next fragment reads come from
 
     // step kt: MFMAs of tile kt from set P.  Under them: wait for tile kt+1 (this wave's DMAs), barrier (every wave's
@@ -665,7 +700,7 @@ __device__ __forceinline__ void gemm2_body(const Map& map, float* smem) {
         mfma_j(Pc, J6{});
         mfma_j(Pc, J7{});
         __builtin_amdgcn_sched_barrier(0);
-        if (KIND != STEP_LAST) lgkm0();
+        if (KIND != STEP_LAST) lgkm0_frags(Q{});
     };
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;

@@ -767,6 +767,8 @@ class ShardedEngine(Engine):
         main_st = self._cur_st                   # the engine's helpers launch on the remembered stream: restore it below
         with torch.cuda.stream(self.side):
             self.side.wait_event(ev)
+            if getattr(self, "debug_capture", False):      # tests: this rank's OWN dense gradients, before the sum over the ranks
+                self._local_dense = self.gflat[: self.n_dense].clone()
             work = self.dist.all_reduce(self.gflat[: self.n_dense], group=self.dense_group, async_op=True)
             if self.unified:
                 if work is not None:
@@ -852,6 +854,25 @@ class ShardedEngine(Engine):
         out["gback"] = stat(L["gback"])
         for k in sorted(self.Gd):
             out["Gd[%s]" % k] = stat(self.Gd[k])
+        loc = getattr(self, "_local_dense", None)
+        if loc is not None:                  # the same tensors as this rank produced them (before the all-reduce)
+            o = 0
+            for k in sorted(self.Gd):
+                nk = self.Gd[k].numel()
+                out["local Gd[%s]" % k] = stat(loc[o:o + nk])
+                if k == "U" and "Hout" in ws and "dPre" in ws and "prev" in L:
+                    # recompute dU = Hout[prev]^T . dPre with torch and name the elements that differ
+                    Hout = ws["Hout"][: n * w].view(n, w); dPre = ws["dPre"][: n * self.GHp].view(n, self.GHp)
+                    prev = L["prev"].long()
+                    A = torch.where((prev >= 0)[:, None], Hout[prev.clamp(min=0)], torch.zeros_like(Hout))
+                    ref = A.double().t() @ dPre.double()
+                    got = loc[o:o + nk].view(w, self.GHp).double()
+                    diff = (got - ref).abs()
+                    bad = torch.nonzero(diff > 1e-3 * (1.0 + ref.abs()))
+                    out["local dU vs torch"] = {"n_bad": int(bad.shape[0]), "first_bad": bad[:6].tolist(),
+                                                "rows": sorted(set((bad[:, 0] // 64).tolist()))[:8], "cols": sorted(set((bad[:, 1] // 64).tolist()))[:8],
+                                                "max_bad_value": float(got[diff > 1e-3 * (1.0 + ref.abs())].abs().max().item()) if bad.shape[0] else 0.0}
+                o += nk
         rows = L["send_idx"].long()
         rows = rows[rows >= 0]
         out["TG[touched rows]"] = stat(self.TG[rows])
@@ -897,9 +918,11 @@ class ShardedEngine(Engine):
 
     def eval_loss(self, d, negatives=None, step=0):
         """Sampled-softmax CE of this rank's batch (no update), scaled like train_step's return value."""
-        if not self.unified:
-            raise NotImplementedError("sharded evaluation needs the unified tables (D == H)")
         self._wait_ready(d)
+        if not self.unified:
+            X, Etgt, Eneg, neg, _ = self._split_rows(d, step)
+            self._cell_and_loss_split(d, X, Etgt, Eneg, neg, None, None, None, train=False)
+            return self.loss_sum * (self.R / d["n_total"])
         recv, Eneg, neg, lq_neg, _ = self._rows_in(d, step)
         self._cell_unified(d, recv, Eneg, neg, lq_neg, step, train=False)
         return self.loss_sum * (float(self.R) / d["n_global"])
@@ -908,15 +931,18 @@ class ShardedEngine(Engine):
         """Global rank of every target of THIS rank's tokens (Recall@K = mean(rank < K)): hidden rows and
         target scores of all ranks are all-gathered, every rank counts against its own Eout shard
         (seqrec_rank_count_thr) and the partial counts are summed with one all-reduce."""
-        if not self.unified:
-            raise NotImplementedError("sharded evaluation needs the unified tables (D == H)")
         c, R, st = self.cfg, self.R, self._stream()
         n, w = d["n"], self.Hp
         self._wait_ready(d)
-        recv = self._rows_in(d, 0)[0]
-        Hd = self._hidden(d, recv)
         thr = self.buf("thr", n)
-        call("seqrec_target_score", ptr(Hd), w, ptr(recv), None, ptr(d["take_tgt"]), n, ptr(thr), st)
+        if self.unified:
+            recv = self._rows_in(d, 0)[0]
+            Hd = self._hidden(d, recv)
+            call("seqrec_target_score", ptr(Hd), w, ptr(recv), None, ptr(d["take_tgt"]), n, ptr(thr), st)
+        else:                                # D != H: one exchange per table, rows materialised
+            X, Etgt, _, _, _ = self._split_rows(d, 0, negatives=False)
+            Hd = self._hidden(d, None, X=X)
+            call("seqrec_target_score", ptr(Hd), w, ptr(Etgt), None, ptr(d["arange"]), n, ptr(thr), st)
         nm = torch.tensor([n], dtype=torch.int64, device=self.dev)
         self.dist.all_reduce(nm, op=self.dist.ReduceOp.MAX, group=self.group)
         nmax = int(nm.item())
@@ -948,14 +974,12 @@ class ShardedEngine(Engine):
         hidden rows of all ranks are all-gathered, every rank keeps a running top-64 over its own shard
         (seqrec_topk_merge), the per-shard candidates return to the rows' home ranks with one all-to-all
         and the final top-k of the R x 64 candidates is taken there.  -> (ids int32 [m,k], scores [m,k])."""
-        if not self.unified:
-            raise NotImplementedError("sharded evaluation needs the unified tables (D == H)")
         if not 1 <= k <= 64:
             raise ValueError("1 <= k <= 64")
         c, R, st = self.cfg, self.R, self._stream()
         n, w = d["n"], self.Hp
         self._wait_ready(d)
-        Hd = self._hidden(d, self._rows_in(d, 0)[0])
+        Hd = self._hidden(d, self._rows_in(d, 0)[0]) if self.unified else self._hidden(d, None, X=self._split_rows(d, 0, negatives=False)[0])
         if rows is not None:
             idx = torch.as_tensor(np.asarray(rows) if not torch.is_tensor(rows) else rows, dtype=torch.int32).to(self.dev)
             Hd = self._take(Hd, idx)
@@ -996,13 +1020,17 @@ class ShardedEngine(Engine):
         out_i = torch.gather(ci, 1, out_c.long().clamp_(min=0))          # candidate column -> global item id
         return out_i[:m].contiguous(), out_v[:m].contiguous()
 
-    def _hidden(self, d, recv):
-        """Hidden rows of this rank's tokens from the receive buffer of _rows_in (input rows read through their positions)."""
+    def _hidden(self, d, recv, X=None):
+        """Hidden rows of this rank's tokens from the receive buffer of _rows_in (input rows read through their positions) or,
+        split path, from the materialised input rows X."""
         P = self.P
         n, Hp, GHp, Dp = d["n"], self.Hp, self.GHp, self.Dp
         XW = self.buf("XW", n, GHp)
-        self.gemm(1, 0, n, GHp, Dp, recv, self.Hp, P["W"], GHp, XW, GHp, bias=P.get("b"), tag="xw",
-                  fuse=_lib.gemm_fuse(a_index=d["take_in"]))
+        if X is not None:
+            self.gemm(1, 0, n, GHp, Dp, X, Dp, P["W"], GHp, XW, GHp, bias=P.get("b"), tag="xw")
+        else:
+            self.gemm(1, 0, n, GHp, Dp, recv, self.Hp, P["W"], GHp, XW, GHp, bias=P.get("b"), tag="xw",
+                      fuse=_lib.gemm_fuse(a_index=d["take_in"]))
         Hout = self.buf("Hout", n, Hp); gates = self.buf("gates", n, GHp); aux = self.buf("aux", n, Hp)
         self._scan_fwd(d, XW, Hout, gates, aux)
         return Hout
@@ -1027,7 +1055,7 @@ class ShardedEngine(Engine):
         job, cnt = _lib.rows_jobs([dict(table=self.TT, accum=self.TA, gtab=self.TG, slot=self.TS, rows=rows_eff, vals=gback,
                                         ldv=w, row_scale=None, n=plan.m_tot, width=w, base=0)])
         call("seqrec_rows_scatter_add_multi", job, cnt, st)
-        self._last = {"gback": gback, "send_idx": rows_eff, "n": n, "m_tot": plan.m_tot, "n_tot": plan.n_tot}    # what a failure report names
+        self._last = {"gback": gback, "send_idx": rows_eff, "n": n, "m_tot": plan.m_tot, "n_tot": plan.n_tot, "prev": d["prev"]}    # what a failure report names
         if not apply_update:
             return None
         # -- norm of the owned row gradients (+ this rank's batch loss), summed over the ranks.  Two slots alternate (norms[0] /
@@ -1048,15 +1076,18 @@ class ShardedEngine(Engine):
         self.upack_dirty = True
         return self.loss_sum * (float(self.R) / d["n_global"])    # this rank's share, scaled so the mean over ranks is the global loss
 
-    def _step_split(self, d, lr, eps, clipnorm, step, apply_update):
-        """D != H: the two tables have different row widths, one exchange per table."""
+    def _split_rows(self, d, step, negatives=True):
+        """Forward exchanges of the split path (D != H: one exchange per table): input rows, target rows and -- for a loss --
+        the stratified negatives with their ids.  -> (X [n, Dp], Etgt [n, Hp], Eneg [K, Hp], neg int32[K], negl)."""
         c, P, R = self.cfg, self.P, self.R
         st = self._stream()
-        n, Hp, Dp, K = d["n"], self.Hp, self.Dp, c.K
+        Hp, Dp, K = self.Hp, self.Dp, c.K
         Kr = K // R
         tname = "E" if c.tied else "Eout"
         X = self.ex.fetch(d["plan_in"], self._gather_from(P["E"]), Dp, self._take)
         Etgt = self.ex.fetch(d["plan_tgt"], self._gather_from(P[tname]), Hp, self._take)
+        if not negatives:
+            return X, Etgt, None, None, None
         th, al, _ = self.sampler
         negl = self.buf("negl", R * Kr, dtype=torch.int32)             # local rows I draw for every requester
         call("seqrec_sample_negatives", int(c.seed), int(step) * R + self.rank, R * Kr, ptr(th), ptr(al), c.V_out, ptr(negl), st)
@@ -1066,8 +1097,16 @@ class ShardedEngine(Engine):
         pay[:, :Hp] = self._take(P[tname], negl)
         pay[:, Hp] = ids_out.view(torch.float32)
         got = self.ex.swap_fixed(pay.view(R, Kr, Hp + 1)).view(K, Hp + 1)
-        Eneg = got[:, :Hp].contiguous()
-        neg = got[:, Hp].contiguous().view(torch.int32)
+        return X, Etgt, got[:, :Hp].contiguous(), got[:, Hp].contiguous().view(torch.int32), negl
+
+    def _step_split(self, d, lr, eps, clipnorm, step, apply_update):
+        """D != H: the two tables have different row widths, one exchange per table."""
+        c, P, R = self.cfg, self.P, self.R
+        st = self._stream()
+        n, Hp, Dp, K = d["n"], self.Hp, self.Dp, c.K
+        Kr = K // R
+        tname = "E" if c.tied else "Eout"
+        X, Etgt, Eneg, neg, negl = self._split_rows(d, step)
         dX = self.buf("dX", n, Dp); dEtgt = self.buf("dEtgt", n, Hp); dEneg = self.buf("dEneg", K, Hp)
         self._cell_and_loss_split(d, X, Etgt, Eneg, neg, dX, dEtgt, dEneg)
         Gt = self.Gt

@@ -70,6 +70,7 @@ def main():
         cfg = E.NetConfig(cell=cell, act="relu", H=H, V_in=V, V_out=V, input="embed", D=Dm, output="sampled", K=K, tied=tied,
                           logq=True, seed=9, **dropkw)
         eng = D.ShardedEngine(cfg, "cuda:0", D.HostStagedDist(dist, verify=True))
+        eng.debug_capture = True             # keeps this rank's own dense gradients of the last step for the failure report
         for k in ("W", "U", "b"):
             eng.set_param(k, p[k])
         eng.set_param("E", p["E"][rank::R])
@@ -91,7 +92,7 @@ def main():
         prepared = eng.prepare([Bt.pack_sessions(per_rank[rank]) for per_rank in steps])
         for s, per_rank in enumerate(steps):
             d = prepared[s]
-            if eng.unified and s == 0:
+            if s == 0:
                 ev = float(eng.eval_loss(d, step=s).item())          # forward only, same negatives, same weights
             l = eng.train_step(d, lr=0.01, eps=1e-8, clipnorm=1.0, step=s)
             losses.append(float(l.item()))
@@ -102,12 +103,13 @@ def main():
                 raise
             sc_ = float(eng.scale.item())
             assert np.isfinite(sc_) and sc_ > 0.0, (case, rank, s, sc_)
-            if eng.unified and s == 0 and not dropkw:
+            if s == 0 and not dropkw:
                 assert ev == losses[0], (ev, losses[0])
-        if eng.unified:
-            # sharded Recall@K support: global rank of every target, counted shard by shard
+        if True:
+            # sharded Recall@K support: global rank of every target, counted shard by shard (unified tables and, D != H, split)
             rk = eng.rank_counts(d).cpu().numpy()
-            hd = eng._hidden(d, eng._rows_in(d, 0)[0]).cpu().numpy()[:, :H]
+            hd = (eng._hidden(d, eng._rows_in(d, 0)[0]) if eng.unified else
+                  eng._hidden(d, None, X=eng._split_rows(d, 0, negatives=False)[0])).cpu().numpy()[:, :H]
             tname = "E" if tied else "Eout"
             info = [None] * R
             dist.all_gather_object(info, (rk, hd, d["tgt"].cpu().numpy(), eng.get_param(tname)))
