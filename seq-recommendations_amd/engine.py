@@ -35,6 +35,7 @@ import os as _os
 SPLITK_TARGET_WGS = int(_os.environ.get("SEQREC_SPLITK_WGS", "512"))
 SPLITK_MIN_K = int(_os.environ.get("SEQREC_SPLITK_MIN_K", "512"))
 SPLITK_FILL_WGS = int(_os.environ.get("SEQREC_SPLITK_FILL", "1152"))
+SPLITK_FILL_WGRAD = int(_os.environ.get("SEQREC_SPLITK_FILL_WGRAD", "1700"))
 
 # Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg):
 # _PROF = {"events": [(name, tag, start_event, end_event), ...]} while enabled, else None.
@@ -418,7 +419,7 @@ class Engine:
                 use.append(self._splitk(m, kin, GHp, fill=True) * m * kin)                                          # dX
             shapes = [(Hp, GHp), (kin, GHp), (1, GHp)]                                                   # grouped dU, dW, db
             tiles = sum(((a + 63) // 64) * ((b + 63) // 64) for a, b in shapes if a)
-            sk = self._splitk_tiles(tiles, m, fill=True)
+            sk = self._splitk_tiles(tiles, m, fill=SPLITK_FILL_WGRAD)
             use.append(sk * sum(a * b for a, b in shapes))
             ws = max(ws, max(use))
         need["gemm_ws"] = ws
@@ -482,11 +483,14 @@ class Engine:
         """fill: products with 256 or more tiles that would not be split at all (c4: dH 320, dX 320, dW+dU 544 tiles of 64 x 64 on
         1 280 workgroup slots -- one thin round, 1.25-2.1 workgroups per CU) are split until ~SPLITK_FILL_WGS slots are taken
         (same-box A/B at c4, tools/ab_c4.sh: dH 142 -> 105 us, dX 71 -> 54, dW+dU 210 -> 176; dEneg -- 504 tiles, 8 MB per
-        slab for the scatter to re-read -- is the one product that loses and does not ask for it)."""
+        slab for the scatter to re-read -- is the one product that loses and does not ask for it).  fill may be a slot count
+        of its own: the grouped weight-gradient launch asks for SPLITK_FILL_WGRAD (its slabs are summed by the norm launch,
+        which streams them once: 3 slabs of 544 tiles, 178 -> 117 us), while more slabs of dX cost the scatter more than
+        the GEMM gains (45 -> 64 us at 5 slabs)."""
         mk = min_k or SPLITK_MIN_K
         sk = SPLITK_TARGET_WGS // max(tiles, 1)
         if fill and tiles >= 256:
-            sk = max(sk, SPLITK_FILL_WGS // tiles)
+            sk = max(sk, (SPLITK_FILL_WGS if fill is True else int(fill)) // tiles)
         return int(max(1, min(32, sk, K // mk)))
 
     # ------------------------------------------------------------------ parameters (Keras layouts)
@@ -1052,7 +1056,7 @@ class Engine:
         if wgrad:
             # the weight gradients A^T . dPre all reduce over the tokens: one grouped split-K launch
             tiles = sum(((w_[0] + 63) // 64) * ((w_[1] + 63) // 64) for w_ in wgrad)
-            sk = self._splitk_tiles(tiles, n, fill=True)
+            sk = self._splitk_tiles(tiles, n, fill=SPLITK_FILL_WGRAD)
             wsz = sum(sk * w_[0] * w_[1] for w_ in wgrad)
             wsp = self.buf("gemm_ws", wsz) if sk > 1 else None
             if (self._slab_wgrad and apply_update and sk > 1 and c.merge != "sorted" and not self.priors and len(sparse_jobs) <= 4
