@@ -70,12 +70,9 @@ __global__ __launch_bounds__(256) void gru_cluster_fwd(ClusterArgs a) {
     const int gl = x + 8 * jj;                       // group index inside this launch
     const int r0 = 16 * (a.g_base + gl);
     if (gl >= a.n_groups || r0 >= a.so[1] - a.so[0]) return;
-    __shared__ float smem[2048 + 4 * 16 * (H / 4)];       // partial tiles of a product, twice + the 4 waves' A-row images
-    float* stage = smem + 2048;
-    // consecutive products alternate between the two halves: a wave may write the partials of product n + 1 while a slower wave
-    // still reads those of product n, and it cannot reach product n + 2 before that wave has passed n + 1's barrier
-    int rbuf = 0;
-    auto red_next = [&]() { float* r_ = smem + rbuf; rbuf ^= 1024; return r_; };
+    __shared__ float smem[1024 + 4 * 16 * (H / 4)];       // partial tiles of a product + the 4 waves' A-row images
+    float* red = smem;
+    float* stage = smem + 1024;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int row = tid >> 4, col = 16 * c + (tid & 15);
     float4 bz[NB], br[NB], bh[NB];
@@ -103,17 +100,6 @@ __global__ __launch_bounds__(256) void gru_cluster_fwd(ClusterArgs a) {
     if (tid == 0) st_u32(fl + 32 + c, xcc_id() + 1u, true);
     bool wt = true;                                   // write-through exchange stores until the group is known to share an XCD
     float hprev = 0.f;
-    // in-band exchange (rnn_cluster_dev.h ld_rows_poll): this workgroup's words of the two exchange buffers start as sentinels;
-    // the group meets once (flag base + 1, behind step 0) so that no member polls a word its owner has not reset yet
-    for (int t = 0; t < a.T; ++t) {
-        const int p0 = a.so[t], bt = a.so[t + 1] - p0;
-        if (bt <= r0) break;
-        if (row < min(16, bt - r0)) {
-            const long q = (long)p0 + r0 + row;
-            st_u32(reinterpret_cast<unsigned*>(a.Hout + q * H + col), CL_SENT, true);
-            st_u32(reinterpret_cast<unsigned*>(a.aux + q * H + col), CL_SENT, true);
-        }
-    }
     CS_DECL;
     // input projections of a step are requested one step ahead (after the flag store of the step before: nothing on the
     // exchange path waits for them)
@@ -137,49 +123,50 @@ __global__ __launch_bounds__(256) void gru_cluster_fwd(ClusterArgs a) {
         CS(0);
         if (t > 0) {
             // a wait that runs out: the step's output is poisoned (nothing downstream may look plausible) and the wave leaves
-            if (t == 1) {
-                if (!cl_wait_w<CB>(fl, base + 1u, a.error, a.spin_limit)) { if (ok) a.Hout[q * H + col] = __builtin_nanf(""); return; }
-                wt = !cl_same_xcd<CB>(fl);
-            }
+            if (!cl_wait_w<CB>(fl, base + 2u * t, a.error, a.spin_limit)) { if (ok) a.Hout[q * H + col] = __builtin_nanf(""); return; }
             CS(1);
-            if (!ld_rows_poll<H>(av, a.Hout + ((long)a.so[t - 1] + r0) * H, H, nact, w * (H / 4), stage + w * (16 * H / 4), lane, a.error,
-                                 a.spin_limit)) { if (ok) a.Hout[q * H + col] = __builtin_nanf(""); return; }
+            if (t == 1) wt = !cl_same_xcd<CB>(fl);
+            ld_rows_dma<H>(av, a.Hout + ((long)a.so[t - 1] + r0) * H, H, nact, w * (H / 4), stage + w * (16 * H / 4), lane);
             CS(2);
-            if constexpr (RD) { mul_vec(am, av, mr); cl_tiles<H, 1>(am, br, br, red_next(), tid, accr, dummy); }
-            else cl_tiles<H, 1>(av, br, br, red_next(), tid, accr, dummy);  // r first: r * h_prev is what the others wait for
+            if constexpr (RD) { mul_vec(am, av, mr); cl_tiles<H, 1>(am, br, br, red, tid, accr, dummy); }
+            else cl_tiles<H, 1>(av, br, br, red, tid, accr, dummy);        // r first: r * h_prev is what the others wait for
             CS(3);
         }
         const float r = hard_sigmoid(accr + xr);
-        if (ok) st_f32(a.aux + q * H + col, cl_canon(r * hprev), wt);        // exchange 1: the store is the signal
+        if (ok) st_f32(a.aux + q * H + col, r * hprev, wt);
         if (t > 0) {
+            cl_publish_n<0>(fl + c, base + 2u * t + 1u, wt);
             CS(4);
-            if constexpr (RD) { mul_vec(am, av, mz); cl_tiles<H, 1>(am, bz, bz, red_next(), tid, accz, dummy); }
-            else cl_tiles<H, 1>(av, bz, bz, red_next(), tid, accz, dummy);  // z under the exchange (only the h update needs it)
+            if constexpr (RD) { mul_vec(am, av, mz); cl_tiles<H, 1>(am, bz, bz, red, tid, accz, dummy); }
+            else cl_tiles<H, 1>(av, bz, bz, red, tid, accz, dummy);        // z under the exchange (only the h update needs it)
             CS(5);
         }
         const float z = hard_sigmoid(accz + xz);
         if (t > 0) {
+            if (!cl_wait_w<CB>(fl, base + 2u * t + 1u, a.error, a.spin_limit)) { if (ok) a.Hout[q * H + col] = __builtin_nanf(""); return; }
             CS(6);
-            if (!ld_rows_poll<H>(av, a.aux + ((long)p0 + r0) * H, H, nact, w * (H / 4), stage + w * (16 * H / 4), lane, a.error,
-                                 a.spin_limit)) { if (ok) a.Hout[q * H + col] = __builtin_nanf(""); return; }
+            ld_rows_dma<H>(av, a.aux + ((long)p0 + r0) * H, H, nact, w * (H / 4), stage + w * (16 * H / 4), lane);
             CS(7);
-            if constexpr (RD) { mul_vec(am, av, mh); cl_tiles<H, 1>(am, bh, bh, red_next(), tid, acch, dummy); }
-            else cl_tiles<H, 1>(av, bh, bh, red_next(), tid, acch, dummy);
+            __syncthreads();                                          // red: slower waves may still read the z product
+            if constexpr (RD) { mul_vec(am, av, mh); cl_tiles<H, 1>(am, bh, bh, red, tid, acch, dummy); }
+            else cl_tiles<H, 1>(av, bh, bh, red, tid, acch, dummy);
             CS(8);
         }
         const float hh = act_fwd<ACT>(acch + xh);
         float hn = z * hprev + (1.f - z) * hh;
         if (col >= a.H_real) hn = 0.f;
         if (ok) {
-            st_f32(a.Hout + q * H + col, cl_canon(hn), wt);                  // exchange 2
-            // the stash (z, r, h~ for the BPTT) rides behind the exchange store
+            st_f32(a.Hout + q * H + col, hn, wt);
+            // the stash (z, r, h~ for the BPTT) rides behind the exchange store: in flight under the flag and the next poll
             st_f32(a.gates + q * GH + col, z, false);
             st_f32(a.gates + q * GH + H + col, r, false);
             st_f32(a.gates + q * GH + 2 * H + col, hh, false);
         }
         hprev = hn;
-        if (t == 0 && more) cl_publish_n<0>(fl + c, base + 1u, true);       // the one meeting: every member's sentinels are in place
-        if (more) prefetch_xw(t + 1);
+        if (more) {
+            cl_publish_n<3>(fl + c, base + 2u * t + 2u, wt);
+            prefetch_xw(t + 1);
+        }
         CS(9);
 #ifdef SEQREC_CLUSTER_STAMP
         if (t > 0) ++cs_steps;

@@ -96,57 +96,6 @@ template <int K> __device__ __forceinline__ void ld_rows_dma(float (&a)[K / 16],
         a[4 * j] = t.x; a[4 * j + 1] = t.y; a[4 * j + 2] = t.z; a[4 * j + 3] = t.w;
     }
 }
-// IN-BAND form of the same load (round 3): the rows ARE the signal.  Every word of an exchange buffer holds CL_SENT until its
-// producer stores the value (the scan pre-fills its own words, then the group meets ONCE: cl_fill_barrier below); a consumer
-// loads the rows, checks every word it is going to use, and re-issues the DMA instructions that still showed a sentinel.
-// Correct by construction -- a 4-byte store is atomic and each word is validated on its own, no ordering between stores is
-// assumed -- and one L2 round trip shorter per exchange than flag -> poll -> load: the producer neither drains its stores
-// nor meets at a barrier nor writes a flag.  Producers canonicalise a NaN that happens to carry the sentinel's bits
-// (cl_canon), so that only "not written yet" reads as CL_SENT.  false = the bounded spin ran out (counted in *error).
-constexpr unsigned CL_SENT = 0xFFFFFFFFu;
-__device__ __forceinline__ float cl_canon(float v) { return __float_as_uint(v) == CL_SENT ? __uint_as_float(0x7FC00000u) : v; }
-template <int RPI> constexpr unsigned long long cl_rowmask(int i) {      // lanes whose operand row (lane & 15) came with DMA instruction i
-    unsigned long long m = 0;
-    for (int l = 0; l < 64; ++l) if ((l & 15) / RPI == i) m |= 1ull << l;
-    return m;
-}
-template <int K> __device__ __forceinline__ bool ld_rows_poll(float (&a)[K / 16], const float* base, long row_stride, int nact,
-                                                               int kslice0, float* lds_wave, int lane, unsigned* error, int spin_limit) {
-    constexpr int SL = K / 4, LPR = SL / 4, RPI = 64 / LPR, NI = 16 / RPI;
-    static_assert(LPR <= 64 && LPR >= 4, "slice fits a wave instruction");
-    unsigned need = (1u << NI) - 1u;
-    const int m = lane & 15, q = lane >> 4;
-    const float* src = lds_wave + m * SL;
-    int spins = 0;
-    while (true) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            if ((need >> i) & 1u) {                                    // wave-uniform
-                const int rl = RPI * i + lane / LPR;
-                const int ch = (lane % LPR) ^ (rl % LPR);
-                const float* p = base + (long)min(rl, nact - 1) * row_stride + kslice0 + 4 * ch;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                                 (__attribute__((address_space(3))) void*)(lds_wave + i * (RPI * SL)), 16, 0, 16 /* sc1 */);
-            }
-        }
-        bool bad = false;
-#pragma unroll
-        for (int j = 0; j < K / 64; ++j) {
-            const int pos = (q * (K / 64) + j) ^ (m % LPR);
-            const float4 t = *reinterpret_cast<const float4*>(src + 4 * pos);
-            a[4 * j] = t.x; a[4 * j + 1] = t.y; a[4 * j + 2] = t.z; a[4 * j + 3] = t.w;
-            bad = bad || __float_as_uint(t.x) == CL_SENT || __float_as_uint(t.y) == CL_SENT || __float_as_uint(t.z) == CL_SENT ||
-                  __float_as_uint(t.w) == CL_SENT;
-        }
-        const unsigned long long bm = __ballot(bad);
-        if (bm == 0ull) return true;
-        need = 0u;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) if (bm & cl_rowmask<RPI>(i)) need |= 1u << i;
-        if (++spins > spin_limit) { if (lane == 0) atomicAdd(error, 1u); return false; }
-    }
-}
-
 // The same in PIECES, for slices too long to sit in registers / one LDS image at once (LSTM BPTT: K = 4H, the wave's slice is
 // H floats per row).  In operand order lane (row, q) owns SLQ consecutive floats of its row, [kslice0 + q SLQ, + SLQ); piece
 // `pc` is floats [pc CHF, (pc + 1) CHF) of every lane's run -- the A operands of MFMAs pc CHF .. (pc + 1) CHF - 1 of the
