@@ -104,18 +104,21 @@ __global__ __launch_bounds__(256) void gru_cluster_fwd(ClusterArgs a) {
     // input projections of a step are requested one step ahead (after the flag store of the step before: nothing on the
     // exchange path waits for them)
     float n_xz = 0.f, n_xr = 0.f, n_xh = 0.f;
-    auto prefetch_xw = [&](int t) {
-        const int p0 = a.so[t], nact = min(16, a.so[t + 1] - p0 - r0);
+    auto prefetch_xw = [&](int p0, int p1) {                      // the step whose tokens are [p0, p1)
+        const int nact = min(16, p1 - p0 - r0);
         if (row < nact) { const float* xw = a.XW + ((long)p0 + r0 + row) * GH + col; n_xz = xw[0]; n_xr = xw[H]; n_xh = xw[2 * H]; }
     };
-    prefetch_xw(0);
+    StepWindow sw;                                                // step offsets in registers (rnn_cluster_dev.h)
+    sw.init_up(a.so, a.T);
+    prefetch_xw(sw.s0, sw.s1);
     for (int t = 0; t < a.T; ++t) {
-        const int p0 = a.so[t], bt = a.so[t + 1] - p0;
+        const int p0 = sw.s0, bt = sw.s1 - p0;
         if (bt <= r0) break;
+        sw.request_up(a.so, a.T, t);
         const int nact = min(16, bt - r0);
         const bool ok = row < nact;
         const long q = (long)p0 + r0 + row;
-        const bool more = t + 1 < a.T && a.so[t + 2] - a.so[t + 1] > r0;
+        const bool more = sw.s2 - sw.s1 > r0;
         const float xz = n_xz, xr = n_xr, xh = n_xh;
         float accz = 0.f, accr = 0.f, acch = 0.f, dummy;
         float av[H / 16];
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256) void gru_cluster_fwd(ClusterArgs a) {
             if (!cl_wait_w<CB>(fl, base + 2u * t, a.error, a.spin_limit)) { if (ok) a.Hout[q * H + col] = __builtin_nanf(""); return; }
             CS(1);
             if (t == 1) wt = !cl_same_xcd<CB>(fl);
-            ld_rows_dma<H>(av, a.Hout + ((long)a.so[t - 1] + r0) * H, H, nact, w * (H / 4), stage + w * (16 * H / 4), lane);
+            ld_rows_dma<H>(av, a.Hout + ((long)sw.prev + r0) * H, H, nact, w * (H / 4), stage + w * (16 * H / 4), lane);
             CS(2);
             if constexpr (RD) { mul_vec(am, av, mr); cl_tiles<H, 1>(am, br, br, red, tid, accr, dummy); }
             else cl_tiles<H, 1>(av, br, br, red, tid, accr, dummy);        // r first: r * h_prev is what the others wait for
@@ -165,8 +168,9 @@ __global__ __launch_bounds__(256) void gru_cluster_fwd(ClusterArgs a) {
         hprev = hn;
         if (more) {
             cl_publish_n<3>(fl + c, base + 2u * t + 2u, wt);
-            prefetch_xw(t + 1);
+            prefetch_xw(sw.s1, sw.s2);
         }
+        sw.advance_up();
         CS(9);
 #ifdef SEQREC_CLUSTER_STAMP
         if (t > 0) ++cs_steps;
@@ -213,13 +217,13 @@ __global__ __launch_bounds__(256) void gru_cluster_bwd(ClusterArgs a) {
     if (tid == 0) st_u32(fl + 32 + c, xcc_id() + 1u, true);
     bool wt = true, first_x = true;
     int tg = 0;                                       // steps this row block is alive
-    while (tg < a.T && a.so[tg + 1] - a.so[tg] > r0) ++tg;
+    tg = cl_alive_steps(a.so, a.T, r0);
     float carry = 0.f;
     // the element-wise operands of a step (dHout, z, r, h~, h_prev) are requested one step ahead: they do not depend on
     // the exchange, so their latency hides under the previous step's waits
     float n_dh = 0.f, n_z = 0.f, n_r = 0.f, n_hh = 0.f, n_h0 = 0.f;
-    auto prefetch = [&](int t) {
-        const int p0 = a.so[t], nact = min(16, a.so[t + 1] - p0 - r0);
+    auto prefetch = [&](int t, int p0, int p1, int pm1) {          // step t: tokens [p0, p1), step t - 1 starts at pm1
+        const int nact = min(16, p1 - p0 - r0);
         const long q = (long)p0 + r0 + (row < nact ? row : 0);
         float v = a.dHout[q * H + col];
         for (int sl = 1; sl < a.dh_ns; ++sl) v += a.dHout[(long)sl * a.dh_stride + q * H + col];      // slab order == the reduce launch
@@ -229,12 +233,17 @@ __global__ __launch_bounds__(256) void gru_cluster_bwd(ClusterArgs a) {
         }
         n_dh = v;
         n_z = a.gates[q * GH + col]; n_r = a.gates[q * GH + H + col]; n_hh = a.gates[q * GH + 2 * H + col];
-        n_h0 = t > 0 ? a.Hout[((long)a.so[t - 1] + r0 + (row < nact ? row : 0)) * H + col] : 0.f;
+        n_h0 = t > 0 ? a.Hout[((long)pm1 + r0 + (row < nact ? row : 0)) * H + col] : 0.f;
     };
-    if (tg > 0) prefetch(tg - 1);
-    for (int t = tg - 1; t >= 0; --t) {
-        const int p0 = a.so[t], bt = a.so[t + 1] - p0;
-        const int bnext = t + 1 < a.T ? a.so[t + 2] - a.so[t + 1] : 0;
+    StepWindow sw;
+    sw.init_down(a.so, a.T, tg > 0 ? tg - 1 : 0);
+    if (tg > 0) prefetch(tg - 1, sw.s0, sw.s1, sw.prev);
+    CS_DECL;
+    for (int t = tg - 1; t >= 0; --t, sw.advance_down()) {
+        CS(0);
+        const int p0 = sw.s0, bt = sw.s1 - p0;
+        const int bnext = sw.s2 - sw.s1;                             // 0 behind the last step (entries past T read as so[T])
+        sw.request_down(a.so, t);
         const int nact = min(16, bt - r0);
         const bool ok = row < nact;
         const long q = (long)p0 + r0 + (ok ? row : 0);
@@ -251,17 +260,23 @@ __global__ __launch_bounds__(256) void gru_cluster_bwd(ClusterArgs a) {
             break;
         }
         if (ok) st_f32(a.dPre + q * GH + 2 * H + col, d, wt);
+        CS(1);
         cl_publish_n<0>(fl + c, ++count, wt);
-        prefetch(t - 1);                              // behind the flag store: nothing on the exchange path is issued after it
+        CS(2);
+        prefetch(t - 1, sw.prev, sw.s0, sw.nxt);      // behind the flag store: nothing on the exchange path is issued after it
+        CS(3);
         // a wait that runs out: this step's gradient is poisoned (the norm then is not finite and the update refuses it)
         if (!cl_wait_w<CB>(fl, count, a.error, a.spin_limit)) { if (ok) a.dPre[q * GH + col] = __builtin_nanf(""); return; }
+        CS(4);
         if (first_x) { wt = !cl_same_xcd<CB>(fl); first_x = false; }
         float acc = 0.f, dummy;
         {
             float av[H / 16];
             ld_rows_dma<H>(av, a.dPre + ((long)p0 + r0) * GH + 2 * H, GH, nact, w * (H / 4), stage + w * (16 * 2 * H / 4), lane);
+            CS(5);
             cl_tiles<H, 1>(av, bh, bh, red, tid, acc, dummy);
         }
+        CS(6);
         if constexpr (RD) acc *= m_h;
         const float dcar = dh * z + acc * r;
         if (ok) {
@@ -269,16 +284,22 @@ __global__ __launch_bounds__(256) void gru_cluster_bwd(ClusterArgs a) {
             st_f32(a.dPre + q * GH + H + col, acc * h0 * hard_sigmoid_grad(r), wt);
         }
         cl_publish_n<0>(fl + c, ++count, wt);
+        CS(7);
         if (!cl_wait_w<CB>(fl, count, a.error, a.spin_limit)) { if (ok) a.dPre[q * GH + col] = __builtin_nanf(""); return; }
+        CS(8);
         float acc2[1] = {0.f}, acc2b[1] = {0.f};
         {
             float av2[2 * H / 16];
             ld_rows_dma<2 * H>(av2, a.dPre + ((long)p0 + r0) * GH, GH, nact, w * (2 * H / 4), stage + w * (16 * 2 * H / 4), lane);
+            CS(9);
             cl_tiles_n<2 * H, 1, RD>(av2, bzr, red, tid, acc2, acc2b);
         }
         if constexpr (RD) carry = dcar + (acc2[0] * m_z + acc2b[0] * m_r);
         else carry = dcar + acc2[0];
+        CS(10);
+        CS_STEP();
     }
+    CS_FLUSH(13);
 }
 
 }  // namespace

@@ -56,25 +56,28 @@ __global__ __launch_bounds__(256) void srnn_cluster_fwd(ClusterArgs a) {
     if constexpr (RD) ld_mask(mk, a.rmask, a.B, H, 0, min(r0 + (lane & 15), a.B - 1), w * (H / 4) + (lane >> 4) * (H / 16));
     const unsigned base = a.epoch;
     float n_x = 0.f;
-    auto prefetch_xw = [&](int t) {
-        const int p0 = a.so[t], nact = min(16, a.so[t + 1] - p0 - r0);
+    auto prefetch_xw = [&](int p0, int p1) {                      // the step whose tokens are [p0, p1)
+        const int nact = min(16, p1 - p0 - r0);
         if (row < nact) n_x = a.XW[((long)p0 + r0 + row) * H + col];
     };
-    prefetch_xw(0);
-    for (int t = 0; t < a.T; ++t) {
-        const int p0 = a.so[t], bt = a.so[t + 1] - p0;
+    StepWindow sw;                                                // step offsets in registers (rnn_cluster_dev.h)
+    sw.init_up(a.so, a.T);
+    prefetch_xw(sw.s0, sw.s1);
+    for (int t = 0; t < a.T; ++t, sw.advance_up()) {
+        const int p0 = sw.s0, bt = sw.s1 - p0;
         if (bt <= r0) break;
+        sw.request_up(a.so, a.T, t);
         const int nact = min(16, bt - r0);
         const bool ok = row < nact;
         const long q = (long)p0 + r0 + row;
-        const bool more = t + 1 < a.T && a.so[t + 2] - a.so[t + 1] > r0;
+        const bool more = sw.s2 - sw.s1 > r0;
         const float xw = n_x;
         float acc[1] = {0.f}, unused[1];
         if (t > 0) {
             if (!cl_wait_w<CB>(fl, base + (unsigned)t, a.error, a.spin_limit)) { if (ok) a.Hout[q * H + col] = __builtin_nanf(""); return; }
             if (t == 1) wt = !cl_same_xcd<CB>(fl);
             float av[H / 16];
-            ld_rows_dma<H>(av, a.Hout + ((long)a.so[t - 1] + r0) * H, H, nact, w * (H / 4), stage, lane);
+            ld_rows_dma<H>(av, a.Hout + ((long)sw.prev + r0) * H, H, nact, w * (H / 4), stage, lane);
             if constexpr (RD) mul_vec(av, av, mk);
             cl_tiles_n<H, 1>(av, b, red, tid, acc, unused);
         }
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256) void srnn_cluster_fwd(ClusterArgs a) {
         if (ok) st_f32(a.Hout + q * H + col, y, wt);
         if (more) {
             cl_publish_n<0>(fl + c, base + (unsigned)t + 1u, wt);     // (its barrier also orders this step's reads of `red` before the next writes)
-            prefetch_xw(t + 1);
+            prefetch_xw(sw.s1, sw.s2);
         }
     }
 }
@@ -109,17 +112,20 @@ __global__ __launch_bounds__(256) void srnn_cluster_bwd(ClusterArgs a) {
     unsigned count = a.epoch;
     bool first_x = true;
     int tg = 0;
-    while (tg < a.T && a.so[tg + 1] - a.so[tg] > r0) ++tg;
+    tg = cl_alive_steps(a.so, a.T, r0);
     float carry = 0.f, n_dh = 0.f, n_h = 0.f;
-    auto prefetch = [&](int t) {
-        const int p0 = a.so[t], nact = min(16, a.so[t + 1] - p0 - r0);
+    auto prefetch = [&](int t, int p0, int p1, int pm1) {          // step t: tokens [p0, p1), step t - 1 starts at pm1
+        const int nact = min(16, p1 - p0 - r0); (void)t; (void)pm1;
         const long q = (long)p0 + r0 + (row < nact ? row : 0);
         n_dh = a.dHout[q * H + col]; n_h = a.Hout[q * H + col];
     };
-    if (tg > 0) prefetch(tg - 1);
-    for (int t = tg - 1; t >= 0; --t) {
-        const int p0 = a.so[t], bt = a.so[t + 1] - p0;
-        const int bnext = t + 1 < a.T ? a.so[t + 2] - a.so[t + 1] : 0;
+    StepWindow sw;
+    sw.init_down(a.so, a.T, tg > 0 ? tg - 1 : 0);
+    if (tg > 0) prefetch(tg - 1, sw.s0, sw.s1, sw.prev);
+    for (int t = tg - 1; t >= 0; --t, sw.advance_down()) {
+        const int p0 = sw.s0, bt = sw.s1 - p0;
+        const int bnext = sw.s2 - sw.s1;                             // 0 behind the last step (entries past T read as so[T])
+        sw.request_down(a.so, t);
         const int nact = min(16, bt - r0);
         const bool ok = row < nact;
         const long q = (long)p0 + r0 + (ok ? row : 0);
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(256) void srnn_cluster_bwd(ClusterArgs a) {
         if (t == 0) { if (ok) a.dPre[q * H + col] = dp; break; }
         if (ok) st_f32(a.dPre + q * H + col, dp, wt);
         cl_publish_n<0>(fl + c, ++count, wt);
-        prefetch(t - 1);
+        prefetch(t - 1, sw.prev, sw.s0, sw.nxt);
         if (!cl_wait_w<CB>(fl, count, a.error, a.spin_limit)) { if (ok) a.dPre[q * H + col] = __builtin_nanf(""); return; }
         if (first_x) { wt = !cl_same_xcd<CB>(fl); first_x = false; }
         float acc[1] = {0.f}, unused[1];
@@ -171,22 +177,25 @@ __global__ __launch_bounds__(256, 2) void lstm_cluster_fwd(ClusterArgs a) {
     float cprev = 0.f;
     CS_DECL;
     float n_x[4] = {0.f, 0.f, 0.f, 0.f};
-    auto prefetch_xw = [&](int t) {
-        const int p0 = a.so[t], nact = min(16, a.so[t + 1] - p0 - r0);
+    auto prefetch_xw = [&](int p0, int p1) {                      // the step whose tokens are [p0, p1)
+        const int nact = min(16, p1 - p0 - r0);
         if (row < nact) {
             const float* xw = a.XW + ((long)p0 + r0 + row) * GH + col;
 #pragma unroll
             for (int g = 0; g < 4; ++g) n_x[g] = xw[g * H];
         }
     };
-    prefetch_xw(0);
-    for (int t = 0; t < a.T; ++t) {
-        const int p0 = a.so[t], bt = a.so[t + 1] - p0;
+    StepWindow sw;                                                // step offsets in registers (rnn_cluster_dev.h)
+    sw.init_up(a.so, a.T);
+    prefetch_xw(sw.s0, sw.s1);
+    for (int t = 0; t < a.T; ++t, sw.advance_up()) {
+        const int p0 = sw.s0, bt = sw.s1 - p0;
         if (bt <= r0) break;
+        sw.request_up(a.so, a.T, t);
         const int nact = min(16, bt - r0);
         const bool ok = row < nact;
         const long q = (long)p0 + r0 + row;
-        const bool more = t + 1 < a.T && a.so[t + 2] - a.so[t + 1] > r0;
+        const bool more = sw.s2 - sw.s1 > r0;
         float xw[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) xw[g] = n_x[g];
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void lstm_cluster_fwd(ClusterArgs a) {
             CS(1);
             if (t == 1) wt = !cl_same_xcd<CB>(fl);
             float av[H / 16];
-            ld_rows_dma<H>(av, a.Hout + ((long)a.so[t - 1] + r0) * H, H, nact, w * (H / 4), stage, lane);
+            ld_rows_dma<H>(av, a.Hout + ((long)sw.prev + r0) * H, H, nact, w * (H / 4), stage, lane);
             CS(2);
             if constexpr (RD) {
                 // every gate reads h_{t-1} through its own mask: four masked copies of the A operand, one tile each
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void lstm_cluster_fwd(ClusterArgs a) {
         cprev = cn;
         if (more) {
             cl_publish_n<5>(fl + c, base + (unsigned)t + 1u, wt);
-            prefetch_xw(t + 1);
+            prefetch_xw(sw.s1, sw.s2);
         }
         CS(4);
         if (t > 0) CS_STEP();
@@ -272,27 +281,30 @@ __global__ __launch_bounds__(256, 2) void lstm_cluster_bwd(ClusterArgs a) {
     unsigned count = a.epoch;
     bool first_x = true;
     int tg = 0;
-    while (tg < a.T && a.so[tg + 1] - a.so[tg] > r0) ++tg;
+    tg = cl_alive_steps(a.so, a.T, r0);
     float dh_carry = 0.f, dc_carry = 0.f;
     // element-wise operands of a step, requested one step ahead (they do not depend on the exchange)
     float n_dh = 0.f, n_g[4] = {0.f, 0.f, 0.f, 0.f}, n_cn = 0.f, n_cp = 0.f;
-    auto prefetch = [&](int t) {
-        const int p0 = a.so[t], nact = min(16, a.so[t + 1] - p0 - r0);
+    auto prefetch = [&](int t, int p0, int p1, int pm1) {          // step t: tokens [p0, p1), step t - 1 starts at pm1
+        const int nact = min(16, p1 - p0 - r0); (void)t; (void)pm1;
         const int rr = row < nact ? row : 0;
         const long q = (long)p0 + r0 + rr;
         n_dh = a.dHout[q * H + col];
 #pragma unroll
         for (int g = 0; g < 4; ++g) n_g[g] = a.gates[q * GH + g * H + col];
         n_cn = a.aux[q * H + col];
-        n_cp = t > 0 ? a.aux[((long)a.so[t - 1] + r0 + rr) * H + col] : 0.f;
+        n_cp = t > 0 ? a.aux[((long)pm1 + r0 + rr) * H + col] : 0.f;
     };
-    if (tg > 0) prefetch(tg - 1);
+    StepWindow sw;
+    sw.init_down(a.so, a.T, tg > 0 ? tg - 1 : 0);
+    if (tg > 0) prefetch(tg - 1, sw.s0, sw.s1, sw.prev);
     const int kslice0 = w * (K / 4);
     CS_DECL;
-    for (int t = tg - 1; t >= 0; --t) {
+    for (int t = tg - 1; t >= 0; --t, sw.advance_down()) {
         CS(0);
-        const int p0 = a.so[t], bt = a.so[t + 1] - p0;
-        const int bnext = t + 1 < a.T ? a.so[t + 2] - a.so[t + 1] : 0;
+        const int p0 = sw.s0, bt = sw.s1 - p0;
+        const int bnext = sw.s2 - sw.s1;                             // 0 behind the last step (entries past T read as so[T])
+        sw.request_down(a.so, t);
         const int nact = min(16, bt - r0);
         const bool ok = row < nact;
         const long q = (long)p0 + r0 + (ok ? row : 0);
@@ -316,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void lstm_cluster_bwd(ClusterArgs a) {
         }
         CS(1);
         cl_publish_n<0>(fl + c, ++count, wt);
-        prefetch(t - 1);
+        prefetch(t - 1, sw.prev, sw.s0, sw.nxt);
         CS(2);
         if (!cl_wait_w<CB>(fl, count, a.error, a.spin_limit)) { if (ok) a.dPre[q * GH + col] = __builtin_nanf(""); return; }
         CS(3);

@@ -167,12 +167,37 @@ template <int CB> __device__ __forceinline__ bool cl_wait_w(const unsigned* fl, 
         if (++spins > spin_limit) { if (lane == 0) atomicAdd(error, 1u); return false; }
     }
 }
-template <int CB> __device__ __forceinline__ bool cl_same_xcd(const unsigned* fl) {
-    const unsigned mine = ld_u32_dev(fl + 32);
-    bool same = true;
-    for (int i = 1; i < CB; ++i) same = same && (ld_u32_dev(fl + 32 + i) == mine);
-    return same;
+template <int CB> __device__ __forceinline__ bool cl_same_xcd(const unsigned* fl) {          // one poll: lane i reads member i's XCC id
+    const int lane = threadIdx.x & 63;
+    const unsigned mine = ld_u32_dev(fl + 32 + (lane < CB ? lane : 0));
+    return __all((int)(mine == (unsigned)__builtin_amdgcn_readfirstlane((int)mine)));
 }
+
+// Steps a row block is alive: the first t with so[t + 1] - so[t] <= r0 (step sizes never grow: the batcher sorts sessions by
+// length).  By bisection -- a linear walk is one dependent scalar load per step, ~3 us in front of the longest block's BPTT.
+__device__ __forceinline__ int cl_alive_steps(const int* so, int T, int r0) {
+    int lo = 0, hi = T;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (so[mid + 1] - so[mid] > r0) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// Step offsets of the scan, carried in registers: so[t], so[t + 1], so[t + 2] of the step at hand, the next one requested a step
+// ahead -- a scalar load from the kernel arguments and its wait at every loop top (and another for so[t - 1] in front of the row
+// load) was ~0.25 us of a 3.5 us step.  Entries past T read as so[T] (an empty step).
+struct StepWindow {
+    int prev, s0, s1, s2, nxt, pend;       // so[t - 1], so[t], so[t + 1], so[t + 2]; descending only: nxt = so[t - 2]; pend: the next window's new entry
+    __device__ __forceinline__ void init_up(const int* so, int T) { prev = so[0]; s0 = so[0]; s1 = so[min(1, T)]; s2 = so[min(2, T)]; nxt = 0; pend = 0; }
+    __device__ __forceinline__ void request_up(const int* so, int T, int t) { pend = so[min(t + 3, T)]; }
+    __device__ __forceinline__ void advance_up() { prev = s0; s0 = s1; s1 = s2; s2 = pend; }
+    __device__ __forceinline__ void init_down(const int* so, int T, int t) {
+        prev = so[max(t - 1, 0)]; s0 = so[t]; s1 = so[min(t + 1, T)]; s2 = so[min(t + 2, T)]; nxt = so[max(t - 2, 0)]; pend = 0;
+    }
+    __device__ __forceinline__ void request_down(const int* so, int t) { pend = so[max(t - 3, 0)]; }
+    __device__ __forceinline__ void advance_down() { s2 = s1; s1 = s0; s0 = prev; prev = nxt; nxt = pend; }
+};
 
 // NT 16x16 tile products (one shared A operand, NT packed B operands) with K split over the 4 waves (rnn_step.hip
 // tile_16x16_reg: same order of sums per tile).  red: NT x 4 x 256 floats.  SPLIT: out[t] = the sum of waves 0-1, out2[t] =
