@@ -372,16 +372,24 @@ int cluster_group_cap(const void* kernel, int CB) {
     return cap;
 }
 
+// One launch holds up to CL_MAX_GROUPS row blocks even when they cannot all be resident at once (LSTM-512: 2 workgroups per CU =
+// 2 groups per XCD, a 512-session batch has 4 per XCD).  That is safe because of the ORDER, not the count: group g sits on XCD
+// g mod 8 with all its members, and the workgroups an XCD receives are, in dispatch order, ALL members of its first group, then
+// all of its second, ... -- so at any time an XCD holds complete groups, which finish on their own, and at most ONE group that is
+// still arriving, whose resident members wait (bounded) for slots that the complete groups free.  Row blocks are sorted by
+// length: the short blocks at the back of the order run in the slots the medium ones leave, beside the longest block of their
+// XCD, instead of in a second launch behind it (c4: the 16 shortest row blocks used to cost a launch and 2-4 steps per scan).
+// cluster_group_cap() still has to say that at least one group per XCD fits.
 int launch_sliced(const void* fn, ClusterArgs& a, int CB, int G, int T, hipStream_t st) {
     const int gcap = cluster_group_cap(fn, CB);
     if (gcap < 1) return SEQREC_E_UNSUPPORTED;
     a.spin_limit = cluster_spin_limit();
-    for (int g0 = 0; g0 < G; g0 += gcap) {
+    for (int g0 = 0; g0 < G; g0 += CL_MAX_GROUPS) {
         FlagBuf fb;
         const int rc = get_flagbuf(st, T, fb);
         if (rc) return rc;
         a.flags = fb.flags; a.error = fb.error; a.epoch = fb.epoch;
-        a.g_base = g0; a.n_groups = G - g0 < gcap ? G - g0 : gcap;
+        a.g_base = g0; a.n_groups = G - g0 < CL_MAX_GROUPS ? G - g0 : CL_MAX_GROUPS;
         const unsigned grid = 8u * CB * ((a.n_groups + 7) / 8);
         void* argv[1] = {&a};
         const hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(256), argv, 0, st);
