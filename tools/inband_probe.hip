@@ -59,6 +59,14 @@ template <int LAYOUT> __device__ __forceinline__ void img_read(f32x4 (&v)[4], co
     }
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) :: "memory");
 }
+// LAYOUT 2 (operand-major slab): wave w's instruction i is 1 KB contiguous -- lane (m, q) finds floats [64 w + 16 q + 4 i, + 4) of row m at
+// ((4 w + i) 64 + lane) 16 bytes: four coalesced device-scope loads straight into the MFMA operand registers, no LDS staging at all
+__device__ __forceinline__ void direct_read(f32x4 (&v)[4], const float* slab, int w, int lane) {
+    const float* p = slab + ((size_t)(4 * w) * 64 + lane) * 4;
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:3072 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(p) : "memory");
+}
 __device__ __forceinline__ bool has_sent(const f32x4 (&v)[4]) {
     bool bad = false;
 #pragma unroll
@@ -95,7 +103,8 @@ __global__ __launch_bounds__(256) void exchange_kernel(float* __restrict__ buf, 
 #define ST(i_) do { if (STAMP) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); sacc[i_] += t_ - sprev; sprev = t_; } } while (0)
     for (int it = 0; it < iters; ++it) {
         float* slab = gbuf + (size_t)it * SLAB;
-        st1(LAYOUT == 0 ? slab + row * COLS + col : slab + c * 256 + row * 16 + (tid & 15), own);
+        st1(LAYOUT == 0 ? slab + row * COLS + col : LAYOUT == 1 ? slab + c * 256 + row * 16 + (tid & 15)
+                        : slab + (((c >> 2) * 4 + ((tid & 15) >> 2)) * 64 + (c & 3) * 16 + row) * 4 + (tid & 3), own);
         // the scans' other stores of a step (gate stash): younger than the exchange store, nobody waits for them on purpose
         for (int e = 0; e < extra_stores; ++e) st1(sink + ((size_t)(blockIdx.x * 4 + e) * iters + it) * 256 + tid, own);
         f32x4 v[4];
@@ -110,9 +119,19 @@ __global__ __launch_bounds__(256) void exchange_kernel(float* __restrict__ buf, 
                 if (__all((int)(f >= (unsigned)(it + 1)))) break;
                 if (++spins > (1 << 20)) { if (lane == 0) atomicAdd(errors + 1, 1u); return; }
             }
-            dma_issue<LAYOUT>(slab, w, stage[0][w], lane, 15u);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            img_read<LAYOUT>(v, stage[0][w], lane);
+            if (LAYOUT == 2) direct_read(v, slab, w, lane);
+            else {
+                dma_issue<LAYOUT>(slab, w, stage[0][w], lane, 15u);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                img_read<LAYOUT>(v, stage[0][w], lane);
+            }
+        } else if (PROTO == 1 && LAYOUT == 2) {
+            while (true) {
+                direct_read(v, slab, w, lane);
+                ++npoll;
+                if (__ballot(has_sent(v)) == 0ull) break;
+                if (++spins > (1 << 20)) { if (lane == 0) atomicAdd(errors + 1, 1u); return; }
+            }
         } else if (PROTO == 1) {
             unsigned need = 15u;
             if (w >= nload) { need = 0; }
@@ -230,16 +249,17 @@ int main() {
                h[0] * 10.0 / 200, h[1] * 10.0 / 200, h[2] * 10.0 / 200);
     }
     std::vector<unsigned long long> hc(GMAX * W * 4), hp(GMAX * W * 4);
-    for (int layout = 0; layout < 2; ++layout)
+    for (int layout = 0; layout < 3; ++layout)
     for (int extra : {0, 3})
-        for (int proto = 0; proto < 4; ++proto)
+        for (int proto = 0; proto < (layout == 2 ? 2 : 4); ++proto)
             for (int G : {1, 8, 32}) {
                 const int grid = 8 * W * ((G + 7) / 8);
                 for (int rep = 0; rep < 2; ++rep) {
                     CK(hipMemset(flags, 0, 64 * 64 * 4)); CK(hipMemset(err, 0, 8)); CK(hipMemset(buf, 0xFF, bufn * 4));
                     CK(hipDeviceSynchronize());
 #define LAUNCH(P_, L_) hipLaunchKernelGGL((exchange_kernel<P_, L_>), dim3(grid), dim3(256), 0, 0, buf, flags, G, iters, extra, 4, sink, err, clk, polls)
-                    switch (proto * 2 + layout) {
+                    if (layout == 2) { if (proto == 0) LAUNCH(0, 2); else LAUNCH(1, 2); }
+                    else switch (proto * 2 + layout) {
                         case 0: LAUNCH(0, 0); break; case 1: LAUNCH(0, 1); break; case 2: LAUNCH(1, 0); break; case 3: LAUNCH(1, 1); break;
                         case 4: LAUNCH(2, 0); break; case 5: LAUNCH(2, 1); break; case 6: LAUNCH(3, 0); break; default: LAUNCH(3, 1); break;
                     }
