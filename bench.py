@@ -208,6 +208,9 @@ def kernel_model(cfgd, n_tok, K, B, slabs=None, uniq=None, upack_floats=0):
         "seqrec_gemm_f32_grouped[dW+dU]": ("mfma", 2.0 * n_tok * G * H * (D + H)),          # dW and dU in one launch
         "seqrec_gemm_f32_grouped_slabs[dW+dU]": ("mfma", 2.0 * n_tok * G * H * (D + H),     # slabs finished by the norm launch
                                                  {"gather_bytes": 4.0 * (D + H) * n_tok}),   # E[ids] and Hout[prev] read through their index
+        # ... with dEneg = dlogits^T . H riding in the same launch (same layout, same reduction over the tokens)
+        "seqrec_gemm_f32_grouped_slabs[dW+dU+dEneg]": ("mfma", 2.0 * n_tok * G * H * (D + H) + 2.0 * n_tok * K * H,
+                                                       {"gather_bytes": 4.0 * (D + H) * n_tok}),
         # ---- the HBM side: gather / scatter-update kernels against the HBM peak
         "seqrec_rows_scatter_add_multi": ("hbm", scatter_b),
         "seqrec_opt_sqnorm_slabs": ("hbm", norm_b),

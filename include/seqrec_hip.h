@@ -129,7 +129,7 @@ int seqrec_gemm_f32_fused(int a_kcontig, int b_kcontig, int64_t M, int64_t N, in
                           const float* A, int64_t lda, const float* B, int64_t ldb,
                           float* C, int64_t ldc, const float* bias, int accumulate,
                           int splitk, float* workspace, const seqrec_gemm_fuse* fuse_host, void* stream);
-/*      grouped form: up to 4 independent problems that share the layout flags, K and the split count
+/*      grouped form: up to 6 independent problems that share the layout flags, K and the split count
  *      in ONE launch (the weight-gradient GEMMs dW / dU all reduce over K = N_tok).
  *      workspace (splitk > 1): sum_i splitk * M_i * N_i floats. */
 typedef struct seqrec_gemm_desc {

@@ -377,7 +377,8 @@ __device__ __forceinline__ int xcd_tile(int b, int n) {
 }
 
 // work item (= workgroup) -> (problem, tile, K split)
-struct GemmGroup { GemmArgs g[4]; int ntiles[4]; };
+constexpr int GROUP_MAX = 6;
+struct GemmGroup { GemmArgs g[GROUP_MAX]; int ntiles[GROUP_MAX]; };
 struct PlainMap {
     const GemmArgs* g; int ntiles, nsplits;
     __device__ int count() const { return ntiles * nsplits; }
@@ -392,19 +393,19 @@ struct GroupMap {          // the descriptors stay in the kernel-argument segmen
     __device__ int count() const { return total; }
     __device__ void get(int item, int& p, int& tile, int& z, int& ns) const {
         int l = xcd_tile(item, total);
-        const int c0 = gg->ntiles[0] * nsplits, c1 = gg->ntiles[1] * nsplits, c2 = gg->ntiles[2] * nsplits;
         int nt = gg->ntiles[0];
         p = 0;
-        if (nprob > 1 && l >= c0) { l -= c0; p = 1; nt = gg->ntiles[1];
-            if (nprob > 2 && l >= c1) { l -= c1; p = 2; nt = gg->ntiles[2];
-                if (nprob > 3 && l >= c2) { l -= c2; p = 3; nt = gg->ntiles[3]; } } }
+#pragma unroll
+        for (int i = 1; i < GROUP_MAX; ++i) {                // scalar selects: the problem sizes sit in the kernel arguments
+            const int c = gg->ntiles[i - 1] * nsplits;
+            if (p == i - 1 && i < nprob && l >= c) { l -= c; p = i; nt = gg->ntiles[i]; }
+        }
         z = l / nt; tile = l - z * nt; ns = nsplits;
     }
     __device__ GemmArgs load(int p) const {
         GemmArgs r = gg->g[0];
-        if (p == 1) r = gg->g[1];
-        if (p == 2) r = gg->g[2];
-        if (p == 3) r = gg->g[3];
+#pragma unroll
+        for (int i = 1; i < GROUP_MAX; ++i) if (p == i) r = gg->g[i];
         return r;
     }
 };
@@ -823,7 +824,8 @@ __global__ __launch_bounds__(256) GEMM2_WAVES(BM, BN) void gemm2_f32_grouped_ker
     gemm2_body<BM, BN, false, false, true>(map, smem);
 }
 
-struct ReduceGroup { const float* ws[4]; float* C[4]; const float* bias[4]; long M[4], N[4], ldc[4]; int accumulate[4]; };
+struct ReduceGroup { const float* ws[GROUP_MAX]; float* C[GROUP_MAX]; const float* bias[GROUP_MAX]; long M[GROUP_MAX], N[GROUP_MAX], ldc[GROUP_MAX];
+                     int accumulate[GROUP_MAX]; };
 __global__ void splitk_reduce_grouped_kernel(ReduceGroup r, int splits) {
     const int p = blockIdx.y;
     const long total = r.M[p] * r.N[p];
@@ -1131,7 +1133,7 @@ extern "C" int seqrec_gemm_f32_grouped_slabs(int count, int a_kcontig, int b_kco
 }
 static int gemm_grouped_impl(int count, int a_kcontig, int b_kcontig, const seqrec_gemm_desc* d, int splitk, float* workspace,
                              void* stream, int* slabs_out) {
-    if (count < 1 || count > 4 || !d || splitk < 1) return SEQREC_E_ARG;
+    if (count < 1 || count > GROUP_MAX || !d || splitk < 1) return SEQREC_E_ARG;
     hipStream_t st = as_stream(stream);
     GemmGroup gg = {};
     ReduceGroup rg = {};

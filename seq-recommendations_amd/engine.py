@@ -282,6 +282,9 @@ class Engine:
         self._slab_scatter = _os.environ.get("SEQREC_SLAB_SCATTER", "1") != "0"   # A/B switch: dX / dEneg reach the scatter as split-K slabs
         self._slab_min_k = int(_os.environ.get("SEQREC_SLAB_MIN_K", "256"))
         self._overlap = _os.environ.get("SEQREC_OVERLAP", "0") != "0"      # A/B switch: dEneg GEMM on a side stream under the BPTT (measured +-0.5 %: off)
+        # dEneg = dlogits^T . H reduces over the tokens like dW / dU and has the same operand layout: it rides in THEIR grouped
+        # launch (one launch of ~950 workgroups instead of two of ~500 that fill 1.5-2 slots per CU each; A/B switch)
+        self._group_deneg = _os.environ.get("SEQREC_GROUP_DENEG", "1") != "0"
         self.sq1 = z(1)                 # squared gradient norm (multi-launch path)
         self.sq2 = z(2)                 # two alternating slots of the fused optimizer launches
         self._sq_slots = (self.sq2[0:1], self.sq2[1:2])
@@ -919,6 +922,7 @@ class Engine:
         tr = self.trainable
         sparse_jobs = []     # scatter lists of this step (see _job)
         join_side = False    # a side-stream GEMM has to be joined before its consumer
+        deneg_late, deneg_at = None, -1      # dEneg deferred into the weight-gradient launch: (table, rows, dln, Hd, K), its scatter-list slot
         dh_parts = None      # dH as split-K slabs + target-row term for the BPTT (seqrec_rnn_bwd_stepwise_parts)
         wgrad = []           # deferred weight-gradient GEMMs (M, N, K, A, lda, B, ldb, C, ldc), launched grouped
         wcover = set()       # dense tensors whose gradient those products tile completely
@@ -975,13 +979,25 @@ class Engine:
                     self._cur_st = st
                     self._ev_join.record(side)
                     join_side = True
+                elif (self._slab_scatter and c.merge != "sorted" and self._group_deneg and self._slab_wgrad and apply_update and not self.priors
+                      and "rec" not in drops and c.input != "onehot"
+                      and ((K + 63) // 64) * ((Hp + 63) // 64) + ((self.Dp + 63) // 64 + (Hp + 63) // 64 + 1) * ((GHp + 63) // 64) <= 512):
+                    # ... and it waits for the weight-gradient launch behind the BPTT (its reader, the scatter, comes later still);
+                    # small shapes only: every product of a grouped launch takes the same number of splits, and a large dEneg
+                    # (c4: 504 tiles, 8 MB per slab for the scatter to re-read) wants fewer than the weight gradients do
+                    deneg_late = (tname, neg, dln, Hd, K)
+                    dEneg = None
                 elif self._slab_scatter and c.merge != "sorted":
                     # dEneg's only reader is the row scatter: the split-K slabs go there as they are (no reduce launch)
                     dEneg, ns_neg, ss_neg = self.gemm_slabs(0, 0, K, Hp, n, dln, K, Hd, Hp, "dEneg_slabs", self._splitk(K, Hp, n), tag="dEneg")
                 else:
                     self.gemm(0, 0, K, Hp, n, dln, K, Hd, Hp, dEneg, Hp, splitk=self._splitk(K, Hp, n), tag="dEneg")
                 sparse_jobs.append(self._job(tname, d["tgt"], Hd, Hp, dlt, n, Hp, 0))
-                sparse_jobs.append(self._job(tname, neg, dEneg, Hp, None, K, Hp, n, ns_neg, ss_neg))
+                if dEneg is None:
+                    deneg_at = len(sparse_jobs)          # filled in behind the grouped launch
+                    sparse_jobs.append(None)
+                else:
+                    sparse_jobs.append(self._job(tname, neg, dEneg, Hp, None, K, Hp, n, ns_neg, ss_neg))
             if c.out_bias and tr["bout"]:
                 dbn = self.buf("dbn", K)
                 call("seqrec_colsum", ptr(dln), n, K, K, ptr(dbn), 0, ptr(cs_ws), st)
@@ -1057,17 +1073,40 @@ class Engine:
             # the weight gradients A^T . dPre all reduce over the tokens: one grouped split-K launch
             tiles = sum(((w_[0] + 63) // 64) * ((w_[1] + 63) // 64) for w_ in wgrad)
             sk = self._splitk_tiles(tiles, n, fill=SPLITK_FILL_WGRAD)
-            wsz = sum(sk * w_[0] * w_[1] for w_ in wgrad)
-            wsp = self.buf("gemm_ws", wsz) if sk > 1 else None
-            if (self._slab_wgrad and apply_update and sk > 1 and c.merge != "sorted" and not self.priors and len(sparse_jobs) <= 4
-                    and len([k for k in Gd if tr[k]]) <= 8):
+            slabs_ok = (self._slab_wgrad and apply_update and c.merge != "sorted" and not self.priors and len(sparse_jobs) <= 4
+                        and len([k for k in Gd if tr[k]]) <= 8)
+            ride = deneg_late is not None and slabs_ok and len(wgrad) < 6
+            if ride:
+                # dEneg = dlogits^T . H rides as the LAST problem (same layout, same reduction over the tokens); with it the launch
+                # is sized for ~1 000 workgroups
+                t_, rows_, dln_, Hd_, K_ = deneg_late
+                tiles += ((K_ + 63) // 64) * ((Hp + 63) // 64)
+                sk = max(sk, int(max(1, min(1024 // max(tiles, 1), n // SPLITK_MIN_K))))
+                wgrad_all = wgrad + [(K_, Hp, n, dln_, K_, Hd_, Hp, Hd_, Hp)]
+            else:
+                wgrad_all = wgrad
+            wsz = sum(sk * w_[0] * w_[1] for w_ in wgrad_all)
+            wsp = self.buf("gemm_ws", wsz) if (sk > 1 or ride) else None
+            if slabs_ok and (sk > 1 or ride):
                 # the split-K slabs stay unreduced: the norm launch adds them, writes the gradients and takes their squares
                 import ctypes
-                descs, ns = _lib.gemm_descs(wgrad), ctypes.c_int(0)
-                call("seqrec_gemm_f32_grouped_slabs", len(wgrad), 0, 0, descs, sk, ptr(wsp), ctypes.addressof(ns), st, tag="dW+dU")
+                descs, ns = _lib.gemm_descs(wgrad_all), ctypes.c_int(0)
+                call("seqrec_gemm_f32_grouped_slabs", len(wgrad_all), 0, 0, descs, sk, ptr(wsp), ctypes.addressof(ns), st,
+                     tag="dW+dU+dEneg" if ride else "dW+dU")
                 wg_slabs = (descs, len(wgrad), int(ns.value), wsp)
+                if ride:
+                    nsv = int(ns.value)
+                    off = nsv * sum(w_[0] * w_[1] for w_ in wgrad)
+                    view = wsp[off:off + nsv * K_ * Hp]
+                    sparse_jobs[deneg_at] = self._job(t_, rows_, view, Hp, None, K_, Hp, n, nsv, K_ * Hp)
+                    self.last_slabs["dEneg_slabs"] = (view, nsv, K_, Hp)
+                    deneg_late = None
             else:
                 call("seqrec_gemm_f32_grouped", len(wgrad), 0, 0, _lib.gemm_descs(wgrad), sk, ptr(wsp), st, tag="dW+dU")
+        if deneg_late is not None:           # no launch to ride in after all: on its own, as before
+            t_, rows_, dln_, Hd_, K_ = deneg_late
+            dEn, ns_neg, ss_neg = self.gemm_slabs(0, 0, K_, Hp, n, dln_, K_, Hd_, Hp, "dEneg_slabs", self._splitk(K_, Hp, n), tag="dEneg")
+            sparse_jobs[deneg_at] = self._job(t_, rows_, dEn, Hp, None, K_, Hp, n, ns_neg, ss_neg)
         self.last_counts = {"wgrad": wg_slabs[2] if wg_slabs is not None else 1}      # split-K slab counts of this step (bench.py's byte models)
         for j in sparse_jobs:
             if j.get("n_slabs", 0) > 1:
