@@ -980,11 +980,12 @@ class Engine:
                     self._ev_join.record(side)
                     join_side = True
                 elif (self._slab_scatter and c.merge != "sorted" and self._group_deneg and self._slab_wgrad and apply_update and not self.priors
-                      and "rec" not in drops and c.input != "onehot"
+                      and "rec" not in drops and c.input != "onehot" and n <= 4096
                       and ((K + 63) // 64) * ((Hp + 63) // 64) + ((self.Dp + 63) // 64 + (Hp + 63) // 64 + 1) * ((GHp + 63) // 64) <= 512):
                     # ... and it waits for the weight-gradient launch behind the BPTT (its reader, the scatter, comes later still);
                     # small shapes only: every product of a grouped launch takes the same number of splits, and a large dEneg
-                    # (c4: 504 tiles, 8 MB per slab for the scatter to re-read) wants fewer than the weight gradients do
+                    # (c4: 504 tiles, 8 MB per slab for the scatter to re-read) wants fewer than the weight gradients do; with
+                    # many tokens (saturated c3: 25 k) dEneg alone runs at 73 % of the MFMA peak and the mixed launch at 36 %
                     deneg_late = (tname, neg, dln, Hd, K)
                     dEneg = None
                 elif self._slab_scatter and c.merge != "sorted":
