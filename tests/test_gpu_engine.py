@@ -68,6 +68,37 @@ def test_training_steps_match_oracle(case):
     assert all(np.isfinite(v) for v in med.values())
 
 
+def test_deneg_riding_in_the_weight_gradient_launch_changes_nothing():
+    """The training step with dEneg = dlogits^T . H as one more problem of the grouped weight-gradient launch (the default for small
+    batches: Engine._group_deneg) against the same step with dEneg in a launch of its own: same loss, and every parameter --
+    the negatives' output rows above all -- equal to rounding after three updates (the split counts differ, hence the order
+    of the partial sums); the slabs the scatter read DO lie inside the grouped launch's workspace."""
+    res = {}
+    for ride in (True, False):
+        rng = np.random.default_rng(5)
+        case = dict(cell="gru", act="relu", H=128, V=3000, inp="embed", out="sampled", D=128, K=200, logq=True)
+        ecfg, ocfg = make_cfg(**case)
+        pair = Pair(ecfg, ocfg, init_np_params(rng, ocfg, case["V"], case["H"], case["D"]))
+        pair.eng._group_deneg = ride
+        losses = []
+        for step in range(3):
+            sess = make_sessions(rng, 60, case["V"], 2, 14)
+            lg, lo, _ = pair.step(sess, step, lr=0.01)
+            losses.append(lg)
+            assert abs(lg - lo) <= 1e-3 * max(1.0, abs(lo))
+        ws, ns, m_, n_ = pair.eng.last_slabs["dEneg_slabs"]
+        gws = pair.eng.ws.get("gemm_ws")
+        inside = gws is not None and gws.data_ptr() <= ws.data_ptr() < gws.data_ptr() + gws.numel() * 4
+        assert inside == ride and (m_, n_) == (case["K"], pair.eng.Hp) and ns >= 1
+        res[ride] = (losses, {k: pair.eng.get_param(k) for k in pair.op})
+    assert np.allclose(res[True][0], res[False][0], rtol=1e-6, atol=0)
+    for k in res[True][1]:
+        a, b = res[True][1][k], res[False][1][k]
+        # Adagrad's first updates are lr * sign(g): an entry whose gradient is at rounding level may move by 2 lr either way
+        bad = np.abs(a - b) > 1e-5 * max(1.0, np.abs(b).max())
+        assert bad.mean() < 1e-3, (k, bad.mean())
+
+
 @pytest.mark.parametrize("case", [
     dict(cell="gru", act="relu", H=128, V=800, inp="embed", out="sampled", D=128, K=100, logq=True),
     dict(cell="gru", act="relu", H=64, V=300, inp="embed", out="sampled", D=64, K=64, tied=True),

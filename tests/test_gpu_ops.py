@@ -477,6 +477,50 @@ def test_gemm_slabs_feed_the_scatter_like_the_reduced_product(W):
     assert lib.seqrec_rows_merge_sorted(arr, cnt, ptr(mws), nbytes, None) == -3
 
 
+def test_grouped_gemm_takes_six_problems_of_different_shapes():
+    """seqrec_gemm_f32_grouped / _grouped_slabs with SIX problems that share only the layout, K and the split count -- shapes from
+    a [1, N] row to a 2000-row product with a ragged edge, one A operand gathered along K through an index (with -1 entries) --
+    against float64 products; the slab form leaves problem i at sum_{j<i} n_slabs M_j N_j, slab s at + s M_i N_i (the layout the
+    norm launch and the row scatter rely on when dEneg rides in the weight-gradient launch); a seventh problem is refused."""
+    import ctypes
+    rng = np.random.default_rng(77)
+    n, sk = 2555, 4
+    shapes = [(256, 512), (256, 256), (256, 768), (1, 768), (2000, 256), (70, 33)]
+    Bm = dev(rng.normal(size=(n, 768)).astype(np.float32) * 0.1)
+    idx = rng.integers(0, 900, n).astype(np.int32); idx[rng.random(n) < 0.05] = -1
+    table = dev(rng.normal(size=(900, 256)).astype(np.float32))
+    items, refs = [], []
+    for i, (M, N) in enumerate(shapes):
+        C = torch.full((M, N), 3.0, device="cuda")
+        if i == 0:          # gathered: A row k = table[idx[k]] (zero row for -1)
+            A = table
+            Ah = table.cpu().numpy().astype(np.float64)[np.maximum(idx, 0)] * (idx >= 0)[:, None]
+            items.append((M, N, n, A, 256, Bm, 768, C, N, dev(idx)))
+        else:
+            A = dev(rng.normal(size=(n, M)).astype(np.float32))
+            Ah = A.cpu().numpy().astype(np.float64)
+            items.append((M, N, n, A, M, Bm, 768, C, N))
+        refs.append(Ah.T @ Bm.cpu().numpy().astype(np.float64)[:, :N])
+    descs = L.gemm_descs(items)
+    ws = torch.zeros(sk * sum(M * N for M, N in shapes), device="cuda")
+    call("seqrec_gemm_f32_grouped", 6, 0, 0, descs, sk, ptr(ws), st())
+    torch.cuda.synchronize()
+    for it, ref in zip(items, refs):
+        got = it[7].cpu().numpy()
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    ns = ctypes.c_int(0)
+    ws.zero_()
+    call("seqrec_gemm_f32_grouped_slabs", 6, 0, 0, descs, sk, ptr(ws), ctypes.addressof(ns), st())
+    torch.cuda.synchronize()
+    off = 0
+    for (M, N), ref in zip(shapes, refs):
+        got = ws[off:off + ns.value * M * N].view(ns.value, M, N).double().sum(0).cpu().numpy()
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+        off += ns.value * M * N
+    seven = L.gemm_descs(items + [items[1]])
+    assert L.load().seqrec_gemm_f32_grouped(7, 0, 0, seven, sk, ptr(ws), st()) == -1
+
+
 def test_norm_launch_finishes_grouped_slab_products():
     """seqrec_gemm_f32_grouped_slabs + seqrec_opt_sqnorm_slabs == seqrec_gemm_f32_grouped + seqrec_opt_sqnorm: the products
     written by the norm launch are bit-identical to the reducing form (same slab order), two of them column blocks of ONE
