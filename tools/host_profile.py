@@ -50,3 +50,5 @@ print("again, 288 steps: host enqueue ms/step %.3f   wall ms/step %.3f   (graph=
 if len(sys.argv) > 3:
     pr = cProfile.Profile(); pr.enable(); run(96); pr.disable(); torch.cuda.synchronize()
     st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
+    if len(sys.argv) > 4:
+        st.sort_stats("cumtime").print_stats(45)
