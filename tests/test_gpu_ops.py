@@ -764,7 +764,8 @@ def _run_scan_both_ways(lib, cell, act, H, H_real, rb, XWd, up, dHd, rmask, grap
 
 @pytest.mark.parametrize("cell,rd", [("gru", 0), ("gru", 1), ("lstm", 0), ("lstm", 1), ("simplernn", 0), ("simplernn", 1)])
 @pytest.mark.parametrize("H,B,maxlen,act", [(256, 512, 40, "tanh"), (256, 700, 9, "relu"), (128, 333, 25, "tanh"), (64, 40, 12, "linear"),
-                                            (512, 100, 17, "tanh"), (512, 512, 12, "relu"), (256, 5, 60, "tanh"), (256, 16, 1, "tanh")])
+                                            (512, 100, 17, "tanh"), (512, 512, 12, "relu"), (256, 5, 60, "tanh"), (256, 16, 1, "tanh"),
+                                            (128, 1100, 6, "tanh")])       # 69 row blocks: more than one launch's flag buffer holds (64)
 def test_cluster_scan_equals_stepwise_scan(cell, rd, H, B, maxlen, act):
     """The one-launch cluster form of the scans (rnn_cluster.hip GRU, rnn_cluster2.hip LSTM / SimpleRNN: in-kernel exchange
     between the column-slice workgroups of a row block; with and without recurrent dropout) against the launch-per-product
