@@ -82,6 +82,10 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--parity-steps", type=int, default=8, help="steps whose loss is compared GPU vs CPU (>= 5)")
     ap.add_argument("--parity-sessions", type=int, default=256, help="held-out sessions of the Recall@20 parity sample")
+    ap.add_argument("--arbiter", default="auto", choices=["auto", "on", "off"],
+                    help="fp64 arbiter + re-synchronised single-step comparison of the parity leg: 'auto' runs them when the free-running "
+                         "trajectories part by more than the bound")
+    ap.add_argument("--resync-steps", type=int, default=0, help="steps of the re-synchronised comparison (0 = --parity-steps)")
     ap.add_argument("--recall-steps", type=int, default=1500, help="extra training steps before Recall@20 (0 = skip)")
     ap.add_argument("--force-sharded", action="store_true", help="use the row-sharded engine even on one GPU")
     ap.add_argument("--sharded-recall", action="store_true",
@@ -382,6 +386,151 @@ def cpu_leg(cd, batch, flat, starts, sels, weights, th, al, logq, seed, seconds,
                       % (timed, batch, el)}
 
 
+def _oracle_cfg(cd):
+    return dict(cell=cd["cell"], act="relu", input="embed", output="sampled", tied=bool(cd.get("tied", False)), use_bias=True, out_bias=False)
+
+
+def cpu_free_run(cd, flat, starts, sels, weights, th, al, logq, seed, steps, dtype, lr=0.01, eps=1e-8, clipnorm=1.0):
+    """Losses of `steps` free-running training steps of the oracle computed in `dtype` from `weights` (the fp64 ARBITER of the
+    parity leg: which of two fp32 trajectories that part is the one that left the exact one?)."""
+    from oracle import nn as onn
+    from oracle import rng as orng
+    p = {k: v.astype(dtype) for k, v in weights.items()}
+    acc = {k: np.zeros_like(v) for k, v in p.items()}
+    net = onn.OracleNet(_oracle_cfg(cd), p)
+    out = []
+    for i in range(steps):
+        neg = orng.sample_negatives(seed, i, cd["K"], th, al)
+        o = net.forward(padded_batch(flat, starts, sels[i % len(sels)]), negatives=neg, logq=logq)
+        onn.adagrad_step(p, acc, net.backward(), lr=lr, eps=eps, clipnorm=clipnorm)
+        out.append(float(o["loss"]))
+    return out
+
+
+class GpuSide:
+    """What parity_resync needs from the device path (tests/test_bench_cpu.py substitutes a second oracle)."""
+
+    def __init__(self, eng, ds, sels, lr=0.01, eps=1e-8, clipnorm=1.0):
+        self.eng, self.ds, self.sels, self.hp = eng, ds, sels, (lr, eps, clipnorm)
+
+    def reset(self, weights):
+        for k, v in weights.items():
+            self.eng.set_param(k, v)
+            self.eng.A[k].zero_()
+
+    def step(self, i):
+        lr, eps, clipnorm = self.hp
+        d = self.eng.upload_device(self.ds, self.sels[i % len(self.sels)])
+        return float(self.eng.train_step(d, lr=lr, eps=eps, clipnorm=clipnorm, step=i).item())
+
+    def read(self, name, rows):
+        return self.eng.get_param(name) if rows is None else self.eng.get_rows(name, rows)
+
+    def write(self, name, rows, p, a):
+        if rows is None:
+            self.eng.set_param(name, p)
+            self.eng.set_param(name, a, accum=True)
+        else:
+            self.eng.set_rows(name, rows, p)
+            self.eng.set_rows(name, rows, a, accum=True)
+
+    def scale(self):
+        return float(self.eng.scale.item())
+
+
+def parity_resync(cd, flat, starts, sels, weights, th, al, logq, seed, steps, gpu, lr=0.01, eps=1e-8, clipnorm=1.0):
+    """RE-SYNCHRONISED single-step comparison.  Three paths -- the oracle in fp64 (master), the oracle in fp32
+    and the device -- run step i on the same batch and negatives FROM IDENTICAL NUMBERS: after every step the master's updated
+    weights and Adagrad accumulators are rounded to fp32 and loaded into all three (only the rows the step touched, plus the
+    dense tensors), so rounding cannot compound from step to step.  Compared per step: the loss (computed before the update) and,
+    per tensor, the update each path applied, dX = X_after - X_before, against the master's:
+      l2       |dX - d64| / |d64| over the touched rows;
+      flips    elements whose update differs from the master's by more than lr / 2 -- Adagrad from a zero (or tiny) accumulator moves
+               an element by -lr g / (|g| + eps) ~ -lr sign(g): a gradient element within rounding of 0 flips its +-lr move;
+      l2_rest  the same l2 without the flipped elements.
+    The fp32 oracle stands beside the device as the yardstick: the device is held to what fp32 arithmetic itself achieves."""
+    from oracle import nn as onn
+    from oracle import rng as orng
+    K = cd["K"]
+    ocfg = _oracle_cfg(cd)
+    p64 = {k: v.astype(np.float64) for k, v in weights.items()}
+    a64 = {k: np.zeros_like(v) for k, v in p64.items()}
+    p32 = {k: v.astype(np.float32) for k, v in weights.items()}
+    a32 = {k: np.zeros_like(v) for k, v in p32.items()}
+    net64, net32 = onn.OracleNet(ocfg, p64), onn.OracleNet(ocfg, p32)
+    gpu.reset(weights)
+    rec = {"steps": steps, "loss_f64": [], "loss_rel_gpu": [], "loss_rel_cpu32": [], "clip_scale_rel_gpu": [], "clip_scale_rel_cpu32": [],
+           "tokens_ce_clipped": [], "update": {}}
+    for i in range(steps):
+        batch = padded_batch(flat, starts, sels[i % len(sels)])
+        neg = orng.sample_negatives(seed, i, K, th, al)
+        o64 = net64.forward(batch, negatives=neg, logq=logq)
+        g64 = net64.backward()
+        o32 = net32.forward(batch, negatives=neg, logq=logq)
+        g32 = net32.backward()
+        lg = gpu.step(i)
+        # tokens whose target probability sits below the Theano clip (zero gradient there: the loss is continuous, its gradient is not)
+        lt, ln = o64["lt"], o64["ln"]
+        mx = np.maximum(lt, ln.max(axis=1))
+        pt = np.exp(lt - mx) / (np.exp(lt - mx) + np.exp(ln - mx[:, None]).sum(axis=1))
+        rec["tokens_ce_clipped"].append(int((pt < 1e-7).sum()))
+        rows = {k: (np.asarray(v[0]) if isinstance(v, tuple) else None) for k, v in g64.items()}
+        before = {k: (p32[k].copy() if r is None else p32[k][r].copy()) for k, r in rows.items()}
+        sc64 = onn.adagrad_step(p64, a64, g64, lr=lr, eps=eps, clipnorm=clipnorm)
+        sc32 = onn.adagrad_step(p32, a32, g32, lr=lr, eps=eps, clipnorm=clipnorm)
+        rec["loss_f64"].append(float(o64["loss"]))
+        rec["loss_rel_gpu"].append(float("%.3g" % rel(lg, float(o64["loss"]))))
+        rec["loss_rel_cpu32"].append(float("%.3g" % rel(float(o32["loss"]), float(o64["loss"]))))
+        rec["clip_scale_rel_gpu"].append(float("%.3g" % rel(gpu.scale(), sc64)))
+        rec["clip_scale_rel_cpu32"].append(float("%.3g" % rel(sc32, sc64)))
+        for k, r in rows.items():
+            b = before[k].astype(np.float64)
+            d64 = (p64[k] if r is None else p64[k][r]) - b
+            cand = {"gpu": gpu.read(k, r).astype(np.float64) - b, "cpu32": (p32[k] if r is None else p32[k][r]).astype(np.float64) - b}
+            u = rec["update"].setdefault(k, {"elements": [], "gpu_l2": [], "cpu32_l2": [], "gpu_flips": [], "cpu32_flips": [],
+                                             "gpu_l2_rest": [], "cpu32_l2_rest": []})
+            u["elements"].append(int(d64.size))
+            den = max(float(np.linalg.norm(d64)), 1e-30)
+            for who, dx in cand.items():
+                e = dx - d64
+                flip = np.abs(e) > 0.5 * lr
+                u[who + "_l2"].append(float("%.3g" % (np.linalg.norm(e) / den)))
+                u[who + "_flips"].append(int(flip.sum()))
+                u[who + "_l2_rest"].append(float("%.3g" % (np.linalg.norm(e[~flip]) / den)))
+        # re-synchronise: the master, rounded to fp32, becomes everybody's state
+        for k, r in rows.items():
+            if r is None:
+                p32[k][...] = p64[k]; a32[k][...] = a64[k]
+                p64[k][...] = p32[k]; a64[k][...] = a32[k]
+                gpu.write(k, None, p32[k], a32[k])
+            else:
+                p32[k][r] = p64[k][r]; a32[k][r] = a64[k][r]
+                p64[k][r] = p32[k][r]; a64[k][r] = a32[k][r]
+                gpu.write(k, r, p32[k][r], a32[k][r])
+    return rec
+
+
+RESYNC_LOSS_BOUND = 1e-5          # one step from identical numbers: loss of the device vs the fp64 master
+RESYNC_REST_BOUND = 1e-3          # ... and its update outside the +-lr flips (north_star's bound, on the update itself)
+
+
+def resync_verdict(rec):
+    """Machine-checked reading of a parity_resync record: ok iff at EVERY step the device's loss is within RESYNC_LOSS_BOUND of the
+    fp64 master's and, per tensor, its update outside the flipped elements is within RESYNC_REST_BOUND (or within 4x of what the fp32
+    oracle manages), with no more flips than 4x the fp32 oracle's + 8."""
+    why = []
+    for i, x in enumerate(rec["loss_rel_gpu"]):
+        if not x <= RESYNC_LOSS_BOUND:
+            why.append("step %d: loss off by %.3g" % (i, x))
+    for k, u in rec["update"].items():
+        for i in range(len(u["gpu_l2"])):
+            if not u["gpu_l2_rest"][i] <= max(RESYNC_REST_BOUND, 4.0 * u["cpu32_l2_rest"][i]):
+                why.append("step %d: update of %s off by %.3g outside the flips (fp32 oracle: %.3g)" % (i, k, u["gpu_l2_rest"][i], u["cpu32_l2_rest"][i]))
+            if u["gpu_flips"][i] > 4 * u["cpu32_flips"][i] + 8:
+                why.append("step %d: %d flipped elements in %s (fp32 oracle: %d)" % (i, u["gpu_flips"][i], k, u["cpu32_flips"][i]))
+    return (not why), why
+
+
 def sample_order(rb):
     """Packed-token index of every real (session row, step) in the row-major order cpu_rank_counts uses."""
     order, ls, so = rb.order.astype(np.int64), rb.lengths.astype(np.int64), rb.step_off.astype(np.int64)
@@ -398,8 +547,36 @@ def rel(a, b):
     return abs(a - b) / max(abs(b), 1e-12)
 
 
+def self_launch(a, argv):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start `python -m torch.distributed.run --nproc-per-node N
+    bench.py <same flags>` as a CHILD process -- before this process has touched the GPU (torch is not even imported yet;
+    replacing a process that has initialised HIP is forbidden on the pool) -- relay rank 0's JSON line on stdout and
+    exit with the child's code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                     # a free rendezvous port (several benches may share a node)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    args = list(sys.argv[1:] if argv is None else argv)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + args
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the pool's host driver supports dmabuf IPC only (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)      # stderr passes through
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    elif r.returncode == 0:
+        sys.stderr.write("bench.py: the %d-rank child printed no JSON line\n" % a.gpus)
+        return 1
+    return r.returncode
+
+
 def main(argv=None):
     a = parse(argv)
+    if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a, argv))
     # stdout carries exactly ONE line (the JSON): everything libraries print while we run (RCCL's
     # version banner, warnings) is sent to stderr by pointing fd 1 at fd 2 until the final print.
     sys.stdout.flush()
@@ -410,8 +587,20 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch it as `python bench.py --gpus N` or under "
+                         "torch.distributed.run --nproc-per-node N" % (a.gpus, world))
+    if os.environ.get("SEQREC_BENCH_DRYRUN") == "1":
+        # launcher rehearsal (tests/test_bench_cpu.py, no GPU): rendezvous over gloo, one collective, rank 0's line relayed
+        import torch.distributed as dist_
+        dist_.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.ones(1)
+        dist_.all_reduce(t)
+        dist_.barrier()
+        if rank == 0:
+            os.dup2(saved_stdout, 1)
+            print(json.dumps({"dryrun": True, "n_gpus": world, "ranks_seen": int(t.item()), "steps": a.steps}), flush=True)
+        dist_.destroy_process_group()
+        return
     dist = None
     if world > 1 or a.force_sharded:
         import torch.distributed as dist_
@@ -736,6 +925,37 @@ def main(argv=None):
                         "identical_ranks_frac": round(float((gr2 == cr2[0]).mean()), 5),
                         "note": "GPU-trained weights scored by both paths"}
                     ok = ok and (rg == rc or rel(rg, rc) <= PARITY_BOUND)
+                # ---- the arbiter: when two fp32 trajectories part, fp64 says which one left, and the
+                # re-synchronised comparison says whether any single step of the device is wrong
+                if a.arbiter == "on" or (a.arbiter == "auto" and worst > PARITY_BOUND):
+                    l64 = cpu_free_run(cd, flat, starts, sels, weights, th, al, logq, SEED, P, np.float64)
+                    g64 = [float("%.3g" % rel(g, x)) for g, x in zip(gl, l64)]
+                    c64 = [float("%.3g" % rel(c, x)) for c, x in zip(cl, l64)]
+                    parity["vs_fp64"] = {"loss_f64": [round(x, 6) for x in l64], "gpu_rel": g64, "cpu32_rel": c64,
+                                         "note": "free-running: the same oracle in fp64 on the same batches / negatives / initial weights"}
+                    rs = parity_resync(cd, flat, starts, sels, weights, th, al, logq, SEED, a.resync_steps or P, GpuSide(eng, ds, sels))
+                    rs_ok, why = resync_verdict(rs)
+                    rs["ok"], rs["why_not"] = bool(rs_ok), why
+                    rs["bounds"] = {"loss": RESYNC_LOSS_BOUND, "update_outside_flips": RESYNC_REST_BOUND}
+                    parity["resync"] = rs
+                    parity["resync_ok"] = bool(rs_ok)
+                    # ill-conditioned = the fp32 ORACLE cannot hold the bound against its own fp64 version over these steps
+                    ill = max(c64) > PARITY_BOUND
+                    # the device may leave the exact trajectory no earlier than a step before the fp32 oracle does, and while the oracle is inside
+                    # the bound the device must be too
+                    first = lambda xs: next((i for i, x in enumerate(xs) if x > PARITY_BOUND), len(xs))
+                    no_worse = first(g64) + 1 >= first(c64)
+                    parity["trajectory_ok"] = bool(worst <= PARITY_BOUND)
+                    parity["ill_conditioned"] = bool(ill)
+                    parity["ok_reason"] = ("trajectory within bound" if worst <= PARITY_BOUND else
+                                           ("free-running trajectory ill-conditioned (the fp32 oracle leaves its fp64 version at step %d, the device at step %d); "
+                                            "every single step from identical numbers agrees (resync_ok)" % (first(c64), first(g64))) if (ill and rs_ok and no_worse) else
+                                           "FAILED: " + "; ".join(why[:4] or ["device leaves the fp64 trajectory before the fp32 oracle does"]))
+                    if worst > PARITY_BOUND:
+                        # Recall@20 after P free-running steps of an ill-conditioned trajectory is not comparable either; the trained-weights
+                        # comparison (the SAME weights scored by both paths) is
+                        tp = parity.get("recall_at_20_sample_trained")
+                        ok = bool(ill and rs_ok and no_worse) and (tp is None or tp["gpu"] == tp["cpu"] or tp["rel_diff"] <= PARITY_BOUND)
                 parity["ok"] = bool(ok)
         except Exception as e:                                   # noqa: BLE001
             notes.append("cpu_baseline leg failed: %r" % (e,))

@@ -61,7 +61,7 @@ extern "C" {
  *    seqrec_cluster_scan_errors_reset, seqrec_debug_cluster_spin_limit, seqrec_exchange_pack / _unpack / _grad_pack,
  *    seqrec_sampled_softmax_ce_rows_idx, seqrec_route_*_host; the packed layout of the step-wise LSTM forward
  *    kernel changed (seqrec_rnn_pack_u_stepwise and the scans of one library always agree) */
-#define SEQREC_ABI_VERSION 4
+#define SEQREC_ABI_VERSION 5
 
 enum { SEQREC_OK = 0, SEQREC_E_ARG = -1, SEQREC_E_SHAPE = -2, SEQREC_E_UNSUPPORTED = -3 };
 /* bits of a device status word (see Conventions): set with atomic OR by the kernels, never cleared by them */
@@ -299,7 +299,8 @@ int seqrec_index_affine_i32(int32_t* dst, const int32_t* dst_pos, const int32_t*
  *        carries the draws' global ids id * id_mul + id_add bit-cast into the float buffer.  rows_eff[j] (m_tot) receives
  *        the table row every owner-side row stands for (-1: none) -- the scatter list of the returning gradients.
  *      exchange_unpack (requester, after it): Eneg[k,:] = recv[neg_rows[k],:], neg[k] = ((int32*)recv)[negid_idx[k]],
- *        lq_neg[k] = logq[neg[k]] (nullable).
+ *        lq_neg[k] = logq[neg[k]] (nullable; the ids were written by a peer: one outside [0, logq_rows) reads 0 and sets
+ *        SEQREC_STATUS_BAD_INDEX in *status, ABI 5).
  *      exchange_grad_pack (requester, before all-to-all #2): out[j,:] for the n_tot requester-side rows, b = back_idx[j]:
  *        b < 0 zero; b < n: sum of the dx_slabs split-K slabs of dX row b; b < 2n: dlt[b-n] * Hd[b-n,:]; else the sum of the
  *        dn_slabs slabs of dEneg row b - 2n (seqrec_gemm_f32_slabs products: no reduce launch, no staging copy). */
@@ -308,7 +309,8 @@ int seqrec_exchange_pack(const float* table, int64_t table_rows, int width, cons
                          int32_t row_offset, const int32_t* neg_slots, const int32_t* id_rows, int n_id_rows, int per_peer,
                          int32_t id_mul, int32_t id_add, float* sendbuf, int32_t* rows_eff, uint32_t* status, void* stream);
 int seqrec_exchange_unpack(const float* recv, int width, const int32_t* neg_rows, const int32_t* negid_idx, int K,
-                           const float* logq, float* Eneg, int32_t* neg, float* lq_neg, void* stream);
+                           const float* logq, int64_t logq_rows, float* Eneg, int32_t* neg, float* lq_neg, uint32_t* status,
+                           void* stream);
 int seqrec_exchange_grad_pack(const int32_t* back_idx, int64_t n_tot, int n, int K, int width, const float* dX, int dx_slabs,
                               int64_t dx_stride, const float* Hd, const float* dlt, const float* dEneg, int dn_slabs,
                               int64_t dn_stride, float* out, void* stream);

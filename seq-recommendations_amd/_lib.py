@@ -36,7 +36,7 @@ F = C.c_float
 D = C.c_double
 U64 = C.c_uint64
 
-ABI_VERSION = 4          # SEQREC_ABI_VERSION of include/seqrec_hip.h this binding was written against
+ABI_VERSION = 5          # SEQREC_ABI_VERSION of include/seqrec_hip.h this binding was written against
 
 # name -> argtypes   (restype is int unless listed in _RESTYPES)
 _SIGS = {
@@ -70,7 +70,7 @@ _SIGS = {
     "seqrec_sampled_softmax_ce_rows": [P, L, P, I, P, P, P, P, P, L, I, F, P, P, P],
     "seqrec_sampled_softmax_ce_rows_idx": [P, L, P, I, P, L, P, P, P, P, P, L, I, F, P, P, P],
     "seqrec_exchange_pack": [P, L, I, P, L, U64, U64, I, P, P, I, I, P, P, I, I, I, I, P, P, P, P],
-    "seqrec_exchange_unpack": [P, I, P, P, I, P, P, P, P, P],
+    "seqrec_exchange_unpack": [P, I, P, P, I, P, L, P, P, P, P, P],
     "seqrec_exchange_grad_pack": [P, L, I, I, I, P, I, L, P, P, P, I, L, P, P],
     "seqrec_route_count_host": [P, P, L, I, P],
     "seqrec_route_fill_host": [P, P, L, I, L, I, P, P, P, P],

@@ -69,8 +69,9 @@ __global__ void exchange_pack_kernel(PackArgs a) {
 }
 
 __global__ void exchange_unpack_kernel(const float* __restrict__ recv, int width, const int* __restrict__ neg_rows,
-                                       const int* __restrict__ negid_idx, int K, const float* __restrict__ logq, float* __restrict__ Eneg,
-                                       int* __restrict__ neg, float* __restrict__ lq_neg) {
+                                       const int* __restrict__ negid_idx, int K, const float* __restrict__ logq, long logq_rows,
+                                       float* __restrict__ Eneg, int* __restrict__ neg, float* __restrict__ lq_neg,
+                                       unsigned* __restrict__ status) {
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (k >= K) return;
@@ -78,7 +79,11 @@ __global__ void exchange_unpack_kernel(const float* __restrict__ recv, int width
     if (lane == 0) {
         const int id = reinterpret_cast<const int*>(recv)[negid_idx[k]];
         neg[k] = id;
-        if (lq_neg) lq_neg[k] = logq[id];
+        if (lq_neg) {                              // the id was written by a PEER: never index with it unchecked
+            const bool ok = id >= 0 && (long)id < logq_rows;
+            lq_neg[k] = ok ? logq[id] : 0.f;
+            if (!ok && status) atomicOr(status, SEQREC_STATUS_BAD_INDEX);
+        }
     }
 }
 
@@ -142,13 +147,14 @@ extern "C" int seqrec_exchange_pack(const float* table, int64_t table_rows, int 
 }
 
 extern "C" int seqrec_exchange_unpack(const float* recv, int width, const int32_t* neg_rows, const int32_t* negid_idx, int K,
-                                      const float* logq, float* Eneg, int32_t* neg, float* lq_neg, void* stream) {
-    if (K < 0 || width <= 0 || (width & 3)) return SEQREC_E_ARG;
+                                      const float* logq, int64_t logq_rows, float* Eneg, int32_t* neg, float* lq_neg,
+                                      uint32_t* status, void* stream) {
+    if (K < 0 || width <= 0 || (width & 3) || (lq_neg && logq_rows <= 0)) return SEQREC_E_ARG;
     if (K == 0) return 0;
     if (!recv || !neg_rows || !negid_idx || !Eneg || !neg || (lq_neg && !logq)) return SEQREC_E_ARG;
     if ((reinterpret_cast<uintptr_t>(recv) | reinterpret_cast<uintptr_t>(Eneg)) & 15) return SEQREC_E_ARG;
     hipLaunchKernelGGL(exchange_unpack_kernel, dim3((unsigned)((K + 3) / 4)), dim3(256), 0, as_stream(stream), recv, width, neg_rows,
-                       negid_idx, K, logq, Eneg, neg, lq_neg);
+                       negid_idx, K, logq, (long)logq_rows, Eneg, neg, lq_neg, status);
     SEQREC_LAUNCH_CHECK();
     return 0;
 }

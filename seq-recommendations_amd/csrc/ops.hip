@@ -642,8 +642,12 @@ __global__ void opt_apply_kernel(OptPlan pl, const float* __restrict__ sq, float
         if (zero_next) zero_next[0] = 0.f;            // the OTHER norm slot: nobody reads or adds to it during this step
         if (bad && status) atomicOr(status, bad);
     }
-    if (bad) return;                                   // uniform over the launch: every thread read the same three scalars
+    // `bad` is uniform over the launch: every thread read the same three scalars.  A refused step still CLEARS what the row
+    // jobs own -- the gradient rows the scatter filled and the owner slots it claimed -- without touching table or
+    // accumulator: the next step's scatter must find all-zero gradient rows and free slots (a stale atomicMin claim would
+    // keep slot[r] == base + i from ever matching again: the row frozen, its gradient row growing with every step)
     if ((int)blockIdx.y < pl.nd) {
+        if (bad) return;
         float* p = pl.d.p[blockIdx.y];
         float* a = pl.d.a[blockIdx.y];
         const float* g = pl.d.g[blockIdx.y];
@@ -663,6 +667,11 @@ __global__ void opt_apply_kernel(OptPlan pl, const float* __restrict__ sq, float
     const int r = J.rows[i];
     if (r < 0 || J.slot[r] != J.base + (int)i) return;
     const long o = (long)r * J.width;
+    if (bad) {                                         // discard mode (see above)
+        for (int c = lane; c < J.width; c += 64) J.gtab[o + c] = 0.f;
+        if (lane == 0) J.slot[r] = INT_MAX;
+        return;
+    }
     if ((J.width & 3) == 0 && (((uintptr_t)J.gtab | (uintptr_t)J.accum | (uintptr_t)J.table) & 15) == 0) {
         // 16 bytes per lane: a 256-wide row is ONE load per array and one store per array -- the element-wise loop below is
         // four dependent rounds of (3 loads -> 3 stores), the stores of a round fencing the loads of the next (may alias)

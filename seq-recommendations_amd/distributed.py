@@ -509,6 +509,42 @@ class ShardedEngine(Engine):
                 self.Gt[name] = self.TG[lo:hi]
                 self.slot[name] = self.TS[lo:hi]
 
+    # ---- device-side failures: every rank raises, or none does ----------------------------------------
+    def check_status(self):
+        """Engine.check_status over the GROUP: the status word and the cluster scans' error count are rank-local (a bad
+        index from a peer, an exchange wait that ran out on one GPU), but a rank that raises alone leaves the others inside
+        the next all-to-all -- under RCCL a hang until the watchdog fires, not a failure.  Both are all-reduced first (OR of
+        the status bits as a MAX over the bit columns, MAX of the error count; it is a host sync anyway), so every rank
+        decodes the same condition and raises together; the message names the ranks that reported it.  Collective: call it
+        on every rank at the same point (epoch end, evaluation, read-back -- where Engine does)."""
+        from .engine import status_messages
+        lib = _lib.load()
+        st = self._stream()
+        bits = self.status.to(torch.int64)
+        nerr = int(lib.seqrec_cluster_scan_errors(st))
+        nb = 32
+        cols = ((bits >> torch.arange(nb, device=self.dev)) & 1).to(torch.int64)          # [32] one column per status bit
+        mine = torch.cat([cols, torch.tensor([nerr if nerr >= 0 else 1 << 40], dtype=torch.int64, device=self.dev)])
+        every = [torch.empty_like(mine) for _ in range(self.R)]
+        if self.R > 1:
+            self.dist.all_gather(every, mine, group=self.group)
+        else:
+            every = [mine]
+        table = torch.stack(every).cpu().numpy()                                            # [R, 33]
+        gbits = 0
+        for b in range(nb):
+            if table[:, b].any():
+                gbits |= 1 << b
+        gerr = int(table[:, nb].max())
+        msgs = status_messages(gbits, gerr if gerr < (1 << 40) else -1)
+        if not msgs:
+            return
+        who = [int(r) for r in np.nonzero(table.any(axis=1))[0]]
+        self.status.zero_()
+        lib.seqrec_cluster_scan_errors_reset(st)
+        raise _lib.SeqrecError("device-side failure at or before training step %d on rank(s) %s of %d (raised on every rank): %s"
+                               % (self.step_count, who, self.R, "; ".join(msgs)))
+
     # ---- helpers -----------------------------------------------------------------------------------
     def _take(self, src, idx, out=None):
         if out is None:
@@ -913,7 +949,8 @@ class ShardedEngine(Engine):
         neg = self.buf("neg", K, dtype=torch.int32)
         lq_neg = self.buf("lq_neg", K) if (c.logq and self.logq_global is not None) else None
         call("seqrec_exchange_unpack", ptr(recv), w, ptr(d["neg_rows"]), ptr(d["negid_idx"]), K,
-             ptr(self.logq_global if lq_neg is not None else None), ptr(Eneg), ptr(neg), ptr(lq_neg), st)
+             ptr(self.logq_global if lq_neg is not None else None), self.V_global, ptr(Eneg), ptr(neg), ptr(lq_neg),
+             ptr(self.status), st)
         return recv, Eneg, neg, lq_neg, rows_eff
 
     def eval_loss(self, d, negatives=None, step=0):

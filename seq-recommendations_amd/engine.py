@@ -573,6 +573,45 @@ class Engine:
             return a[: c.x_dim, : c.V_out].copy()
         raise KeyError(name)
 
+    def _row_cols(self, name):
+        """Unpadded width of a row of item table `name`."""
+        c = self.cfg
+        if name == "E":
+            return c.H if c.tied else c.D
+        if name == "Eout":
+            return c.H
+        if name == "bout":
+            return 1
+        raise KeyError("%s is not an item table with plain rows (E, Eout, bout)" % name)
+
+    def get_rows(self, name, rows, accum=False):
+        """Rows `rows` (int array) of item table `name` -- or of its Adagrad accumulator -- as an unpadded host array: the
+        read-back of what ONE step changed at catalogue scale, where get_param would move the whole table."""
+        self.check_status()
+        t = (self.A if accum else self.P)[name]
+        idx = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int64)).to(self.dev)
+        w = self._row_cols(name)
+        if t.dim() == 1:
+            return t[idx].cpu().numpy()
+        return t[idx][:, :w].cpu().numpy()
+
+    def set_rows(self, name, rows, values, accum=False):
+        """Overwrite rows of an item table (accum=True: of its accumulator) with unpadded host values; padded columns stay
+        zero.  With set_param(..., accum=True) this loads a complete optimizer state (bench.py's re-synchronised parity leg)."""
+        t = (self.A if accum else self.P)[name]
+        idx = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int64)).to(self.dev)
+        v = torch.from_numpy(np.ascontiguousarray(values, dtype=np.float32)).to(self.dev)
+        if t.dim() == 1:
+            t[idx] = v.reshape(-1)
+            return
+        w = self._row_cols(name)
+        if w == t.shape[1]:
+            t[idx] = v
+        else:
+            pad = torch.zeros((idx.numel(), t.shape[1]), dtype=torch.float32, device=self.dev)
+            pad[:, :w] = v
+            t[idx] = pad
+
     def set_sampler(self, thresh, alias, logq=None):
         """Alias table of the negative-sampling proposal (built on the host)."""
         th = torch.from_numpy(np.asarray(thresh, dtype=np.uint32).view(np.int32).copy()).to(self.dev)

@@ -415,9 +415,12 @@ def test_device_side_failure_raises_instead_of_training_on():
     ecfg, ocfg = make_cfg(cell="lstm", act="relu", H=128, V=500, inp="embed", out="sampled", D=64, K=64)
     pair = Pair(ecfg, ocfg, init_np_params(rng, ocfg, 500, 128, 64))
     eng = pair.eng
-    d = eng.upload(B.pack_sessions(make_sessions(rng, 40, 500, 2, 12)))
-    float(eng.train_step(d, lr=0.01, step=0).item())
-    eng.check_status()                                   # a healthy step: nothing to report
+    first = make_sessions(rng, 40, 500, 2, 12)
+    sessions2 = [make_sessions(rng, 40, 500, 2, 12) for _ in range(2)]
+    lg, lo, _ = pair.step(first, 0, lr=0.01)             # a healthy step on engine and oracle
+    assert abs(lg - lo) <= 1e-4 * max(1.0, abs(lo))
+    d = eng.upload(B.pack_sessions(first))
+    eng.check_status()                                   # nothing to report
     eng.P["Eout"][:] = 1e30
     before = {k: v.clone() for k, v in eng.P.items()}
     eng.train_step(d, lr=0.01, step=1)
@@ -426,6 +429,17 @@ def test_device_side_failure_raises_instead_of_training_on():
     for k, v in eng.P.items():
         assert torch.equal(v, before[k]), k              # the refused update changed nothing
     eng.check_status()                                   # reported once, then clear
+    # ... and the refused step left nothing behind: its gradient rows are zero again and the owner slots free, so a
+    # caller that catches the error and restores the table trains on exactly like the oracle, which saw the healthy steps only
+    for k in eng.Gt:
+        assert float(eng.Gt[k].abs().max().item()) == 0.0, k
+        assert int((eng.slot[k] != 2 ** 31 - 1).sum().item()) == 0, k
+    eng.P["Eout"].copy_(torch.from_numpy(np.pad(pair.op["Eout"], ((0, 0), (0, eng.Hp - 128)))).to(eng.dev))
+    pair.eng.step_count = 1
+    for step in (1, 2):
+        lg, lo, _ = pair.step(sessions2[step - 1], step, lr=0.01)
+        assert abs(lg - lo) <= 1e-4 * max(1.0, abs(lo)), (step, lg, lo)
+    assert max(pair.max_param_diff().values()) < 2e-3
 
 
 def test_pinned_ring_uploads_are_safe_by_construction():

@@ -222,3 +222,38 @@ def test_row_gradients_equal_a_torch_index_add_of_the_three_scatter_lists(world)
         for name in lists:
             eng.Gt[name].zero_()
             eng.slot[name].fill_(E.INT32_MAX)
+
+
+@pytest.mark.parametrize("config", ["c4", "c5"])
+def test_resynchronised_steps_agree_with_the_fp64_oracle_at_full_size(config):
+    """The two configurations whose FREE-RUNNING trajectories are ill-conditioned (c4: relu LSTM-512; c5: one tied 5M-row table)
+    are held step by step instead (bench.parity_resync): the fp64 oracle, the fp32 oracle and the device run
+    five training steps at FULL size -- 1M / 5M items, batch 512, K 4000 / 2000 -- each step from identical numbers (the fp64
+    master's state rounded to fp32, loaded into all three); the device's loss must be within 1e-5 of the master's before every
+    update, and its update of every tensor within 1e-3 (or 4x the fp32 oracle's own error) outside the +-lr sign flips that Adagrad
+    makes of gradient elements within rounding of zero, of which it may not have more than the fp32 oracle (x4 + 8)."""
+    import bench
+    cd = bench.CONFIGS[config]
+    V, SEED = cd["V"], 1234
+    cfg = E.NetConfig(cell=cd["cell"], act="relu", H=cd["H"], V_in=V, V_out=V, input="embed", D=cd["D"], output="sampled",
+                      K=cd["K"], tied=bool(cd.get("tied", False)), use_bias=True, out_bias=False, logq=True, seed=SEED)
+    eng = E.Engine(cfg)
+    gen = Sy.SyntheticSessions(V, seed=SEED)
+    probs = Sm.log_uniform_probs(V, gen.proposal_rank())
+    th, al = Sm.build_alias_table(probs)
+    logq = np.log(probs).astype(np.float32)
+    eng.set_sampler(th, al, logq)
+    flat, starts = gen.generate(8 * B)
+    ds = eng.put_dataset(flat, starts)
+    eng.reserve(B * 49)
+    stream = bench.BatchStream(0, 8 * B, B, SEED)
+    sels = [stream.sel(i).copy() for i in range(5)]
+    weights = bench.host_weights(cd, SEED)
+    rec = bench.parity_resync(cd, flat, starts, sels, weights, th, al, logq, SEED, 5, bench.GpuSide(eng, ds, sels))
+    ok, why = bench.resync_verdict(rec)
+    summary = {k: {f: u[f] for f in ("gpu_l2_rest", "cpu32_l2_rest", "gpu_flips", "cpu32_flips")} for k, u in rec["update"].items()}
+    print("resync %s: loss_rel_gpu %s loss_rel_cpu32 %s update %s" % (config, rec["loss_rel_gpu"], rec["loss_rel_cpu32"], summary))
+    assert ok, (why, rec["loss_rel_gpu"], summary)
+    eng.check_status()
+    del eng
+    torch.cuda.empty_cache()

@@ -6,7 +6,11 @@ inline-asm ds_read behind the last tile had no reader; hipcc -- which does not t
 register to the address arithmetic that followed, and the LDS data arriving later overwrote it: one wave's DMA fetched an A
 row from an arbitrary address, a 32 x 32 block of dU came out as ~1e35, the squared gradient norm as inf, the Keras clip
 scale as 0, the whole step a no-op.  One process alone never opened the window (3 000 of 3 000 launches identical);
-with three other processes on the GPU up to EVERY launch was wrong (tools/mp_stress.py).  This test is that probe."""
+with three other processes on the GPU up to EVERY launch was wrong (tools/mp_stress.py).
+
+Round 4: the deterministic guard for that CLASS of bug is tests/test_asm_lint.py (static check of the emitted ISA, runs on the CPU
+box).  This module is only a short smoke that the kernels still repeat bit for bit beside ONE other process that is proven to be
+running: 100 GEMM launches and 3 x 20 scans -- it no longer loads the shared box with three extra processes and 1 950 launches."""
 import importlib
 import os
 import subprocess
@@ -27,10 +31,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.fixture(scope="module")
 def busy_gpu():
-    """three other processes on the card for the duration of the module (the box allows 6)"""
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "gpu_background_load.py"), "60"]) for _ in range(3)]
-    time.sleep(8)                       # their first import torch + warm-up
-    yield
+    """ONE other process on the card for the duration of the module; it runs until it is terminated (a fixed 60 s could
+    end before the last case and let it pass on an idle GPU) and every case asserts that it is still alive afterwards."""
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "gpu_background_load.py"), "1200"])]
+    time.sleep(8)                       # its first import torch + warm-up
+    yield procs
     for p in procs:
         p.terminate()
     for p in procs:
@@ -68,8 +73,9 @@ def test_gathered_weight_gradient_gemm_is_bit_stable_beside_other_processes(busy
     def grouped():
         call("seqrec_gemm_f32_grouped", 3, 0, 0, descs, 1, None, st)
         return torch.cat([dU.reshape(-1), dW.reshape(-1), db])
-    ref, bad, worst = _repeat(grouped, 1500)
-    assert bad == 0, "%d of 1500 launches differ (max |diff| %.3g)" % (bad, worst)
+    ref, bad, worst = _repeat(grouped, 100)
+    assert bad == 0, "%d of 100 launches differ (max |diff| %.3g)" % (bad, worst)
+    assert all(p.poll() is None for p in busy_gpu), "the background load ended before the test did"
     Hprev = torch.where((prev >= 0)[:, None], Hout[prev.clamp(min=0).long()], torch.zeros_like(Hout))
     want = (Hprev.double().t() @ dPre.double()).float()
     assert float((ref[: H * GH].view(H, GH) - want).abs().max().item()) < 1e-3
@@ -95,6 +101,7 @@ def test_cluster_scans_are_bit_stable_beside_other_processes(busy_gpu, cell, H):
         call("seqrec_rnn_fwd_stepwise", ci, 1, H, H, rb.T, rb.B, None, rb.step_off.ctypes.data, ptr(XW), ptr(Ho), ptr(ga), ptr(au), ptr(up), None, 0, st)
         call("seqrec_rnn_bwd_stepwise", ci, 1, H, H, rb.T, rb.B, None, rb.step_off.ctypes.data, n, ptr(dH), ptr(Ho), ptr(ga), ptr(au), ptr(dP), ptr(up), ptr(ws), None, 0, st)
         return torch.cat([Ho.reshape(-1), dP.reshape(-1)])
-    _, bad, worst = _repeat(scan, 150)
-    assert bad == 0, "%d of 150 scans differ (max |diff| %.3g)" % (bad, worst)
+    _, bad, worst = _repeat(scan, 20)
+    assert bad == 0, "%d of 20 scans differ (max |diff| %.3g)" % (bad, worst)
+    assert all(p.poll() is None for p in busy_gpu), "the background load ended before the test did"
     assert lib.seqrec_cluster_scan_errors(st) == 0
