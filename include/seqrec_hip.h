@@ -37,6 +37,17 @@
  *     Two process-wide test switches exist (seqrec_debug_*): they select
  *     between equivalent kernel forms or force a failure path, are not
  *     thread-safe, and no product code calls them.
+ *     Environment: the library reads NO environment variable.  The developer
+ *     switches of earlier rounds (SEQREC_GEMM_V2, _V2_TILE, _V2_GTILE, _BK32,
+ *     _TILE_THR, SEQREC_CE_BLOCK, SEQREC_SCATTER_COMBINE, SEQREC_SCAN_CLUSTER,
+ *     SEQREC_SCAN_XCD, SEQREC_SCAN_WIDE_RB) exist only in a -DSEQREC_TUNABLES
+ *     build (tools/build_diag.py tunables), where each is read once per
+ *     process at its first use; in the product build each is its default, a
+ *     compile-time constant (csrc/common.h seqrec_env).
+ *     Two entry points DO synchronise beyond the three named above: the first
+ *     cluster scan on a stream (hipMalloc + hipMemset of its flag block) and
+ *     use_graph != 0 when all four executables of a sequence's ring are still
+ *     queued (hipEventSynchronize on the oldest).
  *     One stream per caller thread; calls on one stream must not be issued
  *     concurrently from two threads.
  *

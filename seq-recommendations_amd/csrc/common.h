@@ -3,6 +3,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/seqrec_hip.h"
+#include <stdlib.h>
+
+// Developer switches (A/B and tuning knobs of tools/) are read from the environment ONLY in a -DSEQREC_TUNABLES build
+// (tools/build_diag.py tunables -> tools/diag/, selected with SEQREC_LIB); the product library reads no environment
+// variable: every switch is its default, a compile-time constant (include/seqrec_hip.h, "Hidden state").
+#ifdef SEQREC_TUNABLES
+static inline long seqrec_env(const char* name, long dflt) { const char* v = getenv(name); return v ? atol(v) : dflt; }
+#else
+static inline constexpr long seqrec_env(const char*, long dflt) { return dflt; }
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -884,7 +884,7 @@ int g_v2_tile = -1, g_v2_gtile = -1;      // seqrec_debug_gemm_tile(): tests for
 // v2 (LDS-DMA ring) launcher.  Eligible: 16-byte loads legal on both operands, K % 4 == 0 for a K-contiguous operand
 // (its 16-byte chunks run along K), a K-slice-gathered A with at most V2_IDX_CAP k per workgroup, plain epilogue.
 inline bool gemm2_eligible(int a_kc, int b_kc, const GemmArgs& g) {
-    static const bool on = !(getenv("SEQREC_GEMM_V2") && atoi(getenv("SEQREC_GEMM_V2")) == 0);      // tuning switch
+    static const bool on = seqrec_env("SEQREC_GEMM_V2", 1) != 0;      // tuning switch
     if (!on || !g.a_vec || !g.b_vec || g.epi != 0 || g.K <= 0) return false;
     if ((a_kc || b_kc) && (g.K % 4 != 0)) return false;
     if (g.a_idx && !a_kc && g.k_per_split > V2_IDX_CAP) return false;
@@ -912,7 +912,7 @@ int launch_gemm2(int a_kc, int b_kc, GemmArgs& g, int splits, hipStream_t st) {
 // tile choice of v2 (measured at the c3 shapes, a 25 088-row batch and 4096^3, tools/bench_gemm2.py): the per-workgroup
 // prologue + epilogue favour MANY small workgroups until there are enough tiles for several rounds per CU
 inline int gemm2_tile(long M, long N, int splits) {
-    static const int forced = getenv("SEQREC_GEMM_V2_TILE") ? atoi(getenv("SEQREC_GEMM_V2_TILE")) : 0;      // tuning switch
+    static const int forced = (int)seqrec_env("SEQREC_GEMM_V2_TILE", 0);      // tuning switch
     if (g_v2_tile > 0) return g_v2_tile;
     if (forced) return forced;
     const long t128 = ((M + 127) / 128) * ((N + 127) / 128) * splits;
@@ -933,7 +933,7 @@ int launch_gemm2_auto(int a_kc, int b_kc, GemmArgs& g, int splits, hipStream_t s
 // 128x128 stays at 16 (LDS: 2 x 2 x 32 x 130 x 4 B would cost occupancy)
 template <int BM, int BN>
 int launch_gemm(int a_kc, int b_kc, GemmArgs& g, int splits, hipStream_t st) {
-    static const bool bk32 = getenv("SEQREC_GEMM_BK32") && atoi(getenv("SEQREC_GEMM_BK32")) != 0;   // tuning switch
+    static const bool bk32 = seqrec_env("SEQREC_GEMM_BK32", 0) != 0;   // tuning switch
     if (bk32 && !g.a_idx && BM * BN < 128 * 128 && g.k_per_split >= 64 && g.k_per_split % 32 == 0)
         return launch_gemm_bk<BM, BN, (BM * BN < 128 * 128 ? 32 : 16)>(a_kc, b_kc, g, splits, st);
     return launch_gemm_bk<BM, BN, 16>(a_kc, b_kc, g, splits, st);
@@ -1028,7 +1028,7 @@ static int gemm_f32_impl(int a_kcontig, int b_kcontig, int64_t M, int64_t N, int
     // the c3 shapes, 64x64 beats 128x64 below that (K is short: prologue/epilogue dominate)
     const long t128 = ((M + 127) / 128) * ((N + 127) / 128) * splits;
     const long t12864 = ((M + 127) / 128) * ((N + 63) / 64) * splits;
-    static const long thr = getenv("SEQREC_GEMM_TILE_THR") ? atol(getenv("SEQREC_GEMM_TILE_THR")) : 1024;   // tuning switch
+    static const long thr = seqrec_env("SEQREC_GEMM_TILE_THR", 1024);   // tuning switch
     int rc;
     if (gemm2_eligible(a_kcontig, b_kcontig, g)) rc = launch_gemm2_auto(a_kcontig, b_kcontig, g, splits, st);
     else if (g.a_idx) rc = launch_gemm<64, 64>(a_kcontig, b_kcontig, g, splits, st);
@@ -1166,7 +1166,7 @@ static int gemm_grouped_impl(int count, int a_kcontig, int b_kcontig, const seqr
     }
     bool v2 = !a_kcontig && !b_kcontig;
     for (int i = 0; i < count && v2; ++i) v2 = gemm2_eligible(0, 0, gg.g[i]);
-    static const int gtile_env = getenv("SEQREC_GEMM_V2_GTILE") ? atoi(getenv("SEQREC_GEMM_V2_GTILE")) : 1;      // tuning switch
+    static const int gtile_env = (int)seqrec_env("SEQREC_GEMM_V2_GTILE", 1);      // tuning switch
     const int gtile = g_v2_gtile > 0 ? g_v2_gtile : gtile_env;
     if (v2 && gtile == 2) {
         maxtiles = 0;

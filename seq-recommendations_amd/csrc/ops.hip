@@ -381,10 +381,14 @@ __global__ void rows_scatter_add_multi_kernel(RowsMulti m) {
 // over the 48 ids) adds the others' rows in index order and issues the only atomics for that row.
 template <int NC>
 __global__ void __launch_bounds__(768) rows_scatter_combine_kernel(RowsMulti m) {
+    // rows wider than 256 (c4: 512) go in column blocks of W = 256: blockIdx.z picks the block, the LDS image stays 48 KB
     constexpr int RPW = 4, NW = 12, CPB = RPW * NW, W = 64 * NC;
     __shared__ float vals[CPB * W];
     __shared__ int rid[64];
-    const seqrec_rows_job& J = m.j[blockIdx.y];
+    seqrec_rows_job J = m.j[blockIdx.y];
+    const int width = J.width;                          // row stride of the gradient table
+    J.vals += (long)blockIdx.z * W;
+    J.gtab += (long)blockIdx.z * W;
     const long b0 = (long)blockIdx.x * CPB;
     if (b0 >= J.n) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -439,10 +443,10 @@ __global__ void __launch_bounds__(768) rows_scatter_combine_kernel(RowsMulti m) 
 #pragma unroll
             for (int j = 0; j < NC; ++j) acc[j] += vals[o * W + lane + 64 * j];
         }
-        float* g = J.gtab + (long)r[k] * W;
+        float* g = J.gtab + (long)r[k] * width;
 #pragma unroll
         for (int j = 0; j < NC; ++j) atomicAdd(g + lane + 64 * j, acc[j]);
-        if (lane == 0) atomicMin(J.slot + r[k], J.base + (int)(i0 + k));   // the leader is the smallest index of its row here
+        if (lane == 0 && blockIdx.z == 0) atomicMin(J.slot + r[k], J.base + (int)(i0 + k));   // the leader is the smallest index of its row here
     }
 }
 __global__ void __launch_bounds__(1024) rows_sqnorm_multi_kernel(RowsMulti m, float* __restrict__ sq) {
@@ -925,7 +929,7 @@ int launch_sampled(float* ln, long ld, const float* hd, int H, const float* Eout
                    float* dlt, hipStream_t st, const int* trow = nullptr, long et_ld = 0) {
     // one wave per row; with few rows (an MSNBC-shaped batch has ~2.5 k) single-wave workgroups spread evenly over the
     // 256 CUs (10 per CU) where 4-wave workgroups leave some CUs with 3 and some with 2 (tuning switch: SEQREC_CE_BLOCK)
-    static const int ce_block = getenv("SEQREC_CE_BLOCK") ? atoi(getenv("SEQREC_CE_BLOCK")) : 64;
+    static const int ce_block = (int)seqrec_env("SEQREC_CE_BLOCK", 64);
     const int wpb = (ce_block == 256 || n > 16384) ? 4 : 1;
     const dim3 grid((unsigned)((n + wpb - 1) / wpb)), block(64 * wpb);
     // bit 0: 16-byte accesses to the logit rows are legal; bit 1: to the candidate id / log-Q vectors
@@ -1392,9 +1396,9 @@ extern "C" int seqrec_rows_scatter_add_multi(const seqrec_rows_job* jobs, int co
     for (int i = 0; i < count; ++i) if (jobs[i].n > 0 && !jobs[i].vals) return SEQREC_E_ARG;
     int w0 = jobs[0].width;
     for (int i = 0; i < count; ++i) if (jobs[i].n > 0 && (jobs[i].width != w0 || jobs[i].ldv < w0)) w0 = 0;
-    static const bool combine = !(getenv("SEQREC_SCATTER_COMBINE") && atoi(getenv("SEQREC_SCATTER_COMBINE")) == 0);
-    if (combine && (w0 == 64 || w0 == 128 || w0 == 256)) {
-        const dim3 grid((unsigned)((maxn + 47) / 48), count);
+    static const bool combine = seqrec_env("SEQREC_SCATTER_COMBINE", 1) != 0;
+    if (combine && (w0 == 64 || w0 == 128 || (w0 > 0 && w0 % 256 == 0 && w0 <= 2048))) {
+        const dim3 grid((unsigned)((maxn + 47) / 48), count, w0 > 256 ? w0 / 256 : 1);
         if (w0 == 64) hipLaunchKernelGGL(rows_scatter_combine_kernel<1>, grid, dim3(768), 0, as_stream(stream), m);
         else if (w0 == 128) hipLaunchKernelGGL(rows_scatter_combine_kernel<2>, grid, dim3(768), 0, as_stream(stream), m);
         else hipLaunchKernelGGL(rows_scatter_combine_kernel<4>, grid, dim3(768), 0, as_stream(stream), m);

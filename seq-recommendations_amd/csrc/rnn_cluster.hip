@@ -343,7 +343,7 @@ int get_flagbuf(hipStream_t st, int T, FlagBuf& out) {
 }
 
 bool cluster_enabled() {
-    static const bool on = !(getenv("SEQREC_SCAN_CLUSTER") && atoi(getenv("SEQREC_SCAN_CLUSTER")) == 0);      // A/B switch
+    static const bool on = seqrec_env("SEQREC_SCAN_CLUSTER", 1) != 0;      // A/B switch
     return g_cluster_override >= 0 ? g_cluster_override != 0 : on;
 }
 int cluster_spin_limit() { return g_spin_override > 0 ? g_spin_override : CL_SPIN_LIMIT; }

@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256) void gemm_bwd_step(StepArgs a_in, int H, int l
 }
 
 bool xcd_placement() {
-    static const bool on = !(getenv("SEQREC_SCAN_XCD") && atoi(getenv("SEQREC_SCAN_XCD")) == 0);   // A/B switch
+    static const bool on = seqrec_env("SEQREC_SCAN_XCD", 1) != 0;   // A/B switch
     return on;
 }
 // grid = (row blocks, column blocks) -> the 1-D placement grid of tile_of()
@@ -1189,7 +1189,7 @@ static int rnn_bwd_stepwise_impl(int cell, int act, int H, int H_real, int T, in
         if (cell == SEQREC_CELL_GRU && t == 0) {
             plan_gru_first(pl, act, true, a);                      // no recurrent product at step 0
         } else if (cell == SEQREC_CELL_GRU) {
-            static const int wide_rb = getenv("SEQREC_SCAN_WIDE_RB") ? atoi(getenv("SEQREC_SCAN_WIDE_RB")) : 9;   // A/B switch (0 = never)
+            static const int wide_rb = (int)seqrec_env("SEQREC_SCAN_WIDE_RB", 9);   // A/B switch (0 = never)
             if (wide_rb > 0 && (int)rb >= wide_rb && H >= 128) {
                 a.pk = upack + 6 * HH;
                 CELL_DISPATCH(gru_step_bwd0_wide, dim3(rb, H / 64));

@@ -302,6 +302,8 @@ class Engine:
         # the scan's ~135 dependent launches per step ride a captured hipGraph whose nodes are rewritten with every batch's
         # exact geometry (csrc/rnn_step.hip issue_graph); SEQREC_SCAN_GRAPH=0 issues them eagerly
         self.use_graph = self.stepwise and os.environ.get("SEQREC_SCAN_GRAPH", "1") != "0"
+        if os.environ.get("SEQREC_SCAN_CLUSTER") == "0":        # developer switch: the library itself reads no environment variable
+            _lib.load().seqrec_debug_scan_cluster(0)
         self.sampler = None       # (thresh uint32-as-int32 tensor, alias int32 tensor, logq float tensor)
         self.step_count = 0
         # conditions only the device sees (SEQREC_STATUS_*: a gradient norm that is not finite, a clip scale of 0, an index

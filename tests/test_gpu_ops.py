@@ -395,11 +395,11 @@ def test_index_affine_and_filler_rows():
         assert torch.all(gt == 0) and torch.all(slot == 2 ** 31 - 1)
 
 
-@pytest.mark.parametrize("W", [64, 128, 256, 192])
+@pytest.mark.parametrize("W", [64, 128, 256, 192, 512, 768])
 def test_scatter_add_multi_with_hot_rows(W):
     """seqrec_rows_scatter_add_multi on Zipf-like rows (one row takes a tenth of the contributions, as the most popular
     item of a c3 batch does): widths 64 / 128 / 256 take the form that combines a workgroup's contributions per row in
-    LDS before the atomics, 192 the plain form; two lists share one table (bases 0 and n1), the first has row scales, a
+    LDS before the atomics, multiples of 256 (c4: 512) the same in 256-wide column blocks, 192 the plain form; two lists share one table (bases 0 and n1), the first has row scales, a
     wider value stride and filler rows.  Gradient table against a float64 sum, owner slots exactly."""
     rng = np.random.default_rng(77 + W)
     V, n1, n2, ldv = 3000, 2501, 1999, W + 8
@@ -431,7 +431,7 @@ def test_scatter_add_multi_with_hot_rows(W):
     np.testing.assert_array_equal(slot.cpu().numpy().astype(np.int64), sref)
 
 
-@pytest.mark.parametrize("W", [256, 192])
+@pytest.mark.parametrize("W", [256, 192, 512])
 def test_gemm_slabs_feed_the_scatter_like_the_reduced_product(W):
     """seqrec_gemm_f32_slabs leaves the split-K partial products in the workspace; a scatter list with n_slabs / slab_stride
     adds them per row in slab order.  Slabs summed in that order == the product seqrec_gemm_f32 writes with the same split

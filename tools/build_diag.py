@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Diagnostic builds of the library (developer tool): python tools/build_diag.py stamp|spins -> tools/diag/libseqrec_cl<kind>.so
+"""Diagnostic builds of the library (developer tool): python tools/build_diag.py stamp|spins|tunables -> tools/diag/libseqrec_cl<kind>.so
 (tools/diag/ is git-ignored but travels to the GPU box; select with SEQREC_LIB=...)."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 kind = sys.argv[1] if len(sys.argv) > 1 else "stamp"
-flag = {"stamp": "-DSEQREC_CLUSTER_STAMP", "spins": "-DSEQREC_CLUSTER_SPINS"}[kind]
+flag = {"stamp": "-DSEQREC_CLUSTER_STAMP", "spins": "-DSEQREC_CLUSTER_SPINS", "tunables": "-DSEQREC_TUNABLES"}[kind]      # tunables: the env switches of the A/B scripts
 src = ["gemm.hip", "ops.hip", "rnn.hip", "rnn_step.hip", "rnn_cluster.hip", "rnn_cluster2.hip", "merge.hip", "exchange.hip", "route.hip"]
 os.makedirs(os.path.join(ROOT, "tools", "diag"), exist_ok=True)
 out = os.path.join(ROOT, "tools", "diag", "libseqrec_cl%s.so" % kind)

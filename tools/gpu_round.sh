@@ -34,6 +34,9 @@ import json; d=json.loads(open('$out/bench_$c.log').read().strip().splitlines()[
 import json; d=json.loads(open('$out/bench_sorted.log').read().strip().splitlines()[-1]); print('sorted', d['value'], d['ms_per_step'], [(k,v['avg_us']) for k,v in d['kernels'].items() if 'merge' in k or 'scatter' in k or 'sqnorm' in k])"
    TMO=400 run bench_sat python bench.py --saturated --steps 40 --warmup 5 --cpu-seconds 0 --recall-steps 0 --train-sessions 40000; python -c "
 import json; d=json.loads(open('$out/bench_sat.log').read().strip().splitlines()[-1]); print('saturated', d['value'], d['ms_per_step'], d['tokens_per_s'], [(k[7:],v.get('frac')) for k,v in d['kernels'].items() if v.get('frac')])";;
+arb) for c in c4 c5 c3; do TMO=700 run bench_arb_$c python bench.py --config $c --steps 20 --warmup 5 --arbiter on; python -c "
+import json; d=json.loads(open('$out/bench_arb_$c.log').read().strip().splitlines()[-1]); p=d['parity']; print('$c', d['value'], p['ok'], p.get('ok_reason'), p['rel_diff_per_step'], p.get('vs_fp64'), {k: p['resync'][k] for k in ('loss_rel_gpu','loss_rel_cpu32','clip_scale_rel_gpu','tokens_ce_clipped','ok','why_not')}); print({k: {f: u[f] for f in ('gpu_l2','cpu32_l2','gpu_flips','cpu32_flips','gpu_l2_rest','cpu32_l2_rest')} for k, u in p['resync']['update'].items()}); print(d.get('notes'))"; done;;
+launch2) SEQREC_BENCH_BACKEND=gloo-staged TMO=400 run bench_launch2 python bench.py --gpus 2 --steps 10 --warmup 3 --config c2 --recall-steps 0 --train-sessions 20000 --test-sessions 2000; tail -c 700 $out/bench_launch2.log; tail -5 $out/bench_launch2.err;;
 dbgtopk) TMO=300 run dbgtopk python tools/debug_topk.py c5; cat $out/dbgtopk.log;;
 trace) root=$PWD; cd /tmp; export TMPDIR=/tmp
    timeout -k 10 300 rocprofv3 --hip-trace --kernel-trace --output-format csv -d $root/$out/trace -- python3 $root/tools/stall_probe.py 8 > $root/$out/trace.log 2>&1; echo "trace rc=$?"
