@@ -72,6 +72,7 @@ extern "C" {
  *    seqrec_cluster_scan_errors_reset, seqrec_debug_cluster_spin_limit, seqrec_exchange_pack / _unpack / _grad_pack,
  *    seqrec_sampled_softmax_ce_rows_idx, seqrec_route_*_host; the packed layout of the step-wise LSTM forward
  *    kernel changed (seqrec_rnn_pack_u_stepwise and the scans of one library always agree) */
+/* 5: seqrec_exchange_unpack bounds the ids it reads (logq_rows, status); new entry point seqrec_train_cell */
 #define SEQREC_ABI_VERSION 5
 
 enum { SEQREC_OK = 0, SEQREC_E_ARG = -1, SEQREC_E_SHAPE = -2, SEQREC_E_UNSUPPORTED = -3 };
@@ -300,6 +301,51 @@ int seqrec_fill_i32(int32_t* x, int32_t v, int64_t n, void* stream);
  *      buffers bit-exactly (no float arithmetic ever touches them). */
 int seqrec_index_affine_i32(int32_t* dst, const int32_t* dst_pos, const int32_t* src, const int32_t* src_pos,
                             int64_t n, int32_t mul, int32_t add, void* stream);
+
+/* ---- the cell of a sampled-softmax training step as ONE host call (ABI 5; step.hip).  What Keras' train_function does between
+ *      the embedding lookup and the optimizer (model.py:179-182 -> Model.fit -> train_function) is a fixed
+ *      sequence of the entry points above; issued one by one from Python it costs more host time than the GPU needs to run
+ *      it once collectives share the step (distributed.py: 0.6 ms of host time for a 0.53 ms step).  seqrec_train_cell issues
+ *      the SAME launches with the SAME arguments from one call -- results are bit-identical to the call-by-call sequence,
+ *      which stays the specification (engine.Engine.train_step) and the form the per-kernel profile times.
+ *      stages (bit mask):
+ *        1 forward   [pack_u: seqrec_rnn_pack_u_stepwise, or with sample != 0 seqrec_rnn_pack_u_sample]  ->
+ *                    XW = x . W + bias with the rows of x read through x_index (seqrec_gemm_f32_fused)  ->  seqrec_rnn_fwd_stepwise  ->
+ *                    ln = Hout . Eneg^T  ->  seqrec_sampled_softmax_ce (logq_table / tgt_table by item id; lq_tgt NULL) or
+ *                    seqrec_sampled_softmax_ce_rows_idx (target rows through tgt_index, lq_tgt per token)
+ *        2 backward  dHd = dln . Eneg + dlt * tgt rows (seqrec_gemm_f32_fused, sk_dh splits)  ->  [deneg_mode 1: dEneg slabs]  ->
+ *                    seqrec_rnn_bwd_stepwise  ->  the weight gradients dU (GRU: two column blocks), dW, db [, deneg_mode 2: dEneg] in one
+ *                    grouped launch: wgrad_slabs != 0 leaves split-K slabs (seqrec_gemm_f32_grouped_slabs; descs_out / ns_wgrad
+ *                    are what seqrec_opt_sqnorm_slabs needs), else reduced into dU / dW / db
+ *        4 dX        dX = dPre . W^T as sk_dx split-K slabs (seqrec_gemm_f32_slabs) for the row scatter / the gradient routing
+ *      All pointers are device pointers unless marked host; every workspace is the caller's.  Outputs ns_* / deneg_off /
+ *      n_descs are written into the (host) plan. */
+typedef struct seqrec_cell_plan {
+    int32_t stages, cell, act, Hp, H_real, G, K, Dp, T, B, use_graph, reserved0_;
+    int64_t n;
+    const int32_t* step_off_host;                      /* host, T + 1 entries */
+    /* prologue */
+    int32_t pack_u, sample; uint64_t seed, step;
+    const float* U; float* upack;
+    const uint32_t* thresh; const int32_t* alias; int32_t V, reserved1_; const float* sample_table; const float* sample_logq;
+    int32_t* neg_out; float* Eneg_out; float* lq_neg_out;
+    /* input projection */
+    const float* x_table; int64_t x_ld; const int32_t* x_index; const float* W; const float* bias;
+    float *XW, *Hout, *gates, *aux;
+    /* output side */
+    const float* Eneg; const int32_t* neg; const float* lq_neg;
+    float *ln, *dlt, *loss_rows; float inv_denom; int32_t reserved2_;
+    const float* tgt_table; int64_t tgt_ld; const int32_t* tgt_index; const int32_t* tgt_ids; const float* lq_tgt; const float* logq_table;
+    /* backward */
+    float* dHd; float* gemm_ws; int32_t sk_dh, deneg_mode, sk_deneg, sk_wgrad, wgrad_slabs, sk_dx;
+    float* dEneg_slabs; float* dPre; float* scan_ws; const int32_t* prev;
+    float *dU, *dW, *db; const float* ones; float* wgrad_ws; float* dX_slabs;
+    /* outputs (host) */
+    int32_t ns_deneg, ns_wgrad, ns_dx, n_descs; int64_t deneg_off;
+    seqrec_gemm_desc descs_out[6];
+} seqrec_cell_plan;
+int seqrec_train_cell(seqrec_cell_plan* plan_host, void* stream);
+int64_t seqrec_cell_plan_bytes(void);          /* sizeof(seqrec_cell_plan): bindings check their struct layout against it */
 
 /* ---- row exchange of the multi-GPU step (distributed.py; SURVEY 8e: tables row-sharded, rows moved by all-to-all; no
  *      reference counterpart).  One launch on each side of the step's two collectives:

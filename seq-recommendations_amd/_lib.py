@@ -71,6 +71,8 @@ _SIGS = {
     "seqrec_sampled_softmax_ce_rows_idx": [P, L, P, I, P, L, P, P, P, P, P, L, I, F, P, P, P],
     "seqrec_exchange_pack": [P, L, I, P, L, U64, U64, I, P, P, I, I, P, P, I, I, I, I, P, P, P, P],
     "seqrec_exchange_unpack": [P, I, P, P, I, P, L, P, P, P, P, P],
+    "seqrec_train_cell": [P, P],
+    "seqrec_cell_plan_bytes": [],
     "seqrec_exchange_grad_pack": [P, L, I, I, I, P, I, L, P, P, P, I, L, P, P],
     "seqrec_route_count_host": [P, P, L, I, P],
     "seqrec_route_fill_host": [P, P, L, I, L, I, P, P, P, P],
@@ -124,6 +126,7 @@ _RESTYPES = {
     "seqrec_rows_merge_workspace_bytes": L,
     "seqrec_opt_sqnorm_ordered_floats": L,
     "seqrec_route_blob_host": L,
+    "seqrec_cell_plan_bytes": L,
 }
 EXPORTS = sorted(_SIGS)
 
@@ -167,6 +170,27 @@ def gemm_descs(items):
         arr[i].C, arr[i].ldc, arr[i].bias, arr[i].accumulate = Cm.data_ptr(), int(ldc), None, 0
         arr[i].a_index = it[9].data_ptr() if len(it) > 9 and it[9] is not None else None
     return arr
+
+
+class CellPlan(C.Structure):
+    """seqrec_cell_plan (include/seqrec_hip.h): the arguments of seqrec_train_cell."""
+    _fields_ = [("stages", C.c_int32), ("cell", C.c_int32), ("act", C.c_int32), ("Hp", C.c_int32), ("H_real", C.c_int32), ("G", C.c_int32),
+                ("K", C.c_int32), ("Dp", C.c_int32), ("T", C.c_int32), ("B", C.c_int32), ("use_graph", C.c_int32), ("reserved0_", C.c_int32),
+                ("n", L), ("step_off_host", P),
+                ("pack_u", C.c_int32), ("sample", C.c_int32), ("seed", U64), ("step", U64),
+                ("U", P), ("upack", P), ("thresh", P), ("alias", P), ("V", C.c_int32), ("reserved1_", C.c_int32), ("sample_table", P),
+                ("sample_logq", P), ("neg_out", P), ("Eneg_out", P), ("lq_neg_out", P),
+                ("x_table", P), ("x_ld", L), ("x_index", P), ("W", P), ("bias", P),
+                ("XW", P), ("Hout", P), ("gates", P), ("aux", P),
+                ("Eneg", P), ("neg", P), ("lq_neg", P),
+                ("ln", P), ("dlt", P), ("loss_rows", P), ("inv_denom", F), ("reserved2_", C.c_int32),
+                ("tgt_table", P), ("tgt_ld", L), ("tgt_index", P), ("tgt_ids", P), ("lq_tgt", P), ("logq_table", P),
+                ("dHd", P), ("gemm_ws", P), ("sk_dh", C.c_int32), ("deneg_mode", C.c_int32), ("sk_deneg", C.c_int32), ("sk_wgrad", C.c_int32),
+                ("wgrad_slabs", C.c_int32), ("sk_dx", C.c_int32),
+                ("dEneg_slabs", P), ("dPre", P), ("scan_ws", P), ("prev", P),
+                ("dU", P), ("dW", P), ("db", P), ("ones", P), ("wgrad_ws", P), ("dX_slabs", P),
+                ("ns_deneg", C.c_int32), ("ns_wgrad", C.c_int32), ("ns_dx", C.c_int32), ("n_descs", C.c_int32), ("deneg_off", L),
+                ("descs_out", GemmDesc * 6)]
 
 
 class GemmFuse(C.Structure):
@@ -236,6 +260,8 @@ def load():
     if lib.seqrec_abi_version() != ABI_VERSION:      # struct layouts below are those of this version (seqrec_rows_job grew in 3)
         raise SeqrecError("%s has ABI version %d, this binding needs %d: rebuild it (__graft_entry__.build())"
                           % (LIB_PATH, lib.seqrec_abi_version(), ABI_VERSION))
+    if lib.seqrec_cell_plan_bytes() != C.sizeof(CellPlan):
+        raise SeqrecError("seqrec_cell_plan is %d bytes in %s and %d in this binding" % (lib.seqrec_cell_plan_bytes(), LIB_PATH, C.sizeof(CellPlan)))
     _lib = lib
     return lib
 

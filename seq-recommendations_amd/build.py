@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libseqrec_hip.so")
-SOURCES = ["gemm.hip", "ops.hip", "rnn.hip", "rnn_step.hip", "rnn_cluster.hip", "rnn_cluster2.hip", "merge.hip", "exchange.hip", "route.hip"]
+SOURCES = ["gemm.hip", "ops.hip", "rnn.hip", "rnn_step.hip", "rnn_cluster.hip", "rnn_cluster2.hip", "merge.hip", "exchange.hip", "route.hip", "step.hip"]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
 
 

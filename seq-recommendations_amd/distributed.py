@@ -714,6 +714,10 @@ class ShardedEngine(Engine):
         c, P, Gd = self.cfg, self.P, self.Gd
         st = self._stream()
         n, Hp, GHp, Dp, K, w = d["n"], self.Hp, self.GHp, self.Dp, c.K, self.Hp
+        from . import engine as _eng
+        if (train and self.native_cell and _eng._PROF is None and c.use_bias and c.drop_in == 0 and c.drop_out == 0 and c.drop_rec == 0
+                and all(self.trainable.values()) and Dp % 4 == 0):
+            return self._cell_unified_native(d, recv, Eneg, neg, lq_neg, reduce_dense)
         drops = self._drop_masks(d, step) if train else {}
         XW = self.buf("XW", n, GHp)
         xidx = d["take_in"]
@@ -793,6 +797,60 @@ class ShardedEngine(Engine):
             sk_x = self._splitk_tiles(((n + 63) // 64) * ((Dp + 63) // 64), GHp, min_k=self._slab_min_k, fill=True)
             r["dX"] = self.gemm_slabs(1, 1, n, Dp, GHp, dPre, GHp, P["W"], GHp, "dX_slabs", sk_x, tag="dX")
         return r
+
+    def _cell_unified_native(self, d, recv, Eneg, neg, lq_neg, reduce_dense):
+        """_cell_unified (training, no dropout) with its launches issued by seqrec_train_cell: stages 1 + 2 (forward ... weight
+        gradients) in one call, the dense all-reduce started from here, stage 4 (dX slabs) in a second call.  Same launches, same
+        arguments, same buffers as the call-by-call sequence above."""
+        import ctypes
+        from .engine import _raw_call
+        from ._lib import CELL, ACT
+        c, P, Gd = self.cfg, self.P, self.Gd
+        n, Hp, GHp, Dp, K, w = d["n"], self.Hp, self.GHp, self.Dp, c.K, self.Hp
+        st = self._cur_st
+        pl = self._plan
+        if pl is None:
+            pl = self._plan = _lib.CellPlan()
+            pl.cell, pl.act, pl.Hp, pl.H_real, pl.G, pl.K, pl.Dp = CELL[c.cell], ACT[c.act], Hp, c.H, self.G, K, Dp
+            pl.U, pl.upack, pl.W, pl.bias = ptr(P["U"]), ptr(self.upack), ptr(P["W"]), ptr(P["b"])
+            pl.dU, pl.dW, pl.db = ptr(Gd["U"]), ptr(Gd["W"]), ptr(Gd["b"])
+            pl.inv_denom, pl.deneg_mode, pl.wgrad_slabs, pl.sample = 1.0, 1, 0, 0
+        XW, Hout, gates, aux = self.buf("XW", n, GHp), self.buf("Hout", n, Hp), self.buf("gates", n, GHp), self.buf("aux", n, Hp)
+        ln, dlt, lrows = self.buf("ln", n, K), self.buf("dlt", n), self.buf("loss_rows", n)
+        dHd, dPre = self.buf("dHd", n, Hp), self.buf("dPre", n, GHp)
+        scan_ws = self.buf("scan_ws", 2 * n * Hp)
+        shapes = ([(Hp, 2 * Hp), (Hp, Hp)] if c.cell == "gru" else [(Hp, GHp)]) + [(Dp, GHp), (1, GHp)]
+        tiles = sum(((a + 63) // 64) * ((b + 63) // 64) for a, b in shapes)
+        sk_w = self._splitk_tiles(tiles, n, fill=True)
+        sk_h = self._splitk(n, Hp, K, fill=True)
+        sk_e = self._splitk(K, Hp, n)
+        sk_x = self._splitk_tiles(((n + 63) // 64) * ((Dp + 63) // 64), GHp, min_k=self._slab_min_k, fill=True)
+        wsp = self.buf("gemm_ws", max(sk_w * sum(a * b for a, b in shapes) if sk_w > 1 else 1, sk_h * n * Hp, 1))
+        dEs = self.buf("dEneg_slabs", max(sk_e, 1) * K * Hp)
+        dXs = self.buf("dX_slabs", max(sk_x, 1) * n * Dp)
+        pl.stages, pl.n, pl.T, pl.B, pl.use_graph = 3, n, d["T"], d["B"], int(self.use_graph)
+        pl.step_off_host = d["rb"].step_off.ctypes.data
+        pl.pack_u = int(self.upack_dirty)
+        self.upack_dirty = False
+        pl.x_table, pl.x_ld, pl.x_index = ptr(recv), w, ptr(d["take_in"])
+        pl.XW, pl.Hout, pl.gates, pl.aux = ptr(XW), ptr(Hout), ptr(gates), ptr(aux)
+        pl.Eneg, pl.neg, pl.lq_neg = ptr(Eneg), ptr(neg), ptr(lq_neg)
+        pl.ln, pl.dlt, pl.loss_rows = ptr(ln), ptr(dlt), ptr(lrows)
+        pl.tgt_table, pl.tgt_ld, pl.tgt_index, pl.tgt_ids, pl.lq_tgt = ptr(recv), w, ptr(d["take_tgt"]), ptr(d["tgt"]), ptr(d.get("lq_tgt"))
+        pl.logq_table = None
+        pl.dHd, pl.gemm_ws, pl.sk_dh, pl.sk_deneg, pl.dEneg_slabs = ptr(dHd), ptr(wsp), sk_h, sk_e, ptr(dEs)
+        pl.sk_wgrad, pl.wgrad_ws = sk_w, ptr(wsp)
+        pl.dPre, pl.scan_ws, pl.prev, pl.ones = ptr(dPre), ptr(scan_ws), ptr(d["prev"]), ptr(self._ones(n))
+        pl.sk_dx, pl.dX_slabs = sk_x, ptr(dXs)
+        _raw_call("seqrec_train_cell", ctypes.addressof(pl), st)
+        if reduce_dense:
+            self._start_dense_allreduce()        # the dense gradients are final: reduce them under everything that follows
+        pl.stages = 4
+        _raw_call("seqrec_train_cell", ctypes.addressof(pl), st)
+        self.last_slabs["dEneg_slabs"] = (dEs, int(pl.ns_deneg), K, Hp)
+        self.last_slabs["dX_slabs"] = (dXs, int(pl.ns_dx), n, Dp)
+        return {"Hd": Hout, "dlt": dlt, "loss_rows": lrows, "Hout": Hout, "dEneg": (dEs, int(pl.ns_deneg), K * Hp),
+                "dX": (dXs, int(pl.ns_dx), n * Dp)}
 
     def _start_dense_allreduce(self):
         """Unified path: the dense all-reduce AND the dense gradient norm run on the side stream (its own communicator under

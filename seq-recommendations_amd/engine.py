@@ -311,6 +311,9 @@ class Engine:
         self.status = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.pinned = PinnedRing(self.dev)
         self.drop_seed = cfg.seed       # RNG stream of the dropout masks (distributed.ShardedEngine: one per rank)
+        # the cell of the common training step in ONE C-ABI call (seqrec_train_cell); SEQREC_NATIVE_CELL=0: call by call
+        self.native_cell = _os.environ.get("SEQREC_NATIVE_CELL", "1") != "0"
+        self._plan, self._plan_gen, self._plan_keep = None, None, None
 
     # ------------------------------------------------------------------ device-side failures
     def check_status(self):
@@ -620,6 +623,7 @@ class Engine:
         al = torch.from_numpy(np.asarray(alias, dtype=np.int32).copy()).to(self.dev)
         lq = None if logq is None else torch.from_numpy(np.asarray(logq, dtype=np.float32).copy()).to(self.dev)
         self.sampler = (th, al, lq)
+        self._plan = None
 
     def set_prior(self, name, means, strength):
         """Kernel regularizer strength * sum (w - means)^2 on parameter `name` (must be listed in
@@ -954,6 +958,8 @@ class Engine:
             return torch.zeros(1, device=self.dev)
         st = self._stream()
         Hp, GHp = self.Hp, self.GHp
+        if self._native_cell_ok(negatives, apply_update):
+            return self._train_step_native(d, lr, eps, clipnorm, step)
         # the batch loss is reduced by a spare workgroup of the gradient-norm launch (defer_loss) when that launch runs
         r = self.forward(d, train=True, step=step, negatives=negatives, defer_loss=apply_update)
         drops = r["drops"]
@@ -1149,12 +1155,20 @@ class Engine:
             t_, rows_, dln_, Hd_, K_ = deneg_late
             dEn, ns_neg, ss_neg = self.gemm_slabs(0, 0, K_, Hp, n, dln_, K_, Hd_, Hp, "dEneg_slabs", self._splitk(K_, Hp, n), tag="dEneg")
             sparse_jobs[deneg_at] = self._job(t_, rows_, dEn, Hp, None, K_, Hp, n, ns_neg, ss_neg)
+        if join_side:
+            torch.cuda.current_stream(self.dev).wait_event(self._ev_join)
+        return self._finish_step(d, sparse_jobs, wg_slabs, wcover, lrows, lr, eps, clipnorm, apply_update)
+
+    def _finish_step(self, d, sparse_jobs, wg_slabs, wcover, lrows, lr, eps, clipnorm, apply_update):
+        """Behind the cell: row scatter, global-norm clip, Adagrad (train_step and its one-call form _train_step_native)."""
+        c, P = self.cfg, self.P
+        Gd, tr = self.Gd, self.trainable
+        n = d["n"]
+        st = self._stream()
         self.last_counts = {"wgrad": wg_slabs[2] if wg_slabs is not None else 1}      # split-K slab counts of this step (bench.py's byte models)
         for j in sparse_jobs:
             if j.get("n_slabs", 0) > 1:
                 self.last_counts["dX" if j["name"] == "E" and j["rows"] is d.get("ids") else "dEneg"] = j["n_slabs"]
-        if join_side:
-            torch.cuda.current_stream(self.dev).wait_event(self._ev_join)
         # ---- row-sparse contributions: one launch for (up to 4) scatter lists
         groups = [sparse_jobs[i:i + 4] for i in range(0, len(sparse_jobs), 4)]
         packed = [_lib.rows_jobs(g) for g in groups]
@@ -1232,6 +1246,118 @@ class Engine:
         if self.priors:
             return self.loss_mean + self.reg_sum
         return self.loss_mean            # a VIEW of the engine's loss slot: read or consume it before the next step is enqueued
+
+    # ------------------------------------------------------------------ the cell in ONE host call (seqrec_train_cell)
+    def _native_cell_ok(self, negatives, apply_update):
+        """The step shapes seqrec_train_cell covers: embedding input, sampled softmax over the engine's own negatives, every tensor
+        trainable, no dropout / bias table / regularizer, atomic merge, the default slab forms.  Everything else -- and the per-kernel
+        profile of bench.py, which times call by call -- takes the call-by-call sequence below, which is the specification."""
+        c = self.cfg
+        return (self.native_cell and _PROF is None and apply_update and negatives is None and c.input == "embed" and c.output == "sampled"
+                and self.stepwise and self.sampler is not None and c.merge == "atomic" and not self.priors and not c.out_bias
+                and c.drop_in == 0 and c.drop_out == 0 and c.drop_rec == 0 and all(self.trainable.values()) and c.use_bias
+                and self._slab_scatter and self._slab_wgrad and not self._slab_dh and not self._overlap and self._fuse_prologue
+                and self.Dp % 4 == 0)
+
+    def _cell_plan(self):
+        """The persistent argument block of seqrec_train_cell: everything that does not change from step to step is written once
+        (the parameter tensors never move; set_sampler drops the block)."""
+        c, P = self.cfg, self.P
+        pl = self._plan
+        if pl is not None:
+            return pl
+        pl = _lib.CellPlan()
+        pl.cell, pl.act, pl.Hp, pl.H_real, pl.G, pl.K, pl.Dp = CELL[c.cell], ACT[c.act], self.Hp, c.H, self.G, c.K, self.Dp
+        pl.seed = int(c.seed)
+        pl.U, pl.upack = ptr(P["U"]), ptr(self.upack)
+        th, al, lq = self.sampler
+        Et = P["E"] if c.tied else P["Eout"]
+        pl.thresh, pl.alias, pl.V, pl.sample_table = ptr(th), ptr(al), c.V_out, ptr(Et)
+        pl.sample_logq = ptr(lq if c.logq else None)
+        self._plan_keep = (th, al, lq)
+        self._plan = pl
+        return pl
+
+    def _train_step_native(self, d, lr, eps, clipnorm, step):
+        """train_step for the shapes of _native_cell_ok with the cell issued by ONE C-ABI call: the same launches with the same
+        arguments as the sequence in train_step (bit-identical buffers; tests/test_gpu_engine.py), ~12 ctypes calls and their Python
+        glue less per step."""
+        import ctypes
+        c, P, Gd = self.cfg, self.P, self.Gd
+        n, T, B = d["n"], d["T"], d["B"]
+        Hp, GHp, Dp, K = self.Hp, self.GHp, self.Dp, c.K
+        st = self._cur_st
+        tname = "E" if c.tied else "Eout"
+        Et = P[tname]
+        th, al, lq = self.sampler
+        neg = self.buf("neg", K, dtype=torch.int32)
+        Eneg = self.buf("Eneg", K, Hp)
+        lq_neg = self.buf("lq_neg", K) if c.logq else None
+        XW, Hout, gates, aux = self.buf("XW", n, GHp), self.buf("Hout", n, Hp), self.buf("gates", n, GHp), self.buf("aux", n, Hp)
+        ln, dlt, lrows = self.buf("ln", n, K), self.buf("dlt", n), self.buf("loss_rows", n)
+        dHd, dPre = self.buf("dHd", n, Hp), self.buf("dPre", n, GHp)
+        scan_ws = self.buf("scan_ws", 2 * n * Hp)
+        pl = self._cell_plan()
+        pl.stages, pl.n, pl.T, pl.B, pl.use_graph = 7, n, T, B, int(self.use_graph)
+        so = d["rb"].step_off
+        pl.step_off_host = so.ctypes.data
+        pl.step = int(step)
+        if self.upack_dirty:
+            pl.pack_u, pl.sample = 1, 1
+            self.upack_dirty = False
+        else:                                   # U frozen since the last pack: the negatives on their own
+            pl.pack_u = pl.sample = 0
+            call("seqrec_sample_gather", int(c.seed), int(step), K, ptr(th), ptr(al), c.V_out, ptr(Et), Hp, ptr(lq if c.logq else None),
+                 ptr(neg), ptr(Eneg), ptr(lq_neg), st)
+        pl.neg_out, pl.Eneg_out, pl.lq_neg_out = ptr(neg), ptr(Eneg), ptr(lq_neg)
+        pl.x_table, pl.x_ld, pl.x_index, pl.W, pl.bias = ptr(P["E"]), Dp, ptr(d["ids"]), ptr(P["W"]), ptr(P["b"])
+        pl.XW, pl.Hout, pl.gates, pl.aux = ptr(XW), ptr(Hout), ptr(gates), ptr(aux)
+        pl.Eneg, pl.neg, pl.lq_neg = ptr(Eneg), ptr(neg), ptr(lq_neg)
+        pl.ln, pl.dlt, pl.loss_rows, pl.inv_denom = ptr(ln), ptr(dlt), ptr(lrows), 1.0 / n
+        pl.tgt_table, pl.tgt_ld, pl.tgt_index, pl.tgt_ids, pl.lq_tgt = ptr(Et), Hp, ptr(d["tgt"]), ptr(d["tgt"]), None
+        pl.logq_table = ptr(lq if c.logq else None)
+        # split policy: exactly train_step's
+        sk_h = self._splitk(n, Hp, K, fill=True)
+        shapes = [(Hp, 2 * Hp), (Hp, Hp)] if c.cell == "gru" else [(Hp, GHp)]
+        shapes += [(Dp, GHp), (1, GHp)]
+        tiles = sum(((a + 63) // 64) * ((b + 63) // 64) for a, b in shapes)
+        sk_w = self._splitk_tiles(tiles, n, fill=SPLITK_FILL_WGRAD)
+        ride = (self._group_deneg and n <= 4096 and len(shapes) < 6
+                and ((K + 63) // 64) * ((Hp + 63) // 64) + ((Dp + 63) // 64 + (Hp + 63) // 64 + 1) * ((GHp + 63) // 64) <= 512)
+        if ride:
+            tiles_all = tiles + ((K + 63) // 64) * ((Hp + 63) // 64)
+            sk_w = max(sk_w, int(max(1, min(1024 // max(tiles_all, 1), n // SPLITK_MIN_K))))
+        slabs_w = sk_w > 1 or ride
+        wsz = sum(sk_w * a * b for a, b in shapes) + (sk_w * K * Hp if ride else 0)
+        sk_e = self._splitk(K, Hp, n)
+        wsp = self.buf("gemm_ws", max(wsz, sk_h * n * Hp, 1))
+        dEs = None if ride else self.buf("dEneg_slabs", max(sk_e, 1) * K * Hp)
+        sk_x = self._splitk_tiles(((n + 63) // 64) * ((Dp + 63) // 64), GHp, min_k=self._slab_min_k, fill=True)
+        dXs = self.buf("dX_slabs", max(sk_x, 1) * n * Dp)
+        pl.dHd, pl.gemm_ws, pl.sk_dh = ptr(dHd), ptr(wsp), sk_h
+        pl.deneg_mode, pl.sk_deneg, pl.dEneg_slabs = (2 if ride else 1), sk_e, ptr(dEs)
+        pl.sk_wgrad, pl.wgrad_slabs, pl.wgrad_ws = sk_w, int(slabs_w), ptr(wsp)
+        pl.dPre, pl.scan_ws, pl.prev = ptr(dPre), ptr(scan_ws), ptr(d["prev"])
+        pl.dU, pl.dW, pl.db, pl.ones = ptr(Gd["U"]), ptr(Gd["W"]), ptr(Gd["b"]), ptr(self._ones(n))
+        pl.sk_dx, pl.dX_slabs = sk_x, ptr(dXs)
+        _raw_call("seqrec_train_cell", ctypes.addressof(pl), st)
+        # ---- the scatter lists, as train_step builds them
+        jobs = [self._job(tname, d["tgt"], Hout, Hp, dlt, n, Hp, 0)]
+        if ride:
+            nsv, off = int(pl.ns_wgrad), int(pl.deneg_off)
+            view = wsp[off:off + nsv * K * Hp]
+            jobs.append(self._job(tname, neg, view, Hp, None, K, Hp, n, nsv, K * Hp))
+            self.last_slabs["dEneg_slabs"] = (view, nsv, K, Hp)
+        else:
+            jobs.append(self._job(tname, neg, dEs, Hp, None, K, Hp, n, int(pl.ns_deneg), K * Hp))
+            self.last_slabs["dEneg_slabs"] = (dEs, int(pl.ns_deneg), K, Hp)
+        jobs.append(self._job("E", d["ids"], dXs, Dp, None, n, Dp, (n + K) if c.tied else 0, int(pl.ns_dx), n * Dp))
+        self.last_slabs["dX_slabs"] = (dXs, int(pl.ns_dx), n, Dp)
+        wg = wcover = None
+        if slabs_w:
+            wg = (ctypes.addressof(pl.descs_out), int(pl.n_descs), int(pl.ns_wgrad), wsp)
+            wcover = {"U", "W", "b"}
+        return self._finish_step(d, jobs, wg, wcover or set(), lrows, lr, eps, clipnorm, True)
 
     def grads(self, d, step=0, negatives=None):
         """Debug/test hook: loss and UNPADDED gradients of one batch, no update applied.
