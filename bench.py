@@ -976,6 +976,7 @@ def main(argv=None):
                        "routing_window": WINDOW if (sharded and not resident) else None,
                        "routing_host_ms_per_window": ({"pack": round(1e3 * route_host["pack_s"] / max(route_host["windows"], 1), 2),
                                                        "plan": round(1e3 * route_host["plan_s"] / max(route_host["windows"], 1), 2),
+                                                       "sync_wait": round(1e3 * getattr(eng.ex, "sync_wait_s", 0.0) / max(route_host["windows"], 1), 2),
                                                        "windows": route_host["windows"]} if (sharded and not resident) else None),
                        "parallelism": ("dp%d+row-sharded-tables" % world) if sharded else "single"},
             "tokens_per_s": round(tokens_per_s, 1), "final_loss": round(last_loss, 5), "recall_at_20": recall,

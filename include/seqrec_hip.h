@@ -72,7 +72,8 @@ extern "C" {
  *    seqrec_cluster_scan_errors_reset, seqrec_debug_cluster_spin_limit, seqrec_exchange_pack / _unpack / _grad_pack,
  *    seqrec_sampled_softmax_ce_rows_idx, seqrec_route_*_host; the packed layout of the step-wise LSTM forward
  *    kernel changed (seqrec_rnn_pack_u_stepwise and the scans of one library always agree) */
-/* 5: seqrec_exchange_unpack bounds the ids it reads (logq_rows, status); new entry point seqrec_train_cell */
+/* 5: seqrec_exchange_unpack bounds the ids it reads (logq_rows, status); seqrec_exchange_pack takes the received request list;
+ *    seqrec_route_blob_host writes the row kinds itself (no got_sentinel); new entry point seqrec_train_cell */
 #define SEQREC_ABI_VERSION 5
 
 enum { SEQREC_OK = 0, SEQREC_E_ARG = -1, SEQREC_E_SHAPE = -2, SEQREC_E_UNSUPPORTED = -3 };
@@ -350,7 +351,10 @@ int64_t seqrec_cell_plan_bytes(void);          /* sizeof(seqrec_cell_plan): bind
 /* ---- row exchange of the multi-GPU step (distributed.py; SURVEY 8e: tables row-sharded, rows moved by all-to-all; no
  *      reference counterpart).  One launch on each side of the step's two collectives:
  *      exchange_pack (owner, before all-to-all #1): sendbuf[j,:] for the m_tot owner-side rows -- kinds[j] >= 0: table row
- *        kinds[j] (>= table_rows: zero row + SEQREC_STATUS_BAD_INDEX); -1: an id row; -2: a negative row.  The rank's n_neg
+ *        kinds[j] (>= table_rows: zero row + SEQREC_STATUS_BAD_INDEX); -1: an id row; -2: a negative row.  got != NULL (ABI 5):
+ *        kinds[j] >= 0 is an index into the request list `got` (got_len entries, received from the peers by all-to-all) and
+ *        the table row is got[kinds[j]] -- the host never touches the received list (no per-batch index arithmetic on the device
+ *        between the planning collective and this launch).  The rank's n_neg
  *        stratified draws (seqrec_sample_negatives(seed, step, n_neg, ...), per_peer per requester) are drawn here: draw i
  *        -> table row row_offset + id, copied to sendbuf[neg_slots[i]]; id row r of peer p (id_rows[p * n_id_rows / R + r])
  *        carries the draws' global ids id * id_mul + id_add bit-cast into the float buffer.  rows_eff[j] (m_tot) receives
@@ -361,8 +365,8 @@ int64_t seqrec_cell_plan_bytes(void);          /* sizeof(seqrec_cell_plan): bind
  *      exchange_grad_pack (requester, before all-to-all #2): out[j,:] for the n_tot requester-side rows, b = back_idx[j]:
  *        b < 0 zero; b < n: sum of the dx_slabs split-K slabs of dX row b; b < 2n: dlt[b-n] * Hd[b-n,:]; else the sum of the
  *        dn_slabs slabs of dEneg row b - 2n (seqrec_gemm_f32_slabs products: no reduce launch, no staging copy). */
-int seqrec_exchange_pack(const float* table, int64_t table_rows, int width, const int32_t* kinds, int64_t m_tot,
-                         uint64_t seed, uint64_t step, int n_neg, const uint32_t* thresh, const int32_t* alias, int V_local,
+int seqrec_exchange_pack(const float* table, int64_t table_rows, int width, const int32_t* kinds, const int32_t* got,
+                         int64_t got_len, int64_t m_tot, uint64_t seed, uint64_t step, int n_neg, const uint32_t* thresh, const int32_t* alias, int V_local,
                          int32_t row_offset, const int32_t* neg_slots, const int32_t* id_rows, int n_id_rows, int per_peer,
                          int32_t id_mul, int32_t id_add, float* sendbuf, int32_t* rows_eff, uint32_t* status, void* stream);
 int seqrec_exchange_unpack(const float* recv, int width, const int32_t* neg_rows, const int32_t* negid_idx, int K,
@@ -382,7 +386,7 @@ int seqrec_route_fill_host(const int32_t* ids_host, const int32_t* tgt_host, int
 int64_t seqrec_route_blob_host(const int32_t* step_off_host, int T, const int32_t* prev_host, const int32_t* ids_host,
                                const int32_t* tgt_host, int64_t n, int R, int Kr, int nid, int w, const int64_t* sc_host,
                                const int64_t* rc_host, const int32_t* req_rank_host, const int64_t* got_off_host,
-                               int64_t got_sentinel, float ntok, const float* lq_tgt_host, int32_t* blob_host, int64_t blob_len);
+                               float ntok, const float* lq_tgt_host, int32_t* blob_host, int64_t blob_len);
 
 /* ---- row-sparse gradient path for the item tables (E, Eout, Wk, bout) -- the exact sparse
  *      equivalent of Keras' dense Adagrad (experiments_methods.py:41): a row with zero gradient is

@@ -30,6 +30,7 @@ __device__ __forceinline__ void copy_row(float* __restrict__ dst, const float* _
 struct PackArgs {
     const float* table; long table_rows; int width;
     const int* kinds; long m_tot;                  // owner-side rows: >= 0 local table row, -1 id row, -2 negative row
+    const int* got; long got_len;                  // non-null: kinds[j] >= 0 is an INDEX into the received request list `got`
     uint64_t key, step; int n_neg, V_local, row_offset;
     const uint32_t* thresh; const int* alias;
     const int* neg_slots;                          // [n_neg] owner-side row of negative i
@@ -40,8 +41,13 @@ __global__ void exchange_pack_kernel(PackArgs a) {
     const int lane = threadIdx.x & 63;
     const long wv = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (wv < a.m_tot) {                            // requested rows
-        const int k = a.kinds[wv];
+        int k = a.kinds[wv];
         if (k == -2) return;
+        if (k >= 0 && a.got) {                     // the row a peer asked for: its local row number arrived by all-to-all
+            if (k < a.got_len) k = a.got[k];
+            else { if (lane == 0 && a.status) atomicOr(a.status, (unsigned)SEQREC_STATUS_BAD_INDEX); k = (int)a.table_rows; }
+            if (k < 0) k = (int)a.table_rows;      // a negative row number from a peer is a bad index too (zero row + status)
+        }
         int r = k;
         if (k >= a.table_rows) { if (lane == 0 && a.status) atomicOr(a.status, (unsigned)SEQREC_STATUS_BAD_INDEX); r = -1; }
         if (k == -1) { if (lane == 0) a.rows_eff[wv] = -1; return; }      // id rows are written whole by their own waves below
@@ -123,20 +129,20 @@ __global__ void exchange_grad_pack_kernel(GradPackArgs a) {
 
 }  // namespace
 
-extern "C" int seqrec_exchange_pack(const float* table, int64_t table_rows, int width, const int32_t* kinds, int64_t m_tot,
-                                    uint64_t seed, uint64_t step, int n_neg, const uint32_t* thresh, const int32_t* alias,
+extern "C" int seqrec_exchange_pack(const float* table, int64_t table_rows, int width, const int32_t* kinds, const int32_t* got,
+                                    int64_t got_len, int64_t m_tot, uint64_t seed, uint64_t step, int n_neg, const uint32_t* thresh, const int32_t* alias,
                                     int V_local, int32_t row_offset, const int32_t* neg_slots, const int32_t* id_rows,
                                     int n_id_rows, int per_peer, int32_t id_mul, int32_t id_add, float* sendbuf,
                                     int32_t* rows_eff, uint32_t* status, void* stream) {
     if (m_tot < 0 || width <= 0 || (width & 3) || n_neg < 0 || n_id_rows < 0 || table_rows <= 0) return SEQREC_E_ARG;
-    if (!table || !kinds || !sendbuf || !rows_eff) return SEQREC_E_ARG;
+    if (!table || !kinds || !sendbuf || !rows_eff || (got && got_len < 0)) return SEQREC_E_ARG;
     if (n_neg > 0 && (!thresh || !alias || !neg_slots || V_local <= 0 || per_peer <= 0 || n_neg % per_peer)) return SEQREC_E_ARG;
     if (n_id_rows > 0 && (!id_rows || n_neg <= 0 || n_id_rows % (n_neg / per_peer))) return SEQREC_E_ARG;
     if ((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(sendbuf)) & 15) return SEQREC_E_ARG;
     const long waves = (long)m_tot + n_neg + n_id_rows;
     if (waves == 0) return 0;
     PackArgs a = {};
-    a.table = table; a.table_rows = (long)table_rows; a.width = width; a.kinds = kinds; a.m_tot = (long)m_tot;
+    a.table = table; a.table_rows = (long)table_rows; a.width = width; a.kinds = kinds; a.m_tot = (long)m_tot; a.got = got; a.got_len = (long)got_len;
     a.key = key64(seed, 1); a.step = step; a.n_neg = n_neg; a.V_local = V_local; a.row_offset = row_offset;
     a.thresh = thresh; a.alias = alias; a.neg_slots = neg_slots; a.id_rows = id_rows; a.n_id_rows = n_id_rows;
     a.per_peer = per_peer; a.id_rows_per_peer = n_neg > 0 ? n_id_rows / (n_neg / per_peer) : 1; a.id_mul = id_mul; a.id_add = id_add;

@@ -45,10 +45,10 @@ extern "C" int seqrec_route_fill_host(const int32_t* ids, const int32_t* tgt, in
 //   step_off[T+1] prev[n] ids[n] tgt[n] neg_slots[R Kr] id_rows[R nid] take_in[n] take_tgt[n] neg_rows[R Kr] negid_idx[R Kr]
 //   back_idx[n_tot] own_src[m_tot] ntok[1] (lq_tgt[n])
 // sc / rc: my requests per peer / the peers' requests to me; extra = Kr + nid rows per peer pair; got_off[i]: where peer i's
-// requests of THIS batch start in the received list; got_sentinel: index of the -1 entry behind that list.
+// requests of THIS batch start in the received list.
 extern "C" int64_t seqrec_route_blob_host(const int32_t* step_off, int T, const int32_t* prev, const int32_t* ids, const int32_t* tgt,
                                           int64_t n, int R, int Kr, int nid, int w, const int64_t* sc, const int64_t* rc,
-                                          const int32_t* req_rank, const int64_t* got_off, int64_t got_sentinel, float ntok,
+                                          const int32_t* req_rank, const int64_t* got_off, float ntok,
                                           const float* lq_tgt, int32_t* blob, int64_t blob_len) {
     if (n < 0 || T < 0 || R < 1 || Kr < 0 || nid < 0 || w < 1 || !sc || !rc || !got_off || !blob) return SEQREC_E_ARG;
     const int64_t extra = (int64_t)Kr + nid;
@@ -80,10 +80,17 @@ extern "C" int64_t seqrec_route_blob_host(const int32_t* step_off, int T, const 
     for (int64_t q = 0; q < 2 * n; ++q) back[take[q]] = (int32_t)q;
     for (int j = 0; j < R; ++j) for (int e = 0; e < Kr; ++e) back[sc_end[j] + extra * j + e] = (int32_t)(2 * n + (int64_t)j * Kr + e);
     p += n_tot;
-    // owner-side rows as one gather index into [received rows | -1]: requests of peer i at got_off[i] + t, extras at the sentinel
+    // owner-side rows: requests of peer i as an index got_off[i] + t into the received request list, the extras as their kind
+    // (seqrec_exchange_pack's `kinds` with the received list as `got`: -2 at the rows of my draws, -1 at their id rows)
     int32_t* own = p;
-    for (int64_t i = 0; i < m_tot; ++i) own[i] = (int32_t)got_sentinel;
-    { int64_t pos = 0; for (int i = 0; i < R; ++i) { for (int64_t t = 0; t < rc[i]; ++t) own[pos + t] = (int32_t)(got_off[i] + t); pos += rc[i] + extra; } }
+    { int64_t pos = 0;
+      for (int i = 0; i < R; ++i) {
+          for (int64_t t = 0; t < rc[i]; ++t) own[pos + t] = (int32_t)(got_off[i] + t);
+          pos += rc[i];
+          for (int e = 0; e < Kr; ++e) own[pos + e] = -2;
+          for (int e = 0; e < nid; ++e) own[pos + Kr + e] = -1;
+          pos += extra;
+      } }
     p += m_tot;
     { int32_t bits; __builtin_memcpy(&bits, &ntok, 4); *p++ = bits; }
     if (lq_tgt) { __builtin_memcpy(p, lq_tgt, (size_t)n * 4); p += n; }

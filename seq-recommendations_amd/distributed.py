@@ -297,9 +297,13 @@ class RowExchange:
         """The routing of M batches of the UNIFIED step (requests = [input rows ; target rows], `Kr + nid` owner-chosen rows per
         peer pair), planned by the native host routines of csrc/route.hip: same two collectives and one host sync as
         plan_seg_many, one pass per batch instead of ~60 numpy operations (0.7 ms of host time per batch became the
-        bottleneck of a 0.55 ms step).  Returns per batch (blob, parts, plan): `blob` the batch's int32 upload -- written in
-        place by put_fill(count, dtype, fill) (PinnedRing.put_fill; default: a plain tensor on self.dev) --, `parts` the
-        (name, offset, length) list of its fields, `plan` a SegPlan with the split sizes fetch_seg / push_seg need."""
+        bottleneck of a 0.55 ms step).  Returns per batch (blob, parts, plan): `blob` the batch's int32 index block -- the blocks
+        of ALL M batches are written into ONE upload by put_fill(count, dtype, fill) (PinnedRing.put_fill; default: a plain tensor
+        on self.dev) and cross PCIe in one copy; `parts` the (name, offset, length) list of its fields, `plan` a SegPlan with the
+        split sizes fetch_seg / push_seg need.  Round 4: the host no longer touches the received request list -- the blob's
+        `own_src` field is seqrec_exchange_pack's `kinds` (an index into plan.got_pad for requested rows, -1 / -2 at the id /
+        negative rows) -- and the three small transfers go through page-locked memory (a pageable copy blocks the host until
+        the DMA engine has served it, behind whatever the GPU is busy with)."""
         import ctypes
         R, dist, dev = self.R, self.dist, self.dev
         grp = self.group if isinstance(group, str) else group
@@ -315,11 +319,34 @@ class RowExchange:
         for b in range(M):
             _lib.check(lib.seqrec_route_count_host(P32(ids[b]), P32(tgt[b]), rbs[b].n_tok, R, P64(SC[b])), "seqrec_route_count_host")
         tk = np.array([rb.n_tok for rb in rbs], np.int64)
-        sc_ext = np.concatenate([SC.T, np.tile(tk[None, :], (R, 1))], axis=1) if M else np.zeros((R, 0), np.int64)
-        sc_dev = torch.from_numpy(np.ascontiguousarray(sc_ext)).to(dev)
+        sc_ext = np.ascontiguousarray(np.concatenate([SC.T, np.tile(tk[None, :], (R, 1))], axis=1)) if M else np.zeros((R, 0), np.int64)
+
+        def up(arr):                                   # host array -> device tensor, page-locked when the caller gave us its ring
+            if put_fill is None or arr.size == 0:
+                return torch.from_numpy(arr).to(dev)
+            flat_ = arr.reshape(-1)
+
+            def f(dst):
+                dst[:] = flat_
+            return put_fill(flat_.size, arr.dtype, f).view(arr.shape)
+        sc_dev = up(sc_ext)
         rc_dev = torch.empty_like(sc_dev)
         dist.all_to_all_single(rc_dev, sc_dev, group=grp)
-        rc_ext = rc_dev.cpu().numpy()                                                    # (the ONE host sync)
+        import time as _time
+        _t0 = _time.perf_counter()
+        if dev.type == "cuda":
+            hb = getattr(self, "_rc_host", None)
+            if hb is None or hb.numel() < rc_dev.numel():
+                hb = self._rc_host = torch.empty(max(rc_dev.numel(), 4096), dtype=torch.int64).pin_memory()
+            hv = hb[: rc_dev.numel()].view(rc_dev.shape)
+            hv.copy_(rc_dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            ev.synchronize()                                                             # (the ONE host sync)
+            rc_ext = hv.numpy().copy()
+        else:
+            rc_ext = rc_dev.cpu().numpy()
+        self.sync_wait_s = getattr(self, "sync_wait_s", 0.0) + (_time.perf_counter() - _t0)   # how long the host stood here (bench.py reports it)
         RC = np.ascontiguousarray(rc_ext[:, :M].T)                                       # [M, R]
         n_global = rc_ext[:, M:].sum(axis=0)
         in_split = SC.sum(axis=0)
@@ -332,45 +359,58 @@ class RowExchange:
             _lib.check(lib.seqrec_route_fill_host(P32(ids[b]), P32(tgt[b]), rbs[b].n_tok, R, int(V_in), int(bool(tied)), P64(SC[b]),
                                                   P64(np.ascontiguousarray(base[b])), P32(send), P32(rr)), "seqrec_route_fill_host")
             ranks.append(rr)
-        got_all = torch.empty(int(out_split.sum()), dtype=torch.int32, device=dev)
-        dist.all_to_all_single(got_all, torch.from_numpy(send).to(dev), output_split_sizes=[int(x) for x in out_split],
+        n_got = int(out_split.sum())
+        got_pad = torch.empty(n_got + 1, dtype=torch.int32, device=dev)                 # [received rows | -1]
+        got_pad[n_got:] = -1
+        dist.all_to_all_single(got_pad[:n_got], up(send), output_split_sizes=[int(x) for x in out_split],
                                input_split_sizes=[int(x) for x in in_split], group=grp)
-        got_pad = torch.cat([got_all, torch.full((1,), -1, dtype=torch.int32, device=dev)])
         got_off = (np.concatenate([[0], np.cumsum(out_split)])[:-1][None, :] + np.cumsum(RC, axis=0) - RC).astype(np.int64)   # [M, R]
-        out = []
+        # ---- one upload for the whole window: batch b's block at word offs[b] (64-word aligned)
+        metas, offs, cur = [], [], 0
         for b, rb in enumerate(rbs):
             n, T = rb.n_tok, rb.T
             m = int(RC[b].sum())
             n_tot, m_tot = 2 * n + R * extra, m + R * extra
-            lq = None if lq_host is None else np.ascontiguousarray(lq_host[tgt[b]], dtype=np.float32)
             names = [("step_off", T + 1), ("prev", n), ("ids", n), ("tgt", n), ("neg_slots", R * Kr), ("id_rows", R * nid), ("take_in", n),
                      ("take_tgt", n), ("neg_rows", R * Kr), ("negid_idx", R * Kr), ("back_idx", n_tot), ("own_src", m_tot), ("ntok", 1)]
-            if lq is not None:
+            if lq_host is not None:
                 names.append(("lq_tgt", n))
             total = sum(c for _, c in names)
-            so = np.ascontiguousarray(rb.step_off, dtype=np.int32)
-            pv = np.ascontiguousarray(rb.prev, dtype=np.int32)
-            scb, rcb, gob = np.ascontiguousarray(SC[b]), np.ascontiguousarray(RC[b]), np.ascontiguousarray(got_off[b])
+            metas.append((names, total, n_tot, m_tot))
+            offs.append(cur)
+            cur += (total + 63) // 64 * 64
+        f32p = ctypes.POINTER(ctypes.c_float)
 
-            def fill(dst, b=b, n=n, T=T, so=so, pv=pv, scb=scb, rcb=rcb, gob=gob, lq=lq, total=total):
+        def fill_all(dst):
+            for b, rb in enumerate(rbs):
+                names, total, _, _ = metas[b]
+                n, T = rb.n_tok, rb.T
+                so = np.ascontiguousarray(rb.step_off, dtype=np.int32)
+                pv = np.ascontiguousarray(rb.prev, dtype=np.int32)
+                lq = None if lq_host is None else np.ascontiguousarray(lq_host[tgt[b]], dtype=np.float32)
+                scb, rcb, gob = np.ascontiguousarray(SC[b]), np.ascontiguousarray(RC[b]), np.ascontiguousarray(got_off[b])
+                seg = dst[offs[b]: offs[b] + total]
                 wrote = lib.seqrec_route_blob_host(P32(so), T, P32(pv), P32(ids[b]), P32(tgt[b]), n, R, Kr, nid, w, P64(scb), P64(rcb),
-                                                   P32(ranks[b]), P64(gob), int(got_all.numel()), float(n_global[b]),
-                                                   None if lq is None else lq.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
-                                                   dst.ctypes.data_as(i32p), total)
+                                                   P32(ranks[b]), P64(gob), float(n_global[b]),
+                                                   None if lq is None else lq.ctypes.data_as(f32p), seg.ctypes.data_as(i32p), total)
                 if wrote != total:
                     raise _lib.SeqrecError("seqrec_route_blob_host wrote %d of %d words" % (wrote, total))
-            if put_fill is not None:
-                blob = put_fill(total, np.int32, fill)
-            else:
-                host = np.empty(total, np.int32)
-                fill(host)
-                blob = torch.from_numpy(host).to(dev)
+        if put_fill is not None and cur > 0:
+            big = put_fill(cur, np.int32, fill_all)
+        else:
+            host = np.zeros(max(cur, 1), np.int32)
+            fill_all(host)
+            big = torch.from_numpy(host).to(dev)
+        out = []
+        for b, rb in enumerate(rbs):
+            names, total, n_tot, m_tot = metas[b]
+            blob = big[offs[b]: offs[b] + total]
             parts, o = [], 0
             for name, c in names:
                 parts.append((name, o, c))
                 o += c
             p = SegPlan()
-            p.n, p.extra, p.n_tot, p.m_tot = 2 * n, extra, n_tot, m_tot
+            p.n, p.extra, p.n_tot, p.m_tot = 2 * rb.n_tok, extra, n_tot, m_tot
             p.req_split = [int(c) + extra for c in SC[b]]
             p.own_split = [int(c) + extra for c in RC[b]]
             p.req_pos = p.req_extra = p.back_src = p.own_extra = p.own_rows = p.host = None
@@ -612,10 +652,14 @@ class ShardedEngine(Engine):
             ds = self._prepare_unified(rbs)
             ready = torch.cuda.Event()
             ready.record(self.plan_stream)
+        seen = set()
         for d in ds:
             d["ready"] = ready
-            for t in (d["blob"], d["send_idx"]):
-                t.record_stream(main)            # allocated on the planning stream, consumed on the training stream
+            for t in (d["blob"], d["plan"].got_pad):
+                key = t.untyped_storage().data_ptr()
+                if key not in seen:              # (one storage per window: the blocks of all its batches, the received list)
+                    seen.add(key)
+                    t.record_stream(main)        # allocated on the planning stream, consumed on the training stream
         return ds
 
     def _prepare_unified(self, rbs):
@@ -635,10 +679,9 @@ class ShardedEngine(Engine):
             for k in ("lq_tgt", "ntok"):
                 if k in d:
                     d[k] = d[k].view(torch.float32)
-            # owner-side row kinds for seqrec_exchange_pack: the requested local row, -1 at the id rows, -2 at the rows of my draws
-            kinds = plan.got_pad[d.pop("own_src").long()]
-            kinds[d["neg_slots"].long()] = -2
-            d["send_idx"] = kinds
+            # owner-side row kinds for seqrec_exchange_pack: an index into the received request list (plan.got_pad) for the rows the
+            # peers asked for, -1 at the id rows, -2 at the rows of my draws -- written by the native planner, no device work here
+            d["send_idx"] = d.pop("own_src")
             ds.append(d)
         return ds
 
@@ -715,7 +758,7 @@ class ShardedEngine(Engine):
         st = self._stream()
         n, Hp, GHp, Dp, K, w = d["n"], self.Hp, self.GHp, self.Dp, c.K, self.Hp
         from . import engine as _eng
-        if (train and self.native_cell and _eng._PROF is None and c.use_bias and c.drop_in == 0 and c.drop_out == 0 and c.drop_rec == 0
+        if (train and self.native_cell and self.stepwise and _eng._PROF is None and c.use_bias and c.drop_in == 0 and c.drop_out == 0 and c.drop_rec == 0
                 and all(self.trainable.values()) and Dp % 4 == 0):
             return self._cell_unified_native(d, recv, Eneg, neg, lq_neg, reduce_dense)
         drops = self._drop_masks(d, step) if train else {}
@@ -852,6 +895,16 @@ class ShardedEngine(Engine):
         return {"Hd": Hout, "dlt": dlt, "loss_rows": lrows, "Hout": Hout, "dEneg": (dEs, int(pl.ns_deneg), K * Hp),
                 "dX": (dXs, int(pl.ns_dx), n * Dp)}
 
+    def _dense_arrays(self):
+        """(names, P / A / G pointer arrays, sizes, partial-sum floats) of the dense tensors: they never move, built once."""
+        da = getattr(self, "_dense_arr", None)
+        if da is None:
+            dk = sorted(self.Gd)
+            da = self._dense_arr = (dk, _lib.ptr_array([self.P[k] for k in dk]), _lib.ptr_array([self.A[k] for k in dk]),
+                                    _lib.ptr_array([self.Gd[k] for k in dk]), _lib.i64_array([self.Gd[k].numel() for k in dk]),
+                                    int(_lib.load().seqrec_opt_sqnorm_ordered_floats(len(dk), 0, 0)))
+        return da
+
     def _start_dense_allreduce(self):
         """Unified path: the dense all-reduce AND the dense gradient norm run on the side stream (its own communicator under
         RCCL) while the main stream routes the row gradients; the norm is taken in a fixed order (per-block partials added
@@ -867,10 +920,8 @@ class ShardedEngine(Engine):
             if self.unified:
                 if work is not None:
                     work.wait()                  # orders the side stream behind the collective (no host wait under RCCL)
-                dk = sorted(self.Gd)
-                npart = int(_lib.load().seqrec_opt_sqnorm_ordered_floats(len(dk), 0, 0))
-                call("seqrec_opt_sqnorm_ordered", len(dk), _lib.ptr_array([self.Gd[k] for k in dk]),
-                     _lib.i64_array([self.Gd[k].numel() for k in dk]), None, 0, ptr(self.buf("sq_partials_dense", npart)), npart,
+                dk, _, _, gp, nn, npart = self._dense_arrays()
+                call("seqrec_opt_sqnorm_ordered", len(dk), gp, nn, None, 0, ptr(self.buf("sq_partials_dense", npart)), npart,
                      ptr(self.norms[1:2]), 0, None, 0, None, self._stream())
                 self._dense_work = None
             else:
@@ -999,7 +1050,8 @@ class ShardedEngine(Engine):
         th, al, _ = self.sampler
         sendbuf = self.buf("sendbuf", plan.m_tot, w)
         rows_eff = self.buf("rows_eff", plan.m_tot, dtype=torch.int32)
-        call("seqrec_exchange_pack", ptr(self.TT), self.TT.shape[0], w, ptr(d["send_idx"]), plan.m_tot, int(c.seed), int(step) * R + self.rank,
+        call("seqrec_exchange_pack", ptr(self.TT), self.TT.shape[0], w, ptr(d["send_idx"]), ptr(plan.got_pad), plan.got_pad.numel() - 1,
+             plan.m_tot, int(c.seed), int(step) * R + self.rank,
              R * Kr, ptr(th), ptr(al), c.V_out, self.off_out, ptr(d["neg_slots"]), ptr(d["id_rows"]), R * nid, Kr, R, self.rank,
              ptr(sendbuf), ptr(rows_eff), ptr(self.status), st)
         recv = self.ex.fetch_seg(plan, sendbuf)                                 # collective 1
@@ -1162,9 +1214,8 @@ class ShardedEngine(Engine):
         call("seqrec_opt_sqnorm", 0, None, None, job, cnt, ptr(cur), ptr(r["loss_rows"]), n, ptr(self.loss_out), st)
         self.dist.all_reduce(cur, group=self.group)                             # collective 3: one float
         torch.cuda.current_stream(self.dev).wait_stream(self.side)              # dense gradients reduced, their fixed-order norm in norms[1]
-        dk = sorted(self.Gd)
-        call("seqrec_opt_apply", len(dk), _lib.ptr_array([self.P[k] for k in dk]), _lib.ptr_array([self.A[k] for k in dk]),
-             _lib.ptr_array([self.Gd[k] for k in dk]), _lib.i64_array([self.Gd[k].numel() for k in dk]), job, cnt, ptr(cur),
+        dk, pp, pa, gp, nn, _ = self._dense_arrays()
+        call("seqrec_opt_apply", len(dk), pp, pa, gp, nn, job, cnt, ptr(cur),
              float(clipnorm if clipnorm else 0.0), lr, eps, ptr(self.scale), ptr(nxt), ptr(d["ntok"]), ptr(self.status),
              ptr(self.norms[1:2]), st)
         self.sq = cur

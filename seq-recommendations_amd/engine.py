@@ -145,7 +145,10 @@ class PinnedRing:
         self.dev = device
         self.n = slots
         self.arena = None
-        self.big = [None] * slots          # per-slot dedicated buffer for uploads larger than SLOT_BYTES
+        self.NBIG = 4                      # uploads larger than a slot (a window's routing blocks, ~3 MB) rotate through 4 buffers of their own
+        self.big = [None] * self.NBIG
+        self.big_events = [None] * self.NBIG
+        self.big_pos = 0
         self.events = [None] * slots
         self.pos = 0
 
@@ -164,24 +167,30 @@ class PinnedRing:
         upload straight into the page-locked slot (the native planner does: csrc/route.hip)."""
         tdt = torch.from_numpy(np.zeros(0, dtype)).dtype
         nbytes = int(count) * np.dtype(dtype).itemsize
-        i = self.pos
-        self.pos = (i + 1) % self.n
-        if self.events[i] is not None:
-            self.events[i].synchronize()   # the copy issued from this slot `slots` uploads ago
         if nbytes <= self.SLOT_BYTES:
+            i = self.pos
+            self.pos = (i + 1) % self.n
+            if self.events[i] is not None:
+                self.events[i].synchronize()   # the copy issued from this slot `slots` uploads ago
             if self.arena is None:
                 self.arena = torch.empty(self.n * self.SLOT_BYTES, dtype=torch.uint8).pin_memory()
             buf = self.arena[i * self.SLOT_BYTES: i * self.SLOT_BYTES + nbytes]
+            evs = self.events
         else:
+            i = self.big_pos
+            self.big_pos = (i + 1) % self.NBIG
+            if self.big_events[i] is not None:
+                self.big_events[i].synchronize()
             if self.big[i] is None or self.big[i].numel() < nbytes:
-                self.big[i] = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+                self.big[i] = torch.empty(nbytes + nbytes // 4, dtype=torch.uint8).pin_memory()
             buf = self.big[i][:nbytes]
+            evs = self.big_events
         host = buf.view(tdt)
         fill(host.numpy())
         out = host.to(self.dev, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.dev))
-        self.events[i] = ev
+        evs[i] = ev
         return out
 
 

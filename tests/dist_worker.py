@@ -131,10 +131,14 @@ def unified_plan_checks(D, ex, rank, R):
                 oe, re_ = h["own_extra"], h["req_extra"]
                 back = h["back"].copy()
                 back[re_[:, :Kr].reshape(-1)] = 2 * n + np.arange(R * Kr)
+                # owner-side row kinds (seqrec_exchange_pack): the request's index into the received list, -2 at my draws, -1 at id rows
+                own_kinds = h["own_src"].copy()
+                own_kinds[oe[:, :Kr].reshape(-1)] = -2
+                own_kinds[oe[:, Kr:Kr + nid].reshape(-1)] = -1
                 want = {"step_off": rb.step_off, "prev": rb.prev, "ids": rb.ids, "tgt": rb.tgt, "neg_slots": oe[:, :Kr].reshape(-1),
                         "id_rows": oe[:, Kr:Kr + nid].reshape(-1), "take_in": h["req_pos"][:n], "take_tgt": h["req_pos"][n:],
                         "neg_rows": re_[:, :Kr].reshape(-1), "negid_idx": (re_[:, Kr + q // w] * w + (q % w)[None, :]).reshape(-1),
-                        "back_idx": back, "own_src": h["own_src"],
+                        "back_idx": back, "own_src": own_kinds,
                         "ntok": np.array([pr.n_global], np.float32).view(np.int32)}
                 if lq is not None:
                     want["lq_tgt"] = lq[rb.tgt].view(np.int32)
