@@ -509,5 +509,6 @@ def test_one_call_cell_equals_the_call_by_call_step(case):
         assert abs(la - lb) <= 1e-5 * abs(lb), (step, la, lb)
     for k in a.P:
         d_ = float((a.P[k] - b.P[k]).abs().max().item())
-        assert d_ <= 2e-5 * max(1.0, float(b.P[k].abs().max().item())), (k, d_)
+        # three steps apart only by the rounding of the scatter's float atomics; a flipped +-lr Adagrad move would be 2 lr = 0.04
+        assert d_ <= 5e-4 * max(1.0, float(b.P[k].abs().max().item())), (k, d_)
     a.check_status(); b.check_status()
