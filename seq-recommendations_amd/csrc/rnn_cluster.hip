@@ -45,14 +45,12 @@ __device__ __forceinline__ void cl_tiles(const float (&a)[K / 16], const float4 
             q1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * i + 3], b1[i].w, q1, 0, 0, 0);
         }
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        red[w * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = p0[r] + p1[r];
-        if (NT == 2) red[1024 + w * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = q0[r] + q1[r];
-    }
+    cl_red_store(red + w * 256, lane, p0, p1);
+    if (NT == 2) cl_red_store(red + 1024 + w * 256, lane, q0, q1);
     __syncthreads();
-    out0 = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
-    if (NT == 2) out1 = (red[1024 + tid] + red[1280 + tid]) + (red[1536 + tid] + red[1792 + tid]);
+    const float* rt = red + cl_red_r(tid);
+    out0 = (rt[0] + rt[256]) + (rt[512] + rt[768]);
+    if (NT == 2) out1 = (rt[1024] + rt[1280]) + (rt[1536] + rt[1792]);
 }
 template <int N> __device__ __forceinline__ void mul_vec(float (&o)[N], const float (&a)[N], const float (&m)[N]) {
 #pragma unroll
@@ -70,7 +68,7 @@ __global__ __launch_bounds__(256) void gru_cluster_fwd(ClusterArgs a) {
     const int gl = x + 8 * jj;                       // group index inside this launch
     const int r0 = 16 * (a.g_base + gl);
     if (gl >= a.n_groups || r0 >= a.so[1] - a.so[0]) return;
-    __shared__ float smem[1024 + 4 * 16 * (H / 4)];       // partial tiles of a product + the 4 waves' A-row images
+    __shared__ __attribute__((aligned(16))) float smem[1024 + 4 * 16 * (H / 4)];       // partial tiles of a product + the 4 waves' A-row images
     float* red = smem;
     float* stage = smem + 1024;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -191,7 +189,7 @@ __global__ __launch_bounds__(256) void gru_cluster_bwd(ClusterArgs a) {
     const int gl = x + 8 * jj;
     const int r0 = 16 * (a.g_base + gl);
     if (gl >= a.n_groups || r0 >= a.so[1] - a.so[0]) return;
-    __shared__ float smem[1024 + 4 * 16 * (2 * H / 4)];   // partial tiles of a product + the 4 waves' A-row images (K up to 2H)
+    __shared__ __attribute__((aligned(16))) float smem[1024 + 4 * 16 * (2 * H / 4)];   // partial tiles of a product + the 4 waves' A-row images (K up to 2H)
     float* red = smem;
     float* stage = smem + 1024;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;

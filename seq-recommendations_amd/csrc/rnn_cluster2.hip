@@ -43,7 +43,7 @@ template <int J, int ACT, bool RD>
 __global__ __launch_bounds__(256) void srnn_cluster_fwd(ClusterArgs a) {
     constexpr int H = 64 * J, CB = H / 16, NB = H / 64;
     CL_PROLOGUE(CB);
-    __shared__ float smem[1024 + 4 * 16 * (H / 4)];
+    __shared__ __attribute__((aligned(16))) float smem[1024 + 4 * 16 * (H / 4)];
     float* red = smem;
     float* stage = smem + 1024 + w * (16 * H / 4);
     float4 b[1][NB];
@@ -98,7 +98,7 @@ template <int J, int ACT, bool RD>
 __global__ __launch_bounds__(256) void srnn_cluster_bwd(ClusterArgs a) {
     constexpr int H = 64 * J, CB = H / 16, NB = H / 64;
     CL_PROLOGUE(CB);
-    __shared__ float smem[1024 + 4 * 16 * (H / 4)];
+    __shared__ __attribute__((aligned(16))) float smem[1024 + 4 * 16 * (H / 4)];
     float* red = smem;
     float* stage = smem + 1024 + w * (16 * H / 4);
     float4 b[1][NB];
@@ -156,9 +156,29 @@ template <int J, int ACT, bool RD>
 __global__ __launch_bounds__(256, 2) void lstm_cluster_fwd(ClusterArgs a) {
     constexpr int H = 64 * J, GH = 4 * H, CB = H / 16, NB = H / 64;
     CL_PROLOGUE(CB);
-    __shared__ float smem[4096 + 4 * 16 * (H / 4)];       // 4 gate tiles x 4 waves of partial sums + the waves' A-row images
+    __shared__ __attribute__((aligned(16))) float smem[4096 + 4 * 16 * (H / 4)];       // 4 gate tiles x 4 waves of partial sums + the waves' A-row images
     float* red = smem;
     float* stage = smem + 4096 + w * (16 * H / 4);
+    // recurrent dropout: the lane's multipliers of its H/16 A elements, per gate.  A multiplier is 0 or 1/(1-p) (inverted dropout,
+    // seqrec_dropout_mask), so a gate's H/16 <= 32 of them are ONE bit word + the keep value instead of H/16 registers (round 4:
+    // 4 x 32 floats next to the 128 registers of the U slice pushed the H = 512 kernel out of the cluster form); the product
+    // a * (bit ? keep : 0) is the multiply the float mask gave, bit for bit.
+    [[maybe_unused]] unsigned mbits[RD ? 4 : 1];
+    [[maybe_unused]] float keepv = 0.f;
+    if constexpr (RD) {
+        static_assert(H / 16 <= 32, "one bit word per gate");
+        const int srow = min(r0 + (lane & 15), a.B - 1), koff = w * (H / 4) + (lane >> 4) * (H / 16);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float m[H / 16];
+            ld_mask(m, a.rmask, a.B, H, g, srow, koff);
+            unsigned bits = 0;
+#pragma unroll
+            for (int i = 0; i < H / 16; ++i) { if (m[i] != 0.f) { bits |= 1u << i; keepv = m[i]; } }
+            mbits[g] = bits;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);      // the mask words are built before the 128 registers of the U slice become live
     float4 b[4][NB];
     {
         const float4* pa = reinterpret_cast<const float4*>(a.pk_a);      // packed [U_i U_f U_c U_o], N = 4H: gate g's column block = g CB + c
@@ -166,12 +186,6 @@ __global__ __launch_bounds__(256, 2) void lstm_cluster_fwd(ClusterArgs a) {
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int i = 0; i < NB; ++i) b[g][i] = pa[((size_t)((g * CB + c) * 4 + w) * NB + i) * 64 + lane];
-    }
-    [[maybe_unused]] float mk[RD ? 4 : 1][RD ? H / 16 : 1];
-    if constexpr (RD) {
-        const int srow = min(r0 + (lane & 15), a.B - 1), koff = w * (H / 4) + (lane >> 4) * (H / 16);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) ld_mask(mk[g], a.rmask, a.B, H, g, srow, koff);
     }
     const unsigned base = a.epoch;
     float cprev = 0.f;
@@ -210,16 +224,13 @@ __global__ __launch_bounds__(256, 2) void lstm_cluster_fwd(ClusterArgs a) {
             CS(2);
             if constexpr (RD) {
                 // every gate reads h_{t-1} through its own mask: four masked copies of the A operand, one tile each
-                float4 b1[1][NB];
-                float am[H / 16], o1[1], u1[1];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    mul_vec(am, av, mk[g]);
-#pragma unroll
-                    for (int i = 0; i < NB; ++i) b1[0][i] = b[g][i];
                     if (g) __syncthreads();                          // red of the previous gate has been read
-                    cl_tiles_n<H, 1>(am, b1, red, tid, o1, u1);
-                    acc[g] = o1[0];
+                    // the mask word is made opaque per step: seen as loop-invariant, its 4 x H/16 multipliers are hoisted out of the
+                    // time loop and become 128 live registers (spilled) again
+                    asm volatile("" : "+v"(mbits[g]));
+                    acc[g] = cl_tile_bitmasked<H>(av, mbits[g], keepv, b[g], red, tid);
                 }
             } else {
                 cl_tiles_n<H, 4>(av, b, red, tid, acc, unused);
@@ -263,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void lstm_cluster_bwd(ClusterArgs a) {
     constexpr int NI = 16 / (64 / CHF);                  // DMA instructions per piece
     constexpr int IMG = 16 * 4 * CHF;                    // floats of a piece image
     CL_PROLOGUE(CB);
-    __shared__ float smem[1024 + 4 * RING * IMG];
+    __shared__ __attribute__((aligned(16))) float smem[1024 + 4 * RING * IMG];
     float* red = smem;
     float* ring = smem + 1024 + w * (RING * IMG);
     float4 b[K / 64];
@@ -360,16 +371,18 @@ __global__ __launch_bounds__(256, 2) void lstm_cluster_bwd(ClusterArgs a) {
             }
         });
         CS(4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[w * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc0[r] + acc1[r];
+        cl_red_store(red + w * 256, lane, acc0, acc1);
         __syncthreads();
-        if constexpr (RD) {
-            float v = 0.f;
+        {
+            const float* rt = red + cl_red_r(tid);
+            if constexpr (RD) {
+                float v = 0.f;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) v += red[g * 256 + tid] * m_g[g];
-            dh_carry = v;
-        } else {
-            dh_carry = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+                for (int g = 0; g < 4; ++g) v += rt[g * 256] * m_g[g];
+                dh_carry = v;
+            } else {
+                dh_carry = (rt[0] + rt[256]) + (rt[512] + rt[768]);
+            }
         }
         // (the next write of `red` is behind the next step's publish barrier)
         CS(5);
@@ -408,14 +421,12 @@ __global__ __launch_bounds__(256, 2) void lstm_cluster_bwd(ClusterArgs a) {
         }                                                                                                            \
         return nullptr;                                                                                              \
     }
-// H = 512 with recurrent dropout: the forward LSTM would need 128 mask + 128 kernel registers per lane -> step-wise form;
-// the other three kernels keep one multiplier per thread (BPTT) or 32 per lane (SimpleRNN forward)
+// (round 3 kept the H = 512 forward LSTM with recurrent dropout out of the cluster form: 128 mask + 128 kernel registers per lane;
+// round 4 holds the masks as one bit word per gate -- lstm_cluster_fwd -- and every kernel has every form)
 #define RD8 true
 KERNEL_TABLE(srnn_fwd_kernel, srnn_cluster_fwd)
 KERNEL_TABLE(srnn_bwd_kernel, srnn_cluster_bwd)
 KERNEL_TABLE(lstm_bwd_kernel, lstm_cluster_bwd)
-#undef RD8
-#define RD8 false
 KERNEL_TABLE(lstm_fwd_kernel, lstm_cluster_fwd)
 #undef RD8
 

@@ -199,6 +199,16 @@ struct StepWindow {
     __device__ __forceinline__ void advance_down() { s2 = s1; s1 = s0; s0 = prev; prev = nxt; nxt = pend; }
 };
 
+// The cross-wave reduce buffer of a 16x16 tile: wave w's partial tile at red[w * 256 ...].  An MFMA 16x16x4 lane (q = lane >> 4,
+// n = lane & 15) holds C[4q + r][n], r = 0..3: the four are stored as ONE 16-byte write at [q][n][r] (round 4; four 4-byte writes
+// before -- 16 -> 4 LDS write instructions per wave in the LSTM forward step), and thread tid = (row, col) = (tid >> 4, tid & 15)
+// reads its element at cl_red_r(tid).  A wave's 64 reads cover 64 consecutive floats: conflict-free, like the writes.
+__device__ __forceinline__ int cl_red_w(int lane) { return ((lane >> 4) * 16 + (lane & 15)) * 4; }
+__device__ __forceinline__ int cl_red_r(int tid) { return ((tid >> 6) * 16 + (tid & 15)) * 4 + ((tid >> 4) & 3); }
+__device__ __forceinline__ void cl_red_store(float* red_wave, int lane, const f32x4& a, const f32x4& b) {
+    *reinterpret_cast<f32x4*>(red_wave + cl_red_w(lane)) = f32x4{a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]};
+}
+
 // NT 16x16 tile products (one shared A operand, NT packed B operands) with K split over the 4 waves (rnn_step.hip
 // tile_16x16_reg: same order of sums per tile).  red: NT x 4 x 256 floats.  SPLIT: out[t] = the sum of waves 0-1, out2[t] =
 // the sum of waves 2-3 (the caller weights the halves); else out[t] = (w0 + w1) + (w2 + w3).
@@ -223,16 +233,44 @@ __device__ __forceinline__ void cl_tiles_n(const float (&a)[K / 16], const float
         }
     }
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[t * 1024 + w * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = p0[t][r] + p1[t][r];
+    for (int t = 0; t < NT; ++t) cl_red_store(red + t * 1024 + w * 256, lane, p0[t], p1[t]);
     __syncthreads();
+    const int rp = cl_red_r(tid);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const float* rt = red + t * 1024;
-        if (SPLIT) { out[t] = rt[tid] + rt[256 + tid]; out2[t] = rt[512 + tid] + rt[768 + tid]; }
-        else out[t] = (rt[tid] + rt[256 + tid]) + (rt[512 + tid] + rt[768 + tid]);
+        const float* rt = red + t * 1024 + rp;
+        if (SPLIT) { out[t] = rt[0] + rt[256]; out2[t] = rt[512] + rt[768]; }
+        else out[t] = (rt[0] + rt[256]) + (rt[512] + rt[768]);
     }
+}
+
+// ONE tile product with the A operand multiplied by a bit mask on the way in: a[i] * (bit i of `bits` ? keep : 0) -- the masked
+// copy of the operand is never materialised (4 live values at a time instead of K/16: the LSTM-512 forward under recurrent
+// dropout has no registers for it next to its 128 of U).  Same MFMAs in the same order as cl_tiles_n<K, 1> on the masked copy.
+template <int K>
+__device__ __forceinline__ float cl_tile_bitmasked(const float (&a)[K / 16], unsigned bits, float keep, const float4 (&b)[K / 64],
+                                                   float* __restrict__ red, int tid) {
+    const int lane = tid & 63, w = tid >> 6;
+    f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < K / 64; ++i) {
+        __builtin_amdgcn_sched_barrier(0);         // keep the masked values just-in-time: hoisted, they are K/16 live registers again
+        // sign-extended 1-bit field = all ones or zero: (a AND it) * keep is a * keep or (+0) * keep -- one v_bfe_i32, one v_and, one
+        // v_mul per element, no condition register.  (A dropped element enters the MFMA as +0 where the float mask gave +-0: the
+        // accumulators start at +0, so no sum can tell.)
+        const float a0 = __uint_as_float(__float_as_uint(a[4 * i + 0]) & (unsigned)__builtin_amdgcn_sbfe((int)bits, 4 * i + 0, 1)) * keep;
+        const float a1 = __uint_as_float(__float_as_uint(a[4 * i + 1]) & (unsigned)__builtin_amdgcn_sbfe((int)bits, 4 * i + 1, 1)) * keep;
+        const float a2 = __uint_as_float(__float_as_uint(a[4 * i + 2]) & (unsigned)__builtin_amdgcn_sbfe((int)bits, 4 * i + 2, 1)) * keep;
+        const float a3 = __uint_as_float(__float_as_uint(a[4 * i + 3]) & (unsigned)__builtin_amdgcn_sbfe((int)bits, 4 * i + 3, 1)) * keep;
+        p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[i].x, p0, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[i].y, p1, 0, 0, 0);
+        p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b[i].z, p0, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b[i].w, p1, 0, 0, 0);
+    }
+    cl_red_store(red + w * 256, lane, p0, p1);
+    __syncthreads();
+    const float* rt = red + cl_red_r(tid);
+    return (rt[0] + rt[256]) + (rt[512] + rt[768]);
 }
 
 // recurrent-dropout multipliers of gate g for the lane's A elements (operand order: K/16 consecutive floats at koff)

@@ -553,7 +553,7 @@ __device__ __forceinline__ void lstm_step_fwd_body(const StepArgs& a_in) {
     int r0, cb;
     if (!tile_of(a, r0, cb)) return;
     constexpr int H = 64 * J, GH = 4 * H, NB = H / 64, CBN = H / 16;
-    __shared__ float red[4 * 1024];
+    __shared__ __attribute__((aligned(16))) float red[4 * 1024];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nact = min(16, a.bt - r0);
     const int row = tid >> 4, col = 16 * cb + (tid & 15);
