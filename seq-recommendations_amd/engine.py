@@ -36,6 +36,7 @@ SPLITK_TARGET_WGS = int(_os.environ.get("SEQREC_SPLITK_WGS", "512"))
 SPLITK_MIN_K = int(_os.environ.get("SEQREC_SPLITK_MIN_K", "512"))
 SPLITK_FILL_WGS = int(_os.environ.get("SEQREC_SPLITK_FILL", "1152"))
 SPLITK_FILL_WGRAD = int(_os.environ.get("SEQREC_SPLITK_FILL_WGRAD", "1700"))
+SPLITK_LONGK_WGS = int(_os.environ.get("SEQREC_SPLITK_LONGK", "1280"))
 
 # Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg):
 # _PROF = {"events": [(name, tag, start_event, end_event), ...]} while enabled, else None.
@@ -436,7 +437,7 @@ class Engine:
                 use.append(self._splitk(m, kin, GHp, fill=True) * m * kin)                                          # dX
             shapes = [(Hp, GHp), (kin, GHp), (1, GHp)]                                                   # grouped dU, dW, db
             tiles = sum(((a + 63) // 64) * ((b + 63) // 64) for a, b in shapes if a)
-            sk = self._splitk_tiles(tiles, m, fill=SPLITK_FILL_WGRAD)
+            sk = self._splitk_tiles(tiles, m, fill=SPLITK_FILL_WGRAD, long_k=True)
             use.append(sk * sum(a * b for a, b in shapes))
             ws = max(ws, max(use))
         need["gemm_ws"] = ws
@@ -496,7 +497,7 @@ class Engine:
         return Engine._splitk_tiles(((M + 63) // 64) * ((N + 63) // 64), K, fill=fill)
 
     @staticmethod
-    def _splitk_tiles(tiles, K, min_k=None, fill=False):
+    def _splitk_tiles(tiles, K, min_k=None, fill=False, long_k=False):
         """fill: products with 256 or more tiles that would not be split at all (c4: dH 320, dX 320, dW+dU 544 tiles of 64 x 64 on
         1 280 workgroup slots -- one thin round, 1.25-2.1 workgroups per CU) are split until ~SPLITK_FILL_WGS slots are taken
         (same-box A/B at c4, tools/ab_c4.sh: dH 142 -> 105 us, dX 71 -> 54, dW+dU 210 -> 176; dEneg -- 504 tiles, 8 MB per
@@ -508,6 +509,11 @@ class Engine:
         sk = SPLITK_TARGET_WGS // max(tiles, 1)
         if fill and tiles >= 256:
             sk = max(sk, (SPLITK_FILL_WGS if fill is True else int(fill)) // tiles)
+        if long_k and K >= 8192:
+            # a long reduction into few tiles (saturated c3: the weight gradients, 108 tiles x K = 25 088 tokens): 512 / tiles
+            # splits leave two thirds of the 1 280 workgroup slots empty and 392 K steps per workgroup; fill the slots while a
+            # slab still reduces >= 2 048 tokens (the norm launch streams the slabs once)
+            sk = max(sk, min(SPLITK_LONGK_WGS // max(tiles, 1), K // 2048))
         return int(max(1, min(32, sk, K // mk)))
 
     # ------------------------------------------------------------------ parameters (Keras layouts)
@@ -1129,7 +1135,7 @@ class Engine:
         if wgrad:
             # the weight gradients A^T . dPre all reduce over the tokens: one grouped split-K launch
             tiles = sum(((w_[0] + 63) // 64) * ((w_[1] + 63) // 64) for w_ in wgrad)
-            sk = self._splitk_tiles(tiles, n, fill=SPLITK_FILL_WGRAD)
+            sk = self._splitk_tiles(tiles, n, fill=SPLITK_FILL_WGRAD, long_k=True)
             slabs_ok = (self._slab_wgrad and apply_update and c.merge != "sorted" and not self.priors and len(sparse_jobs) <= 4
                         and len([k for k in Gd if tr[k]]) <= 8)
             ride = deneg_late is not None and slabs_ok and len(wgrad) < 6
@@ -1219,32 +1225,31 @@ class Engine:
             self._sq_par ^= 1
             self.sq = cur
         else:
+            # more than 8 dense tensors (RNNFullModel with every side branch and bias) or more than 4 scatter lists: the multi-launch
+            # form, the dense tensors in groups of 8 (the kernels' argument arrays) -- both merges (round 4: merge='sorted' raised here)
             self.sq = self.sq1
             self.sq.zero_()
             call("seqrec_loss_reduce", ptr(lrows), n, ptr(self.loss_out), st)
-            if dk:
-                gp = _lib.ptr_array([Gd[k] for k in dk])
-                nn = _lib.i64_array([Gd[k].numel() for k in dk])
+            chunks = [dk[i:i + 8] for i in range(0, len(dk), 8)]
+            arrs = [(len(ch), _lib.ptr_array([P[k] for k in ch]), _lib.ptr_array([self.A[k] for k in ch]), _lib.ptr_array([Gd[k] for k in ch]),
+                     _lib.i64_array([Gd[k].numel() for k in ch])) for ch in chunks]
             if c.merge == "sorted":      # ordered partial sums, added call by call (stream order): no float atomics
-                if len(dk) > 8:
-                    raise NotImplementedError("merge='sorted' covers steps with <= 8 dense tensors")
                 mx = max([j["n"] for j in sparse_jobs] + [0])
                 lib = _lib.load()
-                npart = int(max(lib.seqrec_opt_sqnorm_ordered_floats(len(dk), 0, 0), lib.seqrec_opt_sqnorm_ordered_floats(0, 4, mx)))
+                npart = int(max(lib.seqrec_opt_sqnorm_ordered_floats(min(len(dk), 8), 0, 0), lib.seqrec_opt_sqnorm_ordered_floats(0, 4, mx)))
                 pbuf = self.buf("sq_partials", npart)
-                if dk:
-                    call("seqrec_opt_sqnorm_ordered", len(dk), gp, nn, None, 0, ptr(pbuf), npart, ptr(self.sq), 1, None, 0, None, st)
+                for cnt_d, _, _, gp, nn in arrs:
+                    call("seqrec_opt_sqnorm_ordered", cnt_d, gp, nn, None, 0, ptr(pbuf), npart, ptr(self.sq), 1, None, 0, None, st)
                 for arr, cnt in packed:
                     call("seqrec_opt_sqnorm_ordered", 0, None, None, arr, cnt, ptr(pbuf), npart, ptr(self.sq), 1, None, 0, None, st)
             else:
-                if dk:
-                    call("seqrec_sqnorm_multi", len(dk), gp, nn, ptr(self.sq), st)
+                for cnt_d, _, _, gp, nn in arrs:
+                    call("seqrec_sqnorm_multi", cnt_d, gp, nn, ptr(self.sq), st)
                 for arr, cnt in packed:
                     call("seqrec_rows_sqnorm_multi", arr, cnt, ptr(self.sq), st)
             call("seqrec_clip_scale", ptr(self.sq), clip, ptr(self.scale), st)
-            if dk:
-                call("seqrec_adagrad_dense_multi", len(dk), _lib.ptr_array([P[k] for k in dk]),
-                     _lib.ptr_array([self.A[k] for k in dk]), gp, nn, lr, eps, ptr(self.scale), st)
+            for cnt_d, pp, pa, gp, nn in arrs:
+                call("seqrec_adagrad_dense_multi", cnt_d, pp, pa, gp, nn, lr, eps, ptr(self.scale), st)
             for arr, cnt in packed:
                 call("seqrec_rows_adagrad_multi", arr, cnt, lr, eps, ptr(self.scale), st)
         if tr["U"]:
@@ -1330,7 +1335,7 @@ class Engine:
         shapes = [(Hp, 2 * Hp), (Hp, Hp)] if c.cell == "gru" else [(Hp, GHp)]
         shapes += [(Dp, GHp), (1, GHp)]
         tiles = sum(((a + 63) // 64) * ((b + 63) // 64) for a, b in shapes)
-        sk_w = self._splitk_tiles(tiles, n, fill=SPLITK_FILL_WGRAD)
+        sk_w = self._splitk_tiles(tiles, n, fill=SPLITK_FILL_WGRAD, long_k=True)
         ride = (self._group_deneg and n <= 4096 and len(shapes) < 6
                 and ((K + 63) // 64) * ((Hp + 63) // 64) + ((Dp + 63) // 64 + (Hp + 63) // 64 + 1) * ((GHp + 63) // 64) <= 512)
         if ride:
