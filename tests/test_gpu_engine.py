@@ -465,7 +465,7 @@ def test_pinned_ring_uploads_are_safe_by_construction():
 
 @pytest.mark.parametrize("case", [dict(cell="gru", act="relu", H=256, V=5000, inp="embed", out="sampled", D=256, K=500, logq=True),
                                   dict(cell="lstm", act="relu", H=512, V=3000, inp="embed", out="sampled", D=512, K=400, logq=True),
-                                  dict(cell="gru", act="tanh", H=64, V=1500, inp="embed", out="sampled", D=64, K=64, tied=True),
+                                  dict(cell="gru", act="tanh", H=128, V=1500, inp="embed", out="sampled", D=128, K=64, tied=True),
                                   dict(cell="simplernn", act="relu", H=512, V=2000, inp="embed", out="sampled", D=64, K=4000)],
                          ids=lambda c: "-".join(str(v) for v in c.values()))
 def test_one_call_cell_equals_the_call_by_call_step(case):
@@ -498,6 +498,8 @@ def test_one_call_cell_equals_the_call_by_call_step(case):
             assert la == lb
             for name, m in (("XW", n * a.GHp), ("Hout", n * a.Hp), ("gates", n * a.GHp), ("ln", n * case["K"]), ("dlt", n), ("dHd", n * a.Hp),
                             ("dPre", n * a.GHp), ("Eneg", case["K"] * a.Hp)):
+                if name == "gates" and case["cell"] == "simplernn":
+                    continue                                   # (the SimpleRNN scan keeps no gate stash: the buffer is never written)
                 assert torch.equal(a.ws[name][:m], b.ws[name][:m]), name
             for key in ("dX_slabs", "dEneg_slabs"):
                 (va, nsa, ra, ca), (vb, nsb, rb_, cb) = a.last_slabs[key], b.last_slabs[key]
