@@ -223,7 +223,8 @@ def kernel_model(cfgd, n_tok, K, B, slabs=None, uniq=None, upack_floats=0):
         "seqrec_sampled_softmax_ce": ("hbm", ce_b),
         "seqrec_rnn_pack_u_sample": ("hbm", pack_b),
         "seqrec_pack_batch_host": ("hbm", batch_b),
-        "seqrec_gather_rows[E]": ("hbm", 8.0 * D * n_tok),                                   # 4 B read + 4 B written / elt (dropout path only)
+        "seqrec_gather_rows[E]": ("hbm", 8.0 * D * n_tok),                                   # 4 B read + 4 B written / elt (dropout, or > 8 192 tokens)
+        "seqrec_gather_rows[Hprev]": ("hbm", 8.0 * H * n_tok),
     }
     if tied:
         pass          # same formula: one table takes all three lists

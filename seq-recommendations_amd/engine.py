@@ -324,6 +324,8 @@ class Engine:
         # the cell of the common training step in ONE C-ABI call (seqrec_train_cell); SEQREC_NATIVE_CELL=0: call by call
         self.native_cell = _os.environ.get("SEQREC_NATIVE_CELL", "1") != "0"
         self._plan, self._plan_gen, self._plan_keep = None, None, None
+        # batches of more tokens than this materialise E[ids] and h_{t-1} once instead of gathering them inside three GEMMs
+        self.fuse_gather_max = int(_os.environ.get("SEQREC_FUSE_GATHER_MAX", "8192"))
 
     # ------------------------------------------------------------------ device-side failures
     def check_status(self):
@@ -884,7 +886,7 @@ class Engine:
             call("seqrec_gather_rows", ptr(P["Wk"]), ptr(d["ids"]), ptr(XW), n, GHp, ptr(drops.get("in")), ptr(bias), 0, st)
         else:
             xidx = None
-            if c.input == "embed" and "in" not in drops:
+            if c.input == "embed" and "in" not in drops and n <= self.fuse_gather_max:
                 # the embedding lookup is fused into the cell's input GEMM: A = E read THROUGH the ids (no X copy)
                 X, xidx = P["E"], d["ids"]
                 Wm, Kd = P["W"], self.Dp
@@ -973,7 +975,7 @@ class Engine:
             return torch.zeros(1, device=self.dev)
         st = self._stream()
         Hp, GHp = self.Hp, self.GHp
-        if self._native_cell_ok(negatives, apply_update):
+        if n <= self.fuse_gather_max and self._native_cell_ok(negatives, apply_update):
             return self._train_step_native(d, lr, eps, clipnorm, step)
         # the batch loss is reduced by a spare workgroup of the gradient-norm launch (defer_loss) when that launch runs
         r = self.forward(d, train=True, step=step, negatives=negatives, defer_loss=apply_update)
@@ -1075,9 +1077,11 @@ class Engine:
         if c.use_bias and tr["b"] and not bias_in_group:
             call("seqrec_colsum", ptr(dPre), n, GHp, GHp, ptr(Gd["b"]), 0, ptr(cs_ws), st)
         if tr["U"]:
-            if "rec" in drops:
-                Hprev = self.buf("Hprev", n, Hp)
-                call("seqrec_gather_rows", ptr(r["Hout"]), ptr(d["prev"]), ptr(Hprev), n, Hp, None, None, 0, st)
+            if "rec" in drops or n > self.fuse_gather_max:
+                # many tokens (saturated batches: 25 k): the weight-gradient GEMM that gathers its A rows along K runs at ~45 % of the
+                # plain one's rate per K step; a 26 MB copy of h_{t-1} (and of E[ids], above) costs ~10 us and serves it at full rate
+                Hprev, hidx = self.buf("Hprev", n, Hp), None
+                call("seqrec_gather_rows", ptr(r["Hout"]), ptr(d["prev"]), ptr(Hprev), n, Hp, None, None, 0, st, tag="Hprev")
             else:
                 Hprev, hidx = r["Hout"], d["prev"]      # h_{t-1} rows are read through the prev links inside the GEMM
             sk = self._splitk(Hp, GHp, n)
