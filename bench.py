@@ -788,6 +788,10 @@ def main(argv=None):
         sess_total, tok_total = float(tt[0].item()), float(tt[1].item()) * a.steps
     else:
         sess_total, tok_total = sess_timed, n_tok_mean * a.steps
+    # the scan's length is the batch's LONGEST session: the mean over a whole epoch of this stream's batches stands beside the timed
+    # window's (a 20-step window's T_mean wanders by +-8 %, and with it the step time: read `value` with both)
+    trans = (starts[1:] - starts[:-1] - 1)
+    t_mean_epoch = round(float(np.mean([int(trans[stream.sel(i)].max()) for i in range(stream.per_epoch)])), 1)
     ms_per_step = dt / a.steps * 1e3
     sessions_per_s = sess_total / dt
     tokens_per_s = tok_total / dt
@@ -972,7 +976,7 @@ def main(argv=None):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cd["desc"] + (" (saturated: 50 items/session)" if a.saturated else " (MSNBC-shaped lengths)"),
                        "global_batch": a.batch * world, "seq_len": 50, "tokens_per_step_per_gpu": round(n_tok_mean, 1),
-                       "t_mean": round(t_mean, 1), "t_max": t_max, "settle_steps": a.settle, "batches": mode, "scan": scan_issue, "row_gradient_merge": a.merge,
+                       "t_mean": round(t_mean, 1), "t_max": t_max, "t_mean_epoch": t_mean_epoch, "settle_steps": a.settle, "batches": mode, "scan": scan_issue, "row_gradient_merge": a.merge,
                        "train_sessions_per_gpu": n_train, "test_sessions": n_test,
                        "routing_window": WINDOW if (sharded and not resident) else None,
                        "routing_host_ms_per_window": ({"pack": round(1e3 * route_host["pack_s"] / max(route_host["windows"], 1), 2),

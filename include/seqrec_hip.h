@@ -37,6 +37,16 @@
  *     Two process-wide test switches exist (seqrec_debug_*): they select
  *     between equivalent kernel forms or force a failure path, are not
  *     thread-safe, and no product code calls them.
+ *     Residency assumption of the cluster scans: a launch may hold more row
+ *     blocks than can be resident at once (launch_sliced); forward progress
+ *     then rests on the dispatcher handing workgroups out in blockIdx order
+ *     per XCD, so that an XCD holds complete groups (which finish on their
+ *     own) and at most one group that is still arriving.  That is observed
+ *     behaviour of this runtime, not a documented guarantee, and other
+ *     processes on the GPU can break it: EVERY in-kernel wait is bounded,
+ *     counted (seqrec_cluster_scan_errors) and poisons its output; the Python
+ *     engine raises on a non-zero count and switches the process to the
+ *     step-wise form (seqrec_debug_scan_cluster(0)) for the retry.
  *     Environment: the library reads NO environment variable.  The developer
  *     switches of earlier rounds (SEQREC_GEMM_V2, _V2_TILE, _V2_GTILE, _BK32,
  *     _TILE_THR, SEQREC_CE_BLOCK, SEQREC_SCATTER_COMBINE, SEQREC_SCAN_CLUSTER,

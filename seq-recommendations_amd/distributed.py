@@ -582,6 +582,9 @@ class ShardedEngine(Engine):
         who = [int(r) for r in np.nonzero(table.any(axis=1))[0]]
         self.status.zero_()
         lib.seqrec_cluster_scan_errors_reset(st)
+        if gerr:                                     # every rank switches, so the replicas keep issuing the same launches
+            lib.seqrec_debug_scan_cluster(0)
+            msgs.append("the cluster form of the scans is now OFF for this process (step-wise form from here on)")
         raise _lib.SeqrecError("device-side failure at or before training step %d on rank(s) %s of %d (raised on every rank): %s"
                                % (self.step_count, who, self.R, "; ".join(msgs)))
 

@@ -341,6 +341,12 @@ class Engine:
             return
         self.status.zero_()
         _lib.load().seqrec_cluster_scan_errors_reset(self._stream())
+        if nerr:
+            # the one-launch scan rests on its workgroups being co-resident (include/seqrec_hip.h, "Hidden state"): where that
+            # failed once it may fail again -- the rest of the process scans step-wise (one launch per recurrent product, no
+            # in-kernel wait), so a caller that catches this error and retries the step makes progress
+            _lib.load().seqrec_debug_scan_cluster(0)
+            msgs.append("the cluster form of the scans is now OFF for this process (step-wise form from here on)")
         raise _lib.SeqrecError("device-side failure at or before training step %d: %s" % (self.step_count, "; ".join(msgs)))
 
     # ------------------------------------------------------------------ utilities

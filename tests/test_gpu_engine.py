@@ -514,3 +514,41 @@ def test_one_call_cell_equals_the_call_by_call_step(case):
         # three steps apart only by the rounding of the scatter's float atomics; a flipped +-lr Adagrad move would be 2 lr = 0.04
         assert d_ <= 5e-4 * max(1.0, float(b.P[k].abs().max().item())), (k, d_)
     a.check_status(); b.check_status()
+
+
+def test_scan_timeout_raises_then_the_retry_runs_stepwise_and_matches_the_oracle():
+    """the one-launch scans rest on co-residency of their workgroups, which the runtime does not guarantee.  A wait that
+    runs out (forced here: spin limit 1) poisons the scan's output, the update is refused (nothing changes), check_status raises --
+    and switches the process to the step-wise form, so that a caller who catches the error and repeats the step trains on: the
+    retried steps match the oracle, which only ever saw healthy steps."""
+    import importlib
+    import torch
+    B = importlib.import_module("seq-recommendations_amd.batching")
+    Lb = importlib.import_module("seq-recommendations_amd._lib")
+    lib = Lb.load()
+    rng = np.random.default_rng(9)
+    ecfg, ocfg = make_cfg(cell="gru", act="relu", H=256, V=900, inp="embed", out="sampled", D=256, K=128)
+    pair = Pair(ecfg, ocfg, init_np_params(rng, ocfg, 900, 256, 256))
+    eng = pair.eng
+    sess = [make_sessions(rng, 40, 900, 2, 12) for _ in range(3)]
+    lg, lo, _ = pair.step(sess[0], 0, lr=0.01)
+    assert abs(lg - lo) <= 1e-4 * max(1.0, abs(lo))
+    before = {k: v.clone() for k, v in eng.P.items()}
+    try:
+        lib.seqrec_debug_cluster_spin_limit(1)
+        eng.train_step(eng.upload(B.pack_sessions(sess[1])), lr=0.01, step=1)
+        with pytest.raises(Lb.SeqrecError, match="step-wise form from here on"):
+            eng.check_status()
+    finally:
+        lib.seqrec_debug_cluster_spin_limit(0)
+    try:
+        for k, v in eng.P.items():
+            assert torch.equal(v, before[k]), k          # the poisoned step was refused as a whole
+        eng.step_count = 1
+        for step in (1, 2):                              # the retry, now step-wise
+            lg, lo, _ = pair.step(sess[step], step, lr=0.01)
+            assert abs(lg - lo) <= 1e-4 * max(1.0, abs(lo)), (step, lg, lo)
+        eng.check_status()
+        assert max(pair.max_param_diff().values()) < 2e-3
+    finally:
+        lib.seqrec_debug_scan_cluster(-1)                # back to the default form for the tests that follow
