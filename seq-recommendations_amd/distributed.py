@@ -480,8 +480,8 @@ class ShardedEngine(Engine):
             raise NotImplementedError("ShardedEngine: a per-item output bias is not sharded (the BASELINE configs have none)")
         if (cfg.drop_in or cfg.drop_out or cfg.drop_rec) and _ceil4(cfg.D) != _pad_h(cfg.H):
             raise NotImplementedError("ShardedEngine: dropout is wired into the unified step (D == H after padding) only")
-        if cfg.merge != "atomic":
-            raise NotImplementedError("ShardedEngine: the sorted (bitwise-reproducible) row-gradient merge is single-GPU only")
+        if cfg.merge != "atomic" and _ceil4(cfg.D) != _pad_h(cfg.H):
+            raise NotImplementedError("ShardedEngine: the sorted (bitwise-reproducible) row-gradient merge covers the unified step (D == H after padding)")
         self.dist, self.group = dist, group
         self.R = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -1202,9 +1202,16 @@ class ShardedEngine(Engine):
         call("seqrec_exchange_grad_pack", ptr(d["back_idx"]), plan.n_tot, n, K, w, ptr(dX), nsx, ssx, ptr(r["Hd"]), ptr(r["dlt"]),
              ptr(dEn), nsn, ssn, ptr(backbuf), st)
         gback = self.ex.push_seg(plan, backbuf)                                 # collective 2
-        job, cnt = _lib.rows_jobs([dict(table=self.TT, accum=self.TA, gtab=self.TG, slot=self.TS, rows=rows_eff, vals=gback,
-                                        ldv=w, row_scale=None, n=plan.m_tot, width=w, base=0)])
-        call("seqrec_rows_scatter_add_multi", job, cnt, st)
+        jobs = [dict(table=self.TT, accum=self.TA, gtab=self.TG, slot=self.TS, rows=rows_eff, vals=gback, ldv=w, row_scale=None,
+                     n=plan.m_tot, width=w, base=0, name="T")]
+        job, cnt = _lib.rows_jobs(jobs)
+        if c.merge == "sorted":
+            # the deterministic merge (round 4; csrc/merge.hip): the received row gradients sorted by row (stable) and summed per row in
+            # arrival order -- with the slab sums of grad_pack (slab order) and the fixed-order norms, a rank's update repeats bit for
+            # bit given the same received bytes; what the reference's dense Adagrad gives on one device (experiments_methods.py:41)
+            self._merge_sorted(jobs)
+        else:
+            call("seqrec_rows_scatter_add_multi", job, cnt, st)
         self._last = {"gback": gback, "send_idx": rows_eff, "n": n, "m_tot": plan.m_tot, "n_tot": plan.n_tot, "prev": d["prev"]}    # what a failure report names
         if not apply_update:
             return None
@@ -1214,7 +1221,12 @@ class ShardedEngine(Engine):
         cur = self.norms[0:1] if self._norm_par == 0 else self.norms[2:3]
         nxt = self.norms[2:3] if self._norm_par == 0 else self.norms[0:1]
         self._norm_par ^= 1
-        call("seqrec_opt_sqnorm", 0, None, None, job, cnt, ptr(cur), ptr(r["loss_rows"]), n, ptr(self.loss_out), st)
+        if c.merge == "sorted":
+            npart = int(_lib.load().seqrec_opt_sqnorm_ordered_floats(0, cnt, plan.m_tot))
+            call("seqrec_opt_sqnorm_ordered", 0, None, None, job, cnt, ptr(self.buf("sq_partials", npart)), npart, ptr(cur), 0,
+                 ptr(r["loss_rows"]), n, ptr(self.loss_out), st)
+        else:
+            call("seqrec_opt_sqnorm", 0, None, None, job, cnt, ptr(cur), ptr(r["loss_rows"]), n, ptr(self.loss_out), st)
         self.dist.all_reduce(cur, group=self.group)                             # collective 3: one float
         torch.cuda.current_stream(self.dev).wait_stream(self.side)              # dense gradients reduced, their fixed-order norm in norms[1]
         dk, pp, pa, gp, nn, _ = self._dense_arrays()
