@@ -369,6 +369,11 @@ int64_t seqrec_cell_plan_bytes(void);          /* sizeof(seqrec_cell_plan): bind
  *        -> table row row_offset + id, copied to sendbuf[neg_slots[i]]; id row r of peer p (id_rows[p * n_id_rows / R + r])
  *        carries the draws' global ids id * id_mul + id_add bit-cast into the float buffer.  rows_eff[j] (m_tot) receives
  *        the table row every owner-side row stands for (-1: none) -- the scatter list of the returning gradients.
+ *        bias_table / bias_out / bias_rows (nullable, together; ABI 5): the per-item OUTPUT BIAS of a sampled model
+ *        (`Dense(n_classes)` of RNNBaseline, model.py:257) travels beside the rows -- bias_out[j] = bias_table[row - row_offset] for
+ *        rows of the output table and for my draws, 0 elsewhere (one float per owner-side row, moved by an all-to-all with the
+ *        rows' split sizes); bias_rows[j] = that bias row or -1: the scatter list of the bias gradients that return in the same
+ *        positions (exchange_grad_pack bias_grad[j] = dlt of a target row, dbn[k] = sum_i dlogits[i,k] of negative k, else 0).
  *      exchange_unpack (requester, after it): Eneg[k,:] = recv[neg_rows[k],:], neg[k] = ((int32*)recv)[negid_idx[k]],
  *        lq_neg[k] = logq[neg[k]] (nullable; the ids were written by a peer: one outside [0, logq_rows) reads 0 and sets
  *        SEQREC_STATUS_BAD_INDEX in *status, ABI 5).
@@ -378,13 +383,14 @@ int64_t seqrec_cell_plan_bytes(void);          /* sizeof(seqrec_cell_plan): bind
 int seqrec_exchange_pack(const float* table, int64_t table_rows, int width, const int32_t* kinds, const int32_t* got,
                          int64_t got_len, int64_t m_tot, uint64_t seed, uint64_t step, int n_neg, const uint32_t* thresh, const int32_t* alias, int V_local,
                          int32_t row_offset, const int32_t* neg_slots, const int32_t* id_rows, int n_id_rows, int per_peer,
-                         int32_t id_mul, int32_t id_add, float* sendbuf, int32_t* rows_eff, uint32_t* status, void* stream);
+                         int32_t id_mul, int32_t id_add, float* sendbuf, int32_t* rows_eff, uint32_t* status,
+                         const float* bias_table, float* bias_out, int32_t* bias_rows, void* stream);
 int seqrec_exchange_unpack(const float* recv, int width, const int32_t* neg_rows, const int32_t* negid_idx, int K,
                            const float* logq, int64_t logq_rows, float* Eneg, int32_t* neg, float* lq_neg, uint32_t* status,
                            void* stream);
 int seqrec_exchange_grad_pack(const int32_t* back_idx, int64_t n_tot, int n, int K, int width, const float* dX, int dx_slabs,
                               int64_t dx_stride, const float* Hd, const float* dlt, const float* dEneg, int dn_slabs,
-                              int64_t dn_stride, float* out, void* stream);
+                              int64_t dn_stride, float* out, const float* dbn, float* bias_grad, void* stream);
 
 /*      HOST routines (no device work, `_host` pointers throughout): the routing arithmetic of a batch of the unified step
  *      (distributed.py RowExchange.plan_unified) -- per-peer request counts; the per-peer lists of requested local rows and

@@ -69,11 +69,11 @@ _SIGS = {
     "seqrec_sampled_softmax_ce": [P, L, P, I, P, P, P, P, P, P, L, I, F, P, P, P],
     "seqrec_sampled_softmax_ce_rows": [P, L, P, I, P, P, P, P, P, L, I, F, P, P, P],
     "seqrec_sampled_softmax_ce_rows_idx": [P, L, P, I, P, L, P, P, P, P, P, L, I, F, P, P, P],
-    "seqrec_exchange_pack": [P, L, I, P, P, L, L, U64, U64, I, P, P, I, I, P, P, I, I, I, I, P, P, P, P],
+    "seqrec_exchange_pack": [P, L, I, P, P, L, L, U64, U64, I, P, P, I, I, P, P, I, I, I, I, P, P, P, P, P, P, P],
     "seqrec_exchange_unpack": [P, I, P, P, I, P, L, P, P, P, P, P],
     "seqrec_train_cell": [P, P],
     "seqrec_cell_plan_bytes": [],
-    "seqrec_exchange_grad_pack": [P, L, I, I, I, P, I, L, P, P, P, I, L, P, P],
+    "seqrec_exchange_grad_pack": [P, L, I, I, I, P, I, L, P, P, P, I, L, P, P, P, P],
     "seqrec_route_count_host": [P, P, L, I, P],
     "seqrec_route_fill_host": [P, P, L, I, L, I, P, P, P, P],
     "seqrec_route_blob_host": [P, I, P, P, P, L, I, I, I, I, P, P, P, P, F, P, P, L],

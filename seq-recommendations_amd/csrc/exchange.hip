@@ -36,6 +36,10 @@ struct PackArgs {
     const int* neg_slots;                          // [n_neg] owner-side row of negative i
     const int* id_rows; int n_id_rows, per_peer, id_rows_per_peer, id_mul, id_add;   // id row (p, r): ids of negatives p*per_peer + r*width + c
     float* sendbuf; int* rows_eff; unsigned* status;
+    // per-item output bias (nullable, all three together): bias_out[j] = the bias of the item owner-side row j stands for (rows of
+    // the output table and my draws; 0 elsewhere), bias_rows[j] = its row in the bias table or -1 -- the scatter list of the
+    // bias gradients that come back in the same positions
+    const float* bias_table; float* bias_out; int* bias_rows;
 };
 __global__ void exchange_pack_kernel(PackArgs a) {
     const int lane = threadIdx.x & 63;
@@ -50,9 +54,16 @@ __global__ void exchange_pack_kernel(PackArgs a) {
         }
         int r = k;
         if (k >= a.table_rows) { if (lane == 0 && a.status) atomicOr(a.status, (unsigned)SEQREC_STATUS_BAD_INDEX); r = -1; }
-        if (k == -1) { if (lane == 0) a.rows_eff[wv] = -1; return; }      // id rows are written whole by their own waves below
+        if (k == -1) { if (lane == 0) { a.rows_eff[wv] = -1; if (a.bias_out) { a.bias_out[wv] = 0.f; a.bias_rows[wv] = -1; } } return; }      // id rows are written whole by their own waves below
         copy_row(a.sendbuf + wv * a.width, r >= 0 ? a.table + (long)r * a.width : nullptr, a.width, lane);
-        if (lane == 0) a.rows_eff[wv] = r;
+        if (lane == 0) {
+            a.rows_eff[wv] = r;
+            if (a.bias_out) {
+                const int br = r >= a.row_offset ? r - a.row_offset : -1;      // rows of the output table carry a bias (tied: every row)
+                a.bias_out[wv] = br >= 0 ? a.bias_table[br] : 0.f;
+                a.bias_rows[wv] = br;
+            }
+        }
         return;
     }
     long i = wv - a.m_tot;
@@ -60,7 +71,10 @@ __global__ void exchange_pack_kernel(PackArgs a) {
         const int id = draw_alias(a.key, a.step, a.n_neg, (int)i, a.thresh, a.alias, a.V_local);
         const int r = a.row_offset + id, pos = a.neg_slots[i];
         copy_row(a.sendbuf + (long)pos * a.width, a.table + (long)r * a.width, a.width, lane);
-        if (lane == 0) a.rows_eff[pos] = r;
+        if (lane == 0) {
+            a.rows_eff[pos] = r;
+            if (a.bias_out) { a.bias_out[pos] = a.bias_table[id]; a.bias_rows[pos] = id; }
+        }
         return;
     }
     i -= a.n_neg;
@@ -99,12 +113,15 @@ struct GradPackArgs {
     const float* Hd; const float* dlt;
     const float* dEneg; int dn_slabs; long dn_stride;
     float* out;
+    const float* dbn; float* bias_grad;              // nullable: bias_grad[j] = dlt of a target row / dbn[k] of negative k / 0
 };
 __global__ void exchange_grad_pack_kernel(GradPackArgs a) {
     const int lane = threadIdx.x & 63;
     const long j = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (j >= a.n_tot) return;
     const int b = a.back_idx[j];
+    if (a.bias_grad && lane == 0)
+        a.bias_grad[j] = (b >= a.n && b < 2 * a.n) ? a.dlt[b - a.n] : ((b >= 2 * a.n && b < 2 * a.n + a.K) ? a.dbn[b - 2 * a.n] : 0.f);
     float* dst = a.out + j * a.width;
     const int w4 = a.width / 4;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -133,7 +150,9 @@ extern "C" int seqrec_exchange_pack(const float* table, int64_t table_rows, int 
                                     int64_t got_len, int64_t m_tot, uint64_t seed, uint64_t step, int n_neg, const uint32_t* thresh, const int32_t* alias,
                                     int V_local, int32_t row_offset, const int32_t* neg_slots, const int32_t* id_rows,
                                     int n_id_rows, int per_peer, int32_t id_mul, int32_t id_add, float* sendbuf,
-                                    int32_t* rows_eff, uint32_t* status, void* stream) {
+                                    int32_t* rows_eff, uint32_t* status, const float* bias_table, float* bias_out,
+                                    int32_t* bias_rows, void* stream) {
+    if ((bias_table || bias_out || bias_rows) && !(bias_table && bias_out && bias_rows)) return SEQREC_E_ARG;
     if (m_tot < 0 || width <= 0 || (width & 3) || n_neg < 0 || n_id_rows < 0 || table_rows <= 0) return SEQREC_E_ARG;
     if (!table || !kinds || !sendbuf || !rows_eff || (got && got_len < 0)) return SEQREC_E_ARG;
     if (n_neg > 0 && (!thresh || !alias || !neg_slots || V_local <= 0 || per_peer <= 0 || n_neg % per_peer)) return SEQREC_E_ARG;
@@ -147,6 +166,7 @@ extern "C" int seqrec_exchange_pack(const float* table, int64_t table_rows, int 
     a.thresh = thresh; a.alias = alias; a.neg_slots = neg_slots; a.id_rows = id_rows; a.n_id_rows = n_id_rows;
     a.per_peer = per_peer; a.id_rows_per_peer = n_neg > 0 ? n_id_rows / (n_neg / per_peer) : 1; a.id_mul = id_mul; a.id_add = id_add;
     a.sendbuf = sendbuf; a.rows_eff = rows_eff; a.status = status;
+    a.bias_table = bias_table; a.bias_out = bias_out; a.bias_rows = bias_rows;
     hipLaunchKernelGGL(exchange_pack_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, as_stream(stream), a);
     SEQREC_LAUNCH_CHECK();
     return 0;
@@ -167,7 +187,9 @@ extern "C" int seqrec_exchange_unpack(const float* recv, int width, const int32_
 
 extern "C" int seqrec_exchange_grad_pack(const int32_t* back_idx, int64_t n_tot, int n, int K, int width, const float* dX,
                                          int dx_slabs, int64_t dx_stride, const float* Hd, const float* dlt, const float* dEneg,
-                                         int dn_slabs, int64_t dn_stride, float* out, void* stream) {
+                                         int dn_slabs, int64_t dn_stride, float* out, const float* dbn, float* bias_grad,
+                                         void* stream) {
+    if (bias_grad && K > 0 && !dbn) return SEQREC_E_ARG;
     if (n_tot < 0 || n < 0 || K < 0 || width <= 0 || (width & 3) || dx_slabs < 1 || dn_slabs < 1) return SEQREC_E_ARG;
     if (n_tot == 0) return 0;
     if (!back_idx || !out || (n > 0 && (!dX || !Hd || !dlt)) || (K > 0 && !dEneg)) return SEQREC_E_ARG;
@@ -178,6 +200,7 @@ extern "C" int seqrec_exchange_grad_pack(const int32_t* back_idx, int64_t n_tot,
     a.back_idx = back_idx; a.n_tot = (long)n_tot; a.n = n; a.K = K; a.width = width;
     a.dX = dX; a.dx_slabs = dx_slabs; a.dx_stride = (long)dx_stride; a.Hd = Hd; a.dlt = dlt;
     a.dEneg = dEneg; a.dn_slabs = dn_slabs; a.dn_stride = (long)dn_stride; a.out = out;
+    a.dbn = dbn; a.bias_grad = bias_grad;
     hipLaunchKernelGGL(exchange_grad_pack_kernel, dim3((unsigned)((n_tot + 3) / 4)), dim3(256), 0, as_stream(stream), a);
     SEQREC_LAUNCH_CHECK();
     return 0;

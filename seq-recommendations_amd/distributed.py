@@ -476,8 +476,8 @@ class ShardedEngine(Engine):
     def __init__(self, cfg, device, dist, group=None):
         if cfg.input != "embed" or cfg.output != "sampled":
             raise ValueError("ShardedEngine shards item tables: it needs input='embed', output='sampled'")
-        if cfg.out_bias:
-            raise NotImplementedError("ShardedEngine: a per-item output bias is not sharded (the BASELINE configs have none)")
+        if cfg.out_bias and _ceil4(cfg.D) != _pad_h(cfg.H):
+            raise NotImplementedError("ShardedEngine: the per-item output bias rides in the unified step (D == H after padding) only")
         if (cfg.drop_in or cfg.drop_out or cfg.drop_rec) and _ceil4(cfg.D) != _pad_h(cfg.H):
             raise NotImplementedError("ShardedEngine: dropout is wired into the unified step (D == H after padding) only")
         if cfg.merge != "atomic" and _ceil4(cfg.D) != _pad_h(cfg.H):
@@ -589,6 +589,16 @@ class ShardedEngine(Engine):
                                % (self.step_count, who, self.R, "; ".join(msgs)))
 
     # ---- helpers -----------------------------------------------------------------------------------
+    def _neg_ones(self, n):
+        t = self.ws.get("_neg_ones")
+        if t is None or t.numel() < n:
+            t = self.ws["_neg_ones"] = torch.full((max(n, 4096),), -1.0, dtype=torch.float32, device=self.dev)
+        return t
+
+    def _lq_tgt(self, d):
+        """The per-target vector the CE kernel subtracts: log-Q of the targets, minus their output bias when the model has one."""
+        return self._lq_tgt_adj if self.cfg.out_bias else d.get("lq_tgt")
+
     def _take(self, src, idx, out=None):
         if out is None:
             out = torch.empty((idx.numel(), src.shape[1]), dtype=src.dtype, device=self.dev)
@@ -787,7 +797,7 @@ class ShardedEngine(Engine):
         dlt = self.buf("dlt", n)
         loss_rows = self.buf("loss_rows", n)
         # gradients stay SUMS (inv_denom 1): the global token count divides them in the update (seqrec_opt_apply grad_div)
-        call("seqrec_sampled_softmax_ce_rows_idx", ptr(ln), K, ptr(Hd), Hp, ptr(recv), w, ptr(d["take_tgt"]), ptr(d.get("lq_tgt")),
+        call("seqrec_sampled_softmax_ce_rows_idx", ptr(ln), K, ptr(Hd), Hp, ptr(recv), w, ptr(d["take_tgt"]), ptr(self._lq_tgt(d)),
              ptr(lq_neg), ptr(d["tgt"]), ptr(neg), n, K, 1.0, ptr(loss_rows), ptr(dlt), st, prof_name="seqrec_sampled_softmax_ce")
         r = {"Hd": Hd, "dlt": dlt, "loss_rows": loss_rows, "Hout": Hout}
         if not train:
@@ -882,7 +892,7 @@ class ShardedEngine(Engine):
         pl.XW, pl.Hout, pl.gates, pl.aux = ptr(XW), ptr(Hout), ptr(gates), ptr(aux)
         pl.Eneg, pl.neg, pl.lq_neg = ptr(Eneg), ptr(neg), ptr(lq_neg)
         pl.ln, pl.dlt, pl.loss_rows = ptr(ln), ptr(dlt), ptr(lrows)
-        pl.tgt_table, pl.tgt_ld, pl.tgt_index, pl.tgt_ids, pl.lq_tgt = ptr(recv), w, ptr(d["take_tgt"]), ptr(d["tgt"]), ptr(d.get("lq_tgt"))
+        pl.tgt_table, pl.tgt_ld, pl.tgt_index, pl.tgt_ids, pl.lq_tgt = ptr(recv), w, ptr(d["take_tgt"]), ptr(d["tgt"]), ptr(self._lq_tgt(d))
         pl.logq_table = None
         pl.dHd, pl.gemm_ws, pl.sk_dh, pl.sk_deneg, pl.dEneg_slabs = ptr(dHd), ptr(wsp), sk_h, sk_e, ptr(dEs)
         pl.sk_wgrad, pl.wgrad_ws = sk_w, ptr(wsp)
@@ -1053,17 +1063,41 @@ class ShardedEngine(Engine):
         th, al, _ = self.sampler
         sendbuf = self.buf("sendbuf", plan.m_tot, w)
         rows_eff = self.buf("rows_eff", plan.m_tot, dtype=torch.int32)
+        bias_out = bias_rows = None
+        if c.out_bias:       # the per-item output bias (RNNBaseline's Dense bias, model.py:257) travels beside the rows: one float per row
+            bias_out = self.buf("bias_send", plan.m_tot)
+            bias_rows = self.buf("bias_rows", plan.m_tot, dtype=torch.int32)
         call("seqrec_exchange_pack", ptr(self.TT), self.TT.shape[0], w, ptr(d["send_idx"]), ptr(plan.got_pad), plan.got_pad.numel() - 1,
              plan.m_tot, int(c.seed), int(step) * R + self.rank,
              R * Kr, ptr(th), ptr(al), c.V_out, self.off_out, ptr(d["neg_slots"]), ptr(d["id_rows"]), R * nid, Kr, R, self.rank,
-             ptr(sendbuf), ptr(rows_eff), ptr(self.status), st)
+             ptr(sendbuf), ptr(rows_eff), ptr(self.status), ptr(self.P["bout"] if c.out_bias else None), ptr(bias_out), ptr(bias_rows), st)
         recv = self.ex.fetch_seg(plan, sendbuf)                                 # collective 1
+        self._recv_bias = self.ex.fetch_seg(plan, bias_out) if c.out_bias else None      # (+ one all-to-all of n_tot floats with a bias)
+        self._bias_rows = bias_rows
         Eneg = self.buf("Eneg", K, w)
         neg = self.buf("neg", K, dtype=torch.int32)
         lq_neg = self.buf("lq_neg", K) if (c.logq and self.logq_global is not None) else None
         call("seqrec_exchange_unpack", ptr(recv), w, ptr(d["neg_rows"]), ptr(d["negid_idx"]), K,
              ptr(self.logq_global if lq_neg is not None else None), self.V_global, ptr(Eneg), ptr(neg), ptr(lq_neg),
              ptr(self.status), st)
+        if c.out_bias:
+            # logit = h . e + bias - logQ: the CE kernels subtract one vector per candidate and one per target, so the bias enters as
+            # (logQ - bias) -- gathered from the received bias values through the rows' positions, no kernel of its own
+            rb_ = self._recv_bias
+            none = self._neg_ones(max(K, d["n"]))
+            adj_n = self.buf("lqb_neg", K)
+            adj_t = self.buf("lqb_tgt", d["n"])
+            for adj, base, idx, m in ((adj_n, lq_neg, d["neg_rows"], K), (adj_t, d.get("lq_tgt"), d["take_tgt"], d["n"])):
+                if base is not None:
+                    adj.copy_(base)
+                else:
+                    adj.zero_()
+                call("seqrec_gather_rows_bounded", ptr(rb_), rb_.numel(), ptr(idx), ptr(adj), m, 1, ptr(none), None, 1, ptr(self.status), st,
+                     prof_name="seqrec_gather_rows")
+            lq_neg = adj_n
+            self._lq_tgt_adj = adj_t
+        else:
+            self._lq_tgt_adj = None
         return recv, Eneg, neg, lq_neg, rows_eff
 
     def eval_loss(self, d, negatives=None, step=0):
@@ -1088,7 +1122,7 @@ class ShardedEngine(Engine):
         if self.unified:
             recv = self._rows_in(d, 0)[0]
             Hd = self._hidden(d, recv)
-            call("seqrec_target_score", ptr(Hd), w, ptr(recv), None, ptr(d["take_tgt"]), n, ptr(thr), st)
+            call("seqrec_target_score", ptr(Hd), w, ptr(recv), ptr(self._recv_bias), ptr(d["take_tgt"]), n, ptr(thr), st)
         else:                                # D != H: one exchange per table, rows materialised
             X, Etgt, _, _, _ = self._split_rows(d, 0, negatives=False)
             Hd = self._hidden(d, None, X=X)
@@ -1114,7 +1148,7 @@ class ShardedEngine(Engine):
         tgt_local = torch.where((tg >= 0) & (tg % R == self.rank), tg // R, torch.full_like(tg, -1)).to(torch.int32)
         counts = torch.zeros(R * nmax, dtype=torch.int32, device=self.dev)
         Et = self.P["E" if c.tied else "Eout"]
-        call("seqrec_rank_count_thr", ptr(Hall), w, ptr(Et), None, ptr(tgt_local), ptr(thr_all), R * nmax, Et.shape[0],
+        call("seqrec_rank_count_thr", ptr(Hall), w, ptr(Et), ptr(self.P.get("bout")), ptr(tgt_local), ptr(thr_all), R * nmax, Et.shape[0],
              ptr(counts), st)
         self.dist.all_reduce(counts, group=self.group)
         return counts[self.rank * nmax: self.rank * nmax + n].clone()
@@ -1155,7 +1189,7 @@ class ShardedEngine(Engine):
         for c0 in range(0, Vl, ch):
             wd = min(ch, Vl - c0)
             self.gemm(1, 1, rows_all, wd, w, Hall, w, Et[c0:c0 + wd], w, sc, ch, tag="topk")
-            call("seqrec_topk_merge", ptr(sc), ch, rows_all, wd, c0, None, ptr(sv), ptr(si), st)
+            call("seqrec_topk_merge", ptr(sc), ch, rows_all, wd, c0, ptr(self.P.get("bout")), ptr(sv), ptr(si), st)
         gi = torch.where(si >= 0, si * R + self.rank, si)                # local row -> global item id
         cand_v = self.ex.swap_fixed(sv.view(R, mmax, 64))                 # [R, mmax, 64]: candidates of MY rows from every shard
         cand_i = self.ex.swap_fixed(gi.view(R, mmax, 64))
@@ -1199,11 +1233,20 @@ class ShardedEngine(Engine):
         # -- row gradients travel the same routes back: the routing launch reads dX / dEneg as split-K slabs and dlt * Hd in place
         backbuf = self.buf("backbuf", plan.n_tot, w)
         (dX, nsx, ssx), (dEn, nsn, ssn) = r["dX"], r["dEneg"]
+        dbn = bias_grad = None
+        if c.out_bias:       # d loss / d bias: dlt for a target, the column sum of dlogits for a negative; same routes back
+            dbn = self.buf("dbn", K)
+            call("seqrec_colsum", ptr(self.buf("ln", n, K)), n, K, K, ptr(dbn), 0, ptr(self.buf("colsum_ws", 64 * K)), st)
+            bias_grad = self.buf("bias_back", plan.n_tot)
         call("seqrec_exchange_grad_pack", ptr(d["back_idx"]), plan.n_tot, n, K, w, ptr(dX), nsx, ssx, ptr(r["Hd"]), ptr(r["dlt"]),
-             ptr(dEn), nsn, ssn, ptr(backbuf), st)
+             ptr(dEn), nsn, ssn, ptr(backbuf), ptr(dbn), ptr(bias_grad), st)
         gback = self.ex.push_seg(plan, backbuf)                                 # collective 2
+        gbias = self.ex.push_seg(plan, bias_grad) if c.out_bias else None       # (+ one all-to-all of m_tot floats with a bias)
         jobs = [dict(table=self.TT, accum=self.TA, gtab=self.TG, slot=self.TS, rows=rows_eff, vals=gback, ldv=w, row_scale=None,
                      n=plan.m_tot, width=w, base=0, name="T")]
+        if c.out_bias:       # the bias gradients: a width-1 scatter list over the same owner-side rows
+            jobs.append(dict(table=self.P["bout"], accum=self.A["bout"], gtab=self.Gt["bout"], slot=self.slot["bout"], rows=self._bias_rows,
+                             vals=gbias, ldv=1, row_scale=None, n=plan.m_tot, width=1, base=0, name="bout"))
         job, cnt = _lib.rows_jobs(jobs)
         if c.merge == "sorted":
             # the deterministic merge (round 4; csrc/merge.hip): the received row gradients sorted by row (stable) and summed per row in
@@ -1211,7 +1254,9 @@ class ShardedEngine(Engine):
             # bit given the same received bytes; what the reference's dense Adagrad gives on one device (experiments_methods.py:41)
             self._merge_sorted(jobs)
         else:
-            call("seqrec_rows_scatter_add_multi", job, cnt, st)
+            for j1 in jobs:          # one launch per list: lists of different widths would lose the combining form
+                a1, c1 = _lib.rows_jobs([j1])
+                call("seqrec_rows_scatter_add_multi", a1, c1, st)
         self._last = {"gback": gback, "send_idx": rows_eff, "n": n, "m_tot": plan.m_tot, "n_tot": plan.n_tot, "prev": d["prev"]}    # what a failure report names
         if not apply_update:
             return None

@@ -56,7 +56,9 @@ def main():
                  dict(cell="lstm", V=1100, H=512, Dm=512, K=48 * R, tied=False),        # c4's cell: LSTM 512, row-sharded
                  # dropout in the sharded step: the reference's main run trains with z_to_y_drop = 0.3 (experiments_server.py:108-114)
                  dict(cell="lstm", V=1000, H=128, Dm=128, K=40 * R, tied=False, drop=dict(drop_out=0.3)),
-                 dict(cell="gru", V=950, H=128, Dm=128, K=40 * R, tied=True, drop=dict(drop_in=0.1, drop_rec=0.2, drop_out=0.3))):
+                 dict(cell="gru", V=950, H=128, Dm=128, K=40 * R, tied=True, drop=dict(drop_in=0.1, drop_rec=0.2, drop_out=0.3)),
+                 # a per-item output bias (RNNBaseline's Dense(n_classes) bias, model.py:257) row-sharded with the output table
+                 dict(cell="gru", V=1000, H=128, Dm=128, K=40 * R, tied=False, out_bias=True)):
         V, H, Dm, K, tied, cell = case["V"], case["H"], case["Dm"], case["K"], case["tied"], case["cell"]
         G = onn.N_GATES[cell]
         rs = np.random.default_rng(4)                       # identical on every rank: the GLOBAL model
@@ -64,11 +66,14 @@ def main():
              "b": rs.normal(0, 0.1, (G * H,))}
         if not tied:
             p["Eout"] = rs.normal(0, 0.3, (V, H))
+        obias = bool(case.get("out_bias", False))
+        if obias:
+            p["bout"] = rs.normal(0, 0.3, (V,))
         p = {k: v.astype(np.float32) for k, v in p.items()}
         probs = Sm.log_uniform_probs(V)
         dropkw = case.get("drop", {})
         cfg = E.NetConfig(cell=cell, act="relu", H=H, V_in=V, V_out=V, input="embed", D=Dm, output="sampled", K=K, tied=tied,
-                          logq=True, seed=9, **dropkw)
+                          logq=True, seed=9, out_bias=obias, **dropkw)
         eng = D.ShardedEngine(cfg, "cuda:0", D.HostStagedDist(dist, verify=True))
         eng.debug_capture = True             # keeps this rank's own dense gradients of the last step for the failure report
         for k in ("W", "U", "b"):
@@ -76,6 +81,8 @@ def main():
         eng.set_param("E", p["E"][rank::R])
         if not tied:
             eng.set_param("Eout", p["Eout"][rank::R])
+        if obias:
+            eng.set_param("bout", p["bout"][rank::R])
         tables = []
         for j in range(R):
             pl = probs[j::R] / probs[j::R].sum()
@@ -112,14 +119,17 @@ def main():
                   eng._hidden(d, None, X=eng._split_rows(d, 0, negatives=False)[0])).cpu().numpy()[:, :H]
             tname = "E" if tied else "Eout"
             info = [None] * R
-            dist.all_gather_object(info, (rk, hd, d["tgt"].cpu().numpy(), eng.get_param(tname)))
+            dist.all_gather_object(info, (rk, hd, d["tgt"].cpu().numpy(), eng.get_param(tname), eng.get_param("bout") if obias else None))
             if rank == 0:
                 table = np.zeros((V, H), np.float32)
+                bvec = np.zeros(V, np.float64)
                 for j in range(R):
                     table[j::R] = info[j][3]
+                    if obias:
+                        bvec[j::R] = info[j][4]
                 for j in range(R):
-                    rkj, hj, tj, _ = info[j]
-                    sc = hj.astype(np.float64) @ table.T.astype(np.float64)
+                    rkj, hj, tj = info[j][:3]
+                    sc = hj.astype(np.float64) @ table.T.astype(np.float64) + bvec[None, :]
                     ref = (sc > sc[np.arange(len(tj)), tj][:, None]).sum(1)
                     assert (rkj == ref).mean() > 0.97 and np.abs(rkj - ref).max() <= 2, (case, j, np.abs(rkj - ref).max())
                 print("rank counts ok:", case["cell"], "tied" if tied else "untied")
@@ -129,8 +139,8 @@ def main():
             dist.all_gather_object(tk, (ti.cpu().numpy(), tv.cpu().numpy()))
             if rank == 0:
                 for j in range(R):
-                    _, hj, _, _ = info[j]
-                    sc = hj.astype(np.float64) @ table.T.astype(np.float64)
+                    hj = info[j][1]
+                    sc = hj.astype(np.float64) @ table.T.astype(np.float64) + bvec[None, :]
                     ref = np.argsort(-sc, axis=1, kind="stable")[:, :10]
                     gi_, gv_ = tk[j]
                     assert gi_.shape == ref.shape and (gi_ == ref).mean() > 0.99, (case, j, (gi_ == ref).mean())
@@ -140,6 +150,8 @@ def main():
                "E": eng.get_param("E")}
         if not tied:
             got["Eout"] = eng.get_param("Eout")
+        if obias:
+            got["bout"] = eng.get_param("bout")
         allgot = [None] * R
         dist.all_gather_object(allgot, got)
         scales = [None] * R
@@ -149,7 +161,7 @@ def main():
             for r in range(1, R):
                 assert np.array_equal(allgot[r][k], allgot[0][k]), ("replicated weights differ between ranks", case, k, r)
         if rank == 0:
-            ocfg = dict(cell=cell, act="relu", input="embed", output="sampled", tied=tied, use_bias=True, out_bias=False)
+            ocfg = dict(cell=cell, act="relu", input="embed", output="sampled", tied=tied, use_bias=True, out_bias=obias)
             op = {k: v.copy() for k, v in p.items()}
             acc = {k: np.zeros_like(v) for k, v in op.items()}
             net = onn.OracleNet(ocfg, op)
@@ -198,7 +210,7 @@ def main():
                 for k in ("W", "U", "b"):
                     err = np.abs(allgot[r][k] - op[k]).max() / max(1e-6, np.abs(op[k]).max())
                     assert err < 2e-3, (case, r, k, err)
-                for k in (("E",) if tied else ("E", "Eout")):
+                for k in (("E",) if tied else ("E", "Eout")) + (("bout",) if obias else ()):
                     ref = op[k][r::R]
                     diff = np.abs(allgot[r][k] - ref)
                     # Adagrad's lr*sign(g) steps on numerically-zero gradients can flip: allow a vanishing fraction

@@ -418,7 +418,7 @@ def test_sharded_engine_ranks_share_one_gpu_vs_global_oracle(world, poison):
            "127.0.0.1", "--master-port", str(29640 + world + (10 if poison else 0)), os.path.join(here, "dist_gpu_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
-    assert r.stdout.count("case ok") == 6 and r.stdout.count("rank counts ok") == 6 and r.stdout.count("sharded topk ok") == 6
+    assert r.stdout.count("case ok") == 7 and r.stdout.count("rank counts ok") == 7 and r.stdout.count("sharded topk ok") == 7
 
 
 def test_device_side_failure_raises_instead_of_training_on():
