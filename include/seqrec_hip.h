@@ -100,7 +100,9 @@ enum {
 enum { SEQREC_CELL_SIMPLERNN = 0, SEQREC_CELL_LSTM = 1, SEQREC_CELL_GRU = 2 };
 /* activation = z_to_z_activation / z_activation (model.py:243,324); recurrent activation is
  * always Keras' hard_sigmoid */
-enum { SEQREC_ACT_RELU = 0, SEQREC_ACT_TANH = 1, SEQREC_ACT_LINEAR = 2 };
+enum { SEQREC_ACT_RELU = 0, SEQREC_ACT_TANH = 1, SEQREC_ACT_LINEAR = 2,
+       /* ABI 5, seqrec_rnn_{fwd,bwd}_stepwise[_parts] only (step-wise form; the cluster form and seqrec_rnn_fwd / _bwd take 0-2): */
+       SEQREC_ACT_SIGMOID = 3, SEQREC_ACT_HARD_SIGMOID = 4, SEQREC_ACT_SOFTPLUS = 5, SEQREC_ACT_SOFTSIGN = 6, SEQREC_ACT_ELU = 7 };
 
 int seqrec_abi_version(void);
 /* name of the gfx target the code objects were built for ("gfx950") */

@@ -57,6 +57,12 @@ def act_fwd(name, pre):
         return 1.0 / (1.0 + np.exp(-pre))
     if name == "hard_sigmoid":
         return hard_sigmoid(pre)
+    if name == "softplus":                       # Keras / Theano T.nnet.softplus
+        return np.where(pre > 20, pre, np.log1p(np.exp(np.minimum(pre, 20))))
+    if name == "softsign":
+        return pre / (1 + np.abs(pre))
+    if name == "elu":                            # alpha = 1
+        return np.where(pre > 0, pre, np.expm1(np.minimum(pre, 0)))
     raise ValueError(name)
 
 
@@ -72,6 +78,12 @@ def act_bwd(name, pre, y):
         return y * (1 - y)
     if name == "hard_sigmoid":
         return d_hard_sigmoid(pre)
+    if name == "softplus":
+        return 1.0 / (1.0 + np.exp(-pre))
+    if name == "softsign":
+        return 1.0 / np.square(1 + np.abs(pre))
+    if name == "elu":
+        return np.where(pre > 0, np.ones_like(pre), np.exp(np.minimum(pre, 0)))
     raise ValueError(name)
 
 

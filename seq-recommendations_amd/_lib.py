@@ -13,7 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEQREC_LIB") or os.path.join(HERE, "libseqrec_hip.so")
 
 CELL = {"simplernn": 0, "lstm": 1, "gru": 2}
-ACT = {"relu": 0, "tanh": 1, "linear": 2}
+ACT = {"relu": 0, "tanh": 1, "linear": 2,
+       # Keras 2.0's other element-wise activations: step-wise form of the scans only (SEQREC_ACT_SIGMOID ... include/seqrec_hip.h)
+       "sigmoid": 3, "hard_sigmoid": 4, "softplus": 5, "softsign": 6, "elu": 7}
 N_GATES = {"simplernn": 1, "lstm": 4, "gru": 3}
 
 # RNG stream ids (specification: oracle/rng.py)

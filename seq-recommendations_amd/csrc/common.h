@@ -32,15 +32,38 @@ __device__ __forceinline__ float hard_sigmoid(float x) { return fminf(fmaxf(0.2f
 // derivative expressed through the gate value g = hard_sigmoid(pre): 0.2 on the open ramp
 __device__ __forceinline__ float hard_sigmoid_grad(float g) { return (g > 0.0f && g < 1.0f) ? 0.2f : 0.0f; }
 
-template <int ACT> __device__ __forceinline__ float act_fwd(float x) {
+// The cell activation (Keras `activation=` of SimpleRNN / LSTM / GRU; model.py:324,346,351 pass any Keras name through).  relu / tanh /
+// linear are template instances of every scan kernel; the rest of Keras 2.0's element-wise list -- sigmoid, hard_sigmoid, softplus,
+// softsign, elu -- shares ONE instance (SEQREC_ACT_OTHER) of the step-wise kernels with the kind as a run-time value `rt`
+// (SEQREC_ACT_SIGMOID ...): nobody's hot path, one third more kernels instead of 2.7x.
+constexpr int SEQREC_ACT_OTHER = 3;
+template <int ACT> __device__ __forceinline__ float act_fwd(float x, int rt = 0) {
     if (ACT == SEQREC_ACT_RELU) return fmaxf(x, 0.0f);
     if (ACT == SEQREC_ACT_TANH) return tanhf(x);
+    if (ACT == SEQREC_ACT_OTHER) {
+        switch (rt) {
+            case SEQREC_ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
+            case SEQREC_ACT_HARD_SIGMOID: return hard_sigmoid(x);
+            case SEQREC_ACT_SOFTPLUS: return x > 20.0f ? x : log1pf(expf(x));
+            case SEQREC_ACT_SOFTSIGN: return x / (1.0f + fabsf(x));
+            case SEQREC_ACT_ELU: return x > 0.0f ? x : expm1f(x);
+        }
+    }
     return x;
 }
-// derivative through the OUTPUT y = act(pre)   (relu'(0) := 0)
-template <int ACT> __device__ __forceinline__ float act_grad(float y) {
+// derivative through the OUTPUT y = act(pre)   (relu'(0) := 0; every activation here has a derivative that is a function of y)
+template <int ACT> __device__ __forceinline__ float act_grad(float y, int rt = 0) {
     if (ACT == SEQREC_ACT_RELU) return y > 0.0f ? 1.0f : 0.0f;
     if (ACT == SEQREC_ACT_TANH) return 1.0f - y * y;
+    if (ACT == SEQREC_ACT_OTHER) {
+        switch (rt) {
+            case SEQREC_ACT_SIGMOID: return y * (1.0f - y);
+            case SEQREC_ACT_HARD_SIGMOID: return hard_sigmoid_grad(y);
+            case SEQREC_ACT_SOFTPLUS: return 1.0f - expf(-y);                       // sigmoid(x) with e^x = e^y - 1
+            case SEQREC_ACT_SOFTSIGN: { const float u = 1.0f - fabsf(y); return u * u; }   // 1 / (1 + |x|)^2 with |x| = |y| / (1 - |y|)
+            case SEQREC_ACT_ELU: return y > 0.0f ? 1.0f : y + 1.0f;                // e^x = y + 1 for x <= 0
+        }
+    }
     return 1.0f;
 }
 

@@ -285,23 +285,23 @@ template <int N> __device__ __forceinline__ void ld_mask(float (&m)[N], const fl
 // LSTM cell arithmetic shared by the step-wise and the cluster kernels (ONE definition, so that both forms round alike)
 template <int ACT>
 __device__ __forceinline__ void lstm_cell_fwd(float pi, float pf, float pc, float po, float cp, bool live, float& gi, float& gf, float& gg,
-                                              float& go, float& c, float& h) {
+                                              float& go, float& c, float& h, int rt = 0) {
 #pragma clang fp contract(off)      // a*b + c*d may contract either way: without this the two forms round c differently
-    gi = hard_sigmoid(pi); gf = hard_sigmoid(pf); gg = act_fwd<ACT>(pc); go = hard_sigmoid(po);
+    gi = hard_sigmoid(pi); gf = hard_sigmoid(pf); gg = act_fwd<ACT>(pc, rt); go = hard_sigmoid(po);
     c = gf * cp + gi * gg;
-    h = go * act_fwd<ACT>(c);
+    h = go * act_fwd<ACT>(c, rt);
     if (!live) { c = 0.f; h = 0.f; }
 }
 // one (row, hidden column) of the LSTM BPTT step: the four pre-activation gradients and dc for the previous token
 template <int ACT>
 __device__ __forceinline__ void lstm_cell_bwd(float dh, float dcin, float gi, float gf, float gg, float go, float cn, float cp,
-                                              float& di, float& df, float& dg, float& dout, float& dc_prev) {
+                                              float& di, float& df, float& dg, float& dout, float& dc_prev, int rt = 0) {
 #pragma clang fp contract(off)
-    const float ac = act_fwd<ACT>(cn);
-    const float dct = dcin + dh * go * act_grad<ACT>(ac);
+    const float ac = act_fwd<ACT>(cn, rt);
+    const float dct = dcin + dh * go * act_grad<ACT>(ac, rt);
     di = dct * gg * hard_sigmoid_grad(gi);
     df = dct * cp * hard_sigmoid_grad(gf);
-    dg = dct * gi * act_grad<ACT>(gg);
+    dg = dct * gi * act_grad<ACT>(gg, rt);
     dout = dh * ac * hard_sigmoid_grad(go);
     dc_prev = dct * gf;
 }

@@ -53,6 +53,7 @@ struct StepArgs {
     const float* rmask;                       // recurrent-dropout multipliers [G][B][H] (sorted session rows) or null
     int B;
     int cbn, xcd;                             // column blocks of this launch; XCD-aware tile placement on/off
+    int act_rt;                               // SEQREC_ACT_* of the call: read by the SEQREC_ACT_OTHER instances only (common.h act_fwd)
 };
 
 // Diagnostic build only (-DSEQREC_STAMP, tools/stamp_probe.py): s_memtime stamps of ONE workgroup per launch (row
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd(StepArgs a_in) {
         bstore(rG, vg, soG, g);
         if (col >= H) bstore(rA, ok ? (row * H + (col - H)) * 4 : INVALID_OFF, soH, g * h0);   // publish r * h_prev
     } else {
-        const float hh = act_fwd<ACT>(acc + xw);
+        const float hh = act_fwd<ACT>(acc + xw, a.act_rt);
         float hn = zg * h0 + (1.f - zg) * hh;
         if (col >= a.H_real) hn = 0.f;
         bstore(rH, vh, soH, hn);
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a_in) {
     if constexpr (PHASE == 0) {
         if (!carried) {
 #pragma unroll
-            for (int j = 0; j < K / 16; ++j) av[j] = dh[j] * (1.f - zz[j]) * act_grad<ACT>(hh[j]);
+            for (int j = 0; j < K / 16; ++j) av[j] = dh[j] * (1.f - zz[j]) * act_grad<ACT>(hh[j], a.act_rt);
             if (cb == 0 && aok) gstore_vec(av, a.dPre + q * GH + 2 * H + koff);
         }
     }
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd(StepArgs a_in) {
         }
         const float dcar = e_t + acc;
         bstore(rC, vh, soP, dcar);
-        bstore(rDP, vg + 2 * H * 4, soGp, (p_dh + dcar) * (1.f - p_z) * act_grad<ACT>(p_hh));      // d of step t-1, ready for its PHASE 0
+        bstore(rDP, vg + 2 * H * 4, soGp, (p_dh + dcar) * (1.f - p_z) * act_grad<ACT>(p_hh, a.act_rt));      // d of step t-1, ready for its PHASE 0
     }
 #ifdef SEQREC_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -424,7 +425,7 @@ __global__ void gru_first_step_fwd(StepArgs a_in) {
     const int row = (int)(e / H), col = (int)(e % H);
     const long q = (long)a.p0 + row, GH = 3L * H;
     const float* xw = a.XW + q * GH + col;
-    const float z = hard_sigmoid(xw[0]), r = hard_sigmoid(xw[H]), hh = act_fwd<ACT>(xw[2 * H]);
+    const float z = hard_sigmoid(xw[0]), r = hard_sigmoid(xw[H]), hh = act_fwd<ACT>(xw[2 * H], a.act_rt);
     float* g = a.gates + q * GH + col;
     g[0] = z; g[H] = r; g[2 * H] = hh;
     a.aux[q * H + col] = 0.f;
@@ -445,7 +446,7 @@ __global__ void gru_first_step_bwd(StepArgs a_in) {
     float* o = a.dPre + q * GH + col;
     o[0] = dh * (0.f - hh) * hard_sigmoid_grad(z);
     o[H] = 0.f;
-    o[2 * H] = dh * (1.f - z) * act_grad<ACT>(hh);
+    o[2 * H] = dh * (1.f - z) * act_grad<ACT>(hh, a.act_rt);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd0_wide(StepArgs a_in) {
     {
         if (!carried) {
 #pragma unroll
-            for (int j = 0; j < KT; ++j) dv[j] = dh[j] * (1.f - zz[j]) * act_grad<ACT>(hh[j]);
+            for (int j = 0; j < KT; ++j) dv[j] = dh[j] * (1.f - zz[j]) * act_grad<ACT>(hh[j], a.act_rt);
             if (cbw == 0 && dok) gstore_vec(dv, a.dPre + (pt + drow) * GH + 2 * H + dk0);
         }
         float* o = ab + drow * LDA + dk0;
@@ -600,7 +601,7 @@ __device__ __forceinline__ void lstm_step_fwd_body(const StepArgs& a_in) {
         }
     }
     float gi, gf, gg, go, c, h;
-    lstm_cell_fwd<ACT>(acc[0] + xw[0], acc[1] + xw[1], acc[2] + xw[2], acc[3] + xw[3], cp, col < a.H_real, gi, gf, gg, go, c, h);
+    lstm_cell_fwd<ACT>(acc[0] + xw[0], acc[1] + xw[1], acc[2] + xw[2], acc[3] + xw[3], cp, col < a.H_real, gi, gf, gg, go, c, h, a.act_rt);
     bstore(rH, vh, soH, h);
     bstore(rC, vh, soH, c);
     bstore(rG, vg, soG, gi);
@@ -641,7 +642,7 @@ __global__ __launch_bounds__(256) void srnn_step_fwd(StepArgs a_in) {
         if (a.rmask) mask_vec(av, a.rmask, a.B, H, 0, r0 + arow, koff, true);
         acc = tile_16x16_reg<H>(av, b, red, tid);
     }
-    float y = act_fwd<ACT>(acc + xw);
+    float y = act_fwd<ACT>(acc + xw, a.act_rt);
     if (col >= a.H_real) y = 0.f;
     bstore(rH, vh, soH, y);
 }
@@ -659,7 +660,7 @@ __global__ void pointwise_bwd_step(StepArgs a_in) {
     float dh = a.dHout[q * H + col];
     if (row < a.bnext) dh += a.dHc[q * H + col];
     if (CELL == SEQREC_CELL_SIMPLERNN) {
-        a.dPre[q * H + col] = dh * act_grad<ACT>(a.Hout[q * H + col]);
+        a.dPre[q * H + col] = dh * act_grad<ACT>(a.Hout[q * H + col], a.act_rt);
     } else {
         const long GH = 4L * H;
         const float* gp = a.gates + q * GH + col;
@@ -668,7 +669,7 @@ __global__ void pointwise_bwd_step(StepArgs a_in) {
         const float cp = a.first ? 0.f : a.aux[((long)a.pprev0 + row) * H + col];
         const float dcin = row < a.bnext ? a.tmpc[q * H + col] : 0.f;      // dc carried from step t+1
         float di, df, dg, dout, dcp;
-        lstm_cell_bwd<ACT>(dh, dcin, gi, gf, gg, go, cn, cp, di, df, dg, dout, dcp);
+        lstm_cell_bwd<ACT>(dh, dcin, gi, gf, gg, go, cn, cp, di, df, dg, dout, dcp, a.act_rt);
         float* o = a.dPre + q * GH + col;
         o[0] = di;
         o[H] = df;
@@ -754,15 +755,19 @@ template <typename KF> int plan_step(Plan& pl, KF kern, dim3 grid, const StepArg
             case 4 * 1 + 0: rc__ = plan_step(pl, KERN<1, 0, PHASE>, GRID, a); break;            \
             case 4 * 1 + 1: rc__ = plan_step(pl, KERN<1, 1, PHASE>, GRID, a); break;            \
             case 4 * 1 + 2: rc__ = plan_step(pl, KERN<1, 2, PHASE>, GRID, a); break;            \
+            case 4 * 1 + 3: rc__ = plan_step(pl, KERN<1, 3, PHASE>, GRID, a); break;            \
             case 4 * 2 + 0: rc__ = plan_step(pl, KERN<2, 0, PHASE>, GRID, a); break;            \
             case 4 * 2 + 1: rc__ = plan_step(pl, KERN<2, 1, PHASE>, GRID, a); break;            \
             case 4 * 2 + 2: rc__ = plan_step(pl, KERN<2, 2, PHASE>, GRID, a); break;            \
+            case 4 * 2 + 3: rc__ = plan_step(pl, KERN<2, 3, PHASE>, GRID, a); break;            \
             case 4 * 4 + 0: rc__ = plan_step(pl, KERN<4, 0, PHASE>, GRID, a); break;            \
             case 4 * 4 + 1: rc__ = plan_step(pl, KERN<4, 1, PHASE>, GRID, a); break;            \
             case 4 * 4 + 2: rc__ = plan_step(pl, KERN<4, 2, PHASE>, GRID, a); break;            \
+            case 4 * 4 + 3: rc__ = plan_step(pl, KERN<4, 3, PHASE>, GRID, a); break;            \
             case 4 * 8 + 0: rc__ = plan_step(pl, KERN<8, 0, PHASE>, GRID, a); break;            \
             case 4 * 8 + 1: rc__ = plan_step(pl, KERN<8, 1, PHASE>, GRID, a); break;            \
             case 4 * 8 + 2: rc__ = plan_step(pl, KERN<8, 2, PHASE>, GRID, a); break;            \
+            case 4 * 8 + 3: rc__ = plan_step(pl, KERN<8, 3, PHASE>, GRID, a); break;            \
         }                                                                                       \
         if (rc__) return rc__;                                                                  \
     } while (0)
@@ -774,15 +779,19 @@ template <typename KF> int plan_step(Plan& pl, KF kern, dim3 grid, const StepArg
             case 4 * 1 + 0: rc__ = plan_step(pl, KERN<1, 0>, GRID, a); break;                   \
             case 4 * 1 + 1: rc__ = plan_step(pl, KERN<1, 1>, GRID, a); break;                   \
             case 4 * 1 + 2: rc__ = plan_step(pl, KERN<1, 2>, GRID, a); break;                   \
+            case 4 * 1 + 3: rc__ = plan_step(pl, KERN<1, 3>, GRID, a); break;                   \
             case 4 * 2 + 0: rc__ = plan_step(pl, KERN<2, 0>, GRID, a); break;                   \
             case 4 * 2 + 1: rc__ = plan_step(pl, KERN<2, 1>, GRID, a); break;                   \
             case 4 * 2 + 2: rc__ = plan_step(pl, KERN<2, 2>, GRID, a); break;                   \
+            case 4 * 2 + 3: rc__ = plan_step(pl, KERN<2, 3>, GRID, a); break;                   \
             case 4 * 4 + 0: rc__ = plan_step(pl, KERN<4, 0>, GRID, a); break;                   \
             case 4 * 4 + 1: rc__ = plan_step(pl, KERN<4, 1>, GRID, a); break;                   \
             case 4 * 4 + 2: rc__ = plan_step(pl, KERN<4, 2>, GRID, a); break;                   \
+            case 4 * 4 + 3: rc__ = plan_step(pl, KERN<4, 3>, GRID, a); break;                   \
             case 4 * 8 + 0: rc__ = plan_step(pl, KERN<8, 0>, GRID, a); break;                   \
             case 4 * 8 + 1: rc__ = plan_step(pl, KERN<8, 1>, GRID, a); break;                   \
             case 4 * 8 + 2: rc__ = plan_step(pl, KERN<8, 2>, GRID, a); break;                   \
+            case 4 * 8 + 3: rc__ = plan_step(pl, KERN<8, 3>, GRID, a); break;                   \
         }                                                                                       \
         if (rc__) return rc__;                                                                  \
     } while (0)
@@ -791,7 +800,8 @@ template <int CELL> int plan_pointwise(Plan& pl, int act, const StepArgs& a) {
     Launch L;
     L.fn = act == 0 ? reinterpret_cast<const void*>(pointwise_bwd_step<CELL, 0>)
          : act == 1 ? reinterpret_cast<const void*>(pointwise_bwd_step<CELL, 1>)
-                    : reinterpret_cast<const void*>(pointwise_bwd_step<CELL, 2>);
+         : act == 2 ? reinterpret_cast<const void*>(pointwise_bwd_step<CELL, 2>)
+                    : reinterpret_cast<const void*>(pointwise_bwd_step<CELL, 3>);
     L.a = a;
     L.a.tag = (int)pl.size();
     L.grid = (unsigned)(((long)a.bt * a.H + 255) / 256);
@@ -804,9 +814,11 @@ template <int CELL> int plan_pointwise(Plan& pl, int act, const StepArgs& a) {
 int plan_gru_first(Plan& pl, int act, bool bwd, const StepArgs& a) {
     Launch L;
     if (bwd) L.fn = act == 0 ? reinterpret_cast<const void*>(gru_first_step_bwd<0>)
-                  : act == 1 ? reinterpret_cast<const void*>(gru_first_step_bwd<1>) : reinterpret_cast<const void*>(gru_first_step_bwd<2>);
+                  : act == 1 ? reinterpret_cast<const void*>(gru_first_step_bwd<1>)
+                  : act == 2 ? reinterpret_cast<const void*>(gru_first_step_bwd<2>) : reinterpret_cast<const void*>(gru_first_step_bwd<3>);
     else L.fn = act == 0 ? reinterpret_cast<const void*>(gru_first_step_fwd<0>)
-              : act == 1 ? reinterpret_cast<const void*>(gru_first_step_fwd<1>) : reinterpret_cast<const void*>(gru_first_step_fwd<2>);
+              : act == 1 ? reinterpret_cast<const void*>(gru_first_step_fwd<1>)
+              : act == 2 ? reinterpret_cast<const void*>(gru_first_step_fwd<2>) : reinterpret_cast<const void*>(gru_first_step_fwd<3>);
     L.a = a;
     L.a.tag = (int)pl.size();
     L.grid = (unsigned)(((long)a.bt * a.H + 255) / 256);
@@ -837,7 +849,7 @@ int plan_gemm_bwd(Plan& pl, int K, dim3 grid2, const StepArgs& a_in, int H, int 
 }
 
 bool ok_shape(int cell, int act, int H, int H_real, int T, int B) {
-    if (cell < 0 || cell > 2 || act < 0 || act > 2) return false;
+    if (cell < 0 || cell > 2 || act < 0 || act > SEQREC_ACT_ELU) return false;
     if (!(H == 64 || H == 128 || H == 256 || H == 512)) return false;
     if (H_real < 1 || H_real > H || T < 0 || B < 0) return false;
     if ((long)B * T * 4 * H * 4 >= 0x7FFFFFF0L) return false;
@@ -1065,15 +1077,18 @@ extern "C" int seqrec_rnn_fwd_stepwise(int cell, int act, int H, int H_real, int
     const int J = H / 64;
     const long HH = (long)H * H;
     const int32_t* soh = step_off_host;
-    {                                                 // cluster form: one launch, in-kernel exchange (rnn_cluster.hip, rnn_cluster2.hip)
+    const int act_rt = act;
+    if (act <= SEQREC_ACT_LINEAR) {                   // cluster form: one launch, in-kernel exchange (rnn_cluster.hip, rnn_cluster2.hip)
         int rc = 0;
         if (seqrec_cluster_fwd(cell, act, H, H_real, T, B, soh, XW, Hout, gates, aux, upack, rmask, st, &rc)) return rc;
+    } else {
+        act = SEQREC_ACT_OTHER;                       // sigmoid ... elu: the shared instance of the step-wise kernels, kind in StepArgs
     }
     Plan pl;
     pl.reserve(2 * (size_t)T);
     StepArgs a = {};
     a.H = H; a.H_real = H_real; a.XW = XW; a.Hout = Hout; a.gates = gates; a.aux = aux;
-    a.rmask = rmask; a.B = B;
+    a.rmask = rmask; a.B = B; a.act_rt = act_rt;
     for (int t = 0; t < T; ++t) {
         const int bt = soh[t + 1] - soh[t];
         if (bt <= 0) break;
@@ -1156,7 +1171,9 @@ static int rnn_bwd_stepwise_impl(int cell, int act, int H, int H_real, int T, in
     const int32_t* soh = step_off_host;
     // cluster form: one launch, in-kernel exchange (rnn_cluster.hip, rnn_cluster2.hip).  Only the GRU kernel adds the parts
     // of dHout in its own loads; every other form reads dHout from one array
-    if (!parts || cell == SEQREC_CELL_GRU) {
+    const int act_rt = act;
+    const bool core_act = act <= SEQREC_ACT_LINEAR;    // sigmoid ... elu exist in the step-wise form only (one shared kernel instance)
+    if (core_act && (!parts || cell == SEQREC_CELL_GRU)) {
         int rc = 0;
         if (seqrec_cluster_bwd(cell, act, H, H_real, T, B, soh, dHout, Hout, gates, aux, dPre, upack, rmask, st, &rc, parts)) return rc;
     }
@@ -1168,18 +1185,19 @@ static int rnn_bwd_stepwise_impl(int cell, int act, int H, int H_real, int T, in
             SEQREC_LAUNCH_CHECK();
         }
         dHout = dh_scratch;
-        if (cell != SEQREC_CELL_GRU) {
+        if (core_act && cell != SEQREC_CELL_GRU) {
             int rc = 0;
             if (seqrec_cluster_bwd(cell, act, H, H_real, T, B, soh, dHout, Hout, gates, aux, dPre, upack, rmask, st, &rc, nullptr)) return rc;
         }
     }
+    if (!core_act) act = SEQREC_ACT_OTHER;
     Plan pl;
     pl.reserve(2 * (size_t)T);
     StepArgs a = {};
     a.H = H; a.H_real = H_real; a.Hout = const_cast<float*>(Hout); a.gates = const_cast<float*>(gates);
     a.aux = const_cast<float*>(aux); a.dHout = dHout; a.dPre = dPre;
     a.dHc = workspace; a.tmpc = workspace + n_tok * H;
-    a.rmask = rmask; a.B = B;
+    a.rmask = rmask; a.B = B; a.act_rt = act_rt;
     for (int t = T - 1; t >= 0; --t) {
         const int bt = soh[t + 1] - soh[t];
         if (bt <= 0) continue;

@@ -305,7 +305,9 @@ class Engine:
         self.loss_sum, self.loss_mean = self.loss_out[0:1], self.loss_out[1:2]
         self.upack = torch.empty(int(_lib.load().seqrec_rnn_upack_floats(CELL[c.cell], self.Hp)), **f32)
         self.upack_dirty = True
-        self.stepwise = (c.scan == "stepwise") or (c.scan == "auto" and (self.Hp >= 128 or c.drop_rec > 0))
+        self.stepwise = (c.scan == "stepwise") or (c.scan == "auto" and (self.Hp >= 128 or c.drop_rec > 0 or ACT[c.act] > 2))
+        if ACT[c.act] > 2 and not self.stepwise:
+            raise NotImplementedError("activation %r runs in the step-wise form of the scans (scan='stepwise' or 'auto')" % c.act)
         if c.drop_rec > 0 and not self.stepwise:
             raise NotImplementedError("recurrent (z_to_z) dropout needs scan='stepwise' (or 'auto')")
         import os

@@ -32,6 +32,12 @@ from . import batching
 from .keras_compat import Adagrad, Callback, History, initialize
 
 
+
+def _lib_act():
+    """Names of the cell activations the scans implement (_lib.ACT)."""
+    from ._lib import ACT
+    return ACT
+
 class ModelResults:
     def __init__(self, train_loss=None, val_loss=None, epoch=None):
         self.val_loss = val_loss
@@ -168,8 +174,10 @@ class SeqModel:
         cell = {"simpleRNN": "simplernn", "LSTM": "lstm", "GRU": "gru"}.get(rnn_type)
         if cell is None:
             raise ValueError("rnn_type must be 'simpleRNN', 'LSTM' or 'GRU' (got %r)" % (rnn_type,))
-        if activation not in ("relu", "tanh", "linear"):
-            raise NotImplementedError("activation %r: the HIP scan implements relu, tanh and linear" % (activation,))
+        if activation not in _lib_act():
+            # Keras 2.0's element-wise list is covered (relu, tanh, linear, sigmoid, hard_sigmoid, softplus, softsign, elu); `softmax`
+            # as a CELL activation normalises over the hidden units -- not element-wise, and in no call of the reference
+            raise NotImplementedError("activation %r: the HIP scans implement %s" % (activation, ", ".join(sorted(_lib_act()))))
         self.timesteps, self.in_dim, self.n_classes, self.z_dim = timesteps, in_dim, n_classes, z_dim
         self.cell, self.activation = cell, activation
         self.use_bias, self.out_bias = use_bias, out_bias

@@ -35,6 +35,12 @@ CASES = [
     dict(cell="gru", act="tanh", H=64, V=1500, inp="embed", out="sampled", D=64, K=64, tied=True, merge="sorted"),
     dict(cell="lstm", act="relu", H=64, V=17, inp="onehot", out="full", merge="sorted"),
     dict(cell="gru", act="relu", H=64, V=900, inp="embed", out="sampled", D=32, K=50, out_bias=True, merge="sorted"),
+    # Keras 2.0's other element-wise cell activations (model.py:324,346,351 pass any name through): the shared step-wise instance
+    dict(cell="lstm", act="sigmoid", H=128, V=17, inp="onehot", out="full"),
+    dict(cell="gru", act="softsign", H=64, V=900, inp="embed", out="sampled", D=32, K=50),
+    dict(cell="simplernn", act="elu", H=100, V=33, inp="onehot", out="full", drop_rec=0.2),
+    dict(cell="gru", act="softplus", H=256, V=2000, inp="embed", out="sampled", D=256, K=128, logq=True),
+    dict(cell="lstm", act="hard_sigmoid", H=512, V=1200, inp="embed", out="sampled", D=64, K=64, tied=False),
     # the persistent scan stays selectable
     dict(cell="gru", act="relu", H=256, V=800, inp="embed", out="sampled", D=64, K=64, scan="persistent"),
     dict(cell="lstm", act="relu", H=128, V=17, inp="onehot", out="full", scan="persistent"),

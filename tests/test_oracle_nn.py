@@ -143,6 +143,18 @@ def test_finite_differences(cell, inp, out):
     fd_check(cfg, p, batch, fw, list(p.keys()), rng)
 
 
+@pytest.mark.parametrize("act", ["sigmoid", "softplus", "softsign", "elu", "hard_sigmoid"])
+@pytest.mark.parametrize("cell", CELLS)
+def test_finite_differences_other_activations(cell, act):
+    """Keras 2.0's other element-wise cell activations (the reference passes any name through `z_to_z_activation`,
+    model.py:324,346,351): the oracle's derivatives against fp64 finite differences, every cell."""
+    rng = np.random.default_rng(30)
+    V, H, D = 11, 5, 4
+    cfg = cfg_of(cell, "embed", "full", act=act)
+    p = init_params(rng, cfg, V, H, D)
+    fd_check(cfg, p, pad_batch(make_sessions(rng, 5, V)), {}, list(p.keys()), rng, n_probe=4)
+
+
 def test_finite_differences_tied_and_dropout():
     rng = np.random.default_rng(4)
     V, H = 12, 5
