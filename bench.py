@@ -202,6 +202,8 @@ def kernel_model(cfgd, n_tok, K, B, slabs=None, uniq=None, upack_floats=0):
         "seqrec_gemm_f32_fused[xw]": ("mfma", 2.0 * n_tok * D * G * H, {"gather_bytes": 4.0 * D * n_tok}),
         "seqrec_gemm_f32_fused[dH]": ("mfma", 2.0 * n_tok * K * H, {"gather_bytes": 4.0 * H * n_tok}),     # + the target-row term in the final write
         "seqrec_gemm_f32[logits]": ("mfma", 2.0 * n_tok * K * H),
+        # dH = dlogits . Eneg (+ the target-row term) and dEneg = dlogits^T . H in ONE launch of two layout bodies (+ dH's reduce launch)
+        "seqrec_gemm_f32_pair[dH+dEneg]": ("mfma", 4.0 * n_tok * K * H, {"gather_bytes": 4.0 * H * n_tok}),
         "seqrec_gemm_f32[dH]": ("mfma", 2.0 * n_tok * K * H),
         "seqrec_gemm_f32[dEneg]": ("mfma", 2.0 * n_tok * K * H),
         "seqrec_gemm_f32_slabs[dEneg]": ("mfma", 2.0 * n_tok * K * H),       # split-K slabs left for the row scatter: no reduce launch

@@ -154,6 +154,20 @@ int seqrec_gemm_f32_fused(int a_kcontig, int b_kcontig, int64_t M, int64_t N, in
                           const float* A, int64_t lda, const float* B, int64_t ldb,
                           float* C, int64_t ldc, const float* bias, int accumulate,
                           int splitk, float* workspace, const seqrec_gemm_fuse* fuse_host, void* stream);
+/*      TWO independent products of different layouts in ONE launch (ABI 5): product 0 as seqrec_gemm_f32_fused would compute it
+ *      (C0, split-K + reduce, the add_* row term in the final write), product 1 as seqrec_gemm_f32_slabs would leave it (n_slabs1
+ *      slabs in ws1).  For dH = dlogits . Eneg beside dEneg = dlogits^T . H of the sampled softmax's backward: both read dlogits and
+ *      neither fills the chip at MSNBC-shaped batch sizes.  Shapes the pair kernel does not cover (other layouts than (1,0) + (0,0),
+ *      gathered operands, products that fill the chip alone) are issued one after the other with identical results; `together`
+ *      reports which way it went.  The plan is HOST memory; n_slabs1 / together are outputs. */
+typedef struct seqrec_gemm_pair {
+    int32_t a_kc0, b_kc0, a_kc1, b_kc1;
+    int64_t M0, N0, K0; const float* A0; int64_t lda0; const float* B0; int64_t ldb0; float* C0; int64_t ldc0; int32_t splitk0, reserved0_; float* ws0;
+    const float* add_table; const int32_t* add_index; const float* add_scale; int64_t add_ld;
+    int64_t M1, N1, K1; const float* A1; int64_t lda1; const float* B1; int64_t ldb1; int32_t splitk1, reserved1_; float* ws1;
+    int32_t n_slabs1, together;
+} seqrec_gemm_pair;
+int seqrec_gemm_f32_pair(seqrec_gemm_pair* plan_host, void* stream);
 /*      grouped form: up to 6 independent problems that share the layout flags, K and the split count
  *      in ONE launch (the weight-gradient GEMMs dW / dU all reduce over K = N_tok).
  *      workspace (splitk > 1): sum_i splitk * M_i * N_i floats. */
@@ -326,7 +340,8 @@ int seqrec_index_affine_i32(int32_t* dst, const int32_t* dst_pos, const int32_t*
  *                    XW = x . W + bias with the rows of x read through x_index (seqrec_gemm_f32_fused)  ->  seqrec_rnn_fwd_stepwise  ->
  *                    ln = Hout . Eneg^T  ->  seqrec_sampled_softmax_ce (logq_table / tgt_table by item id; lq_tgt NULL) or
  *                    seqrec_sampled_softmax_ce_rows_idx (target rows through tgt_index, lq_tgt per token)
- *        2 backward  dHd = dln . Eneg + dlt * tgt rows (seqrec_gemm_f32_fused, sk_dh splits)  ->  [deneg_mode 1: dEneg slabs]  ->
+ *        2 backward  dHd = dln . Eneg + dlt * tgt rows (seqrec_gemm_f32_fused, sk_dh splits)  ->  [deneg_mode 1: dEneg slabs; 3: dH and
+ *                    dEneg together, seqrec_gemm_f32_pair]  ->
  *                    seqrec_rnn_bwd_stepwise  ->  the weight gradients dU (GRU: two column blocks), dW, db [, deneg_mode 2: dEneg] in one
  *                    grouped launch: wgrad_slabs != 0 leaves split-K slabs (seqrec_gemm_f32_grouped_slabs; descs_out / ns_wgrad
  *                    are what seqrec_opt_sqnorm_slabs needs), else reduced into dU / dW / db

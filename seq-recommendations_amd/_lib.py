@@ -74,6 +74,7 @@ _SIGS = {
     "seqrec_exchange_pack": [P, L, I, P, P, L, L, U64, U64, I, P, P, I, I, P, P, I, I, I, I, P, P, P, P, P, P, P],
     "seqrec_exchange_unpack": [P, I, P, P, I, P, L, P, P, P, P, P],
     "seqrec_train_cell": [P, P],
+    "seqrec_gemm_f32_pair": [P, P],
     "seqrec_cell_plan_bytes": [],
     "seqrec_exchange_grad_pack": [P, L, I, I, I, P, I, L, P, P, P, I, L, P, P, P, P],
     "seqrec_route_count_host": [P, P, L, I, P],
@@ -172,6 +173,17 @@ def gemm_descs(items):
         arr[i].C, arr[i].ldc, arr[i].bias, arr[i].accumulate = Cm.data_ptr(), int(ldc), None, 0
         arr[i].a_index = it[9].data_ptr() if len(it) > 9 and it[9] is not None else None
     return arr
+
+
+class GemmPair(C.Structure):
+    """seqrec_gemm_pair (include/seqrec_hip.h)."""
+    _fields_ = [("a_kc0", C.c_int32), ("b_kc0", C.c_int32), ("a_kc1", C.c_int32), ("b_kc1", C.c_int32),
+                ("M0", L), ("N0", L), ("K0", L), ("A0", P), ("lda0", L), ("B0", P), ("ldb0", L), ("C0", P), ("ldc0", L),
+                ("splitk0", C.c_int32), ("reserved0_", C.c_int32), ("ws0", P),
+                ("add_table", P), ("add_index", P), ("add_scale", P), ("add_ld", L),
+                ("M1", L), ("N1", L), ("K1", L), ("A1", P), ("lda1", L), ("B1", P), ("ldb1", L),
+                ("splitk1", C.c_int32), ("reserved1_", C.c_int32), ("ws1", P),
+                ("n_slabs1", C.c_int32), ("together", C.c_int32)]
 
 
 class CellPlan(C.Structure):

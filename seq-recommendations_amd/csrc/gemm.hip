@@ -800,6 +800,32 @@ __global__ __launch_bounds__(256) GEMM2_WAVES(BM, BN) void gemm2_f32_kernel(Gemm
     gemm2_body<BM, BN, A_KC, B_KC, AIDX>(map, smem);
 }
 
+// TWO independent products of different layouts in one launch (round 4): work items [0, n0) belong to the first, the rest to the
+// second; a workgroup runs ONE of the two layout bodies.  For dH = dlogits . Eneg (k-contiguous A) beside dEneg = dlogits^T . H
+// (row-contiguous operands): both read dlogits, neither fills the chip alone at c3 (480 + 512 workgroups on 1 280 slots), and run
+// side by side they take 46.7 us against 54.2 back to back (tools/pair_probe.py).
+struct PairMap {
+    const GemmArgs* g; int ntiles, nsplits, off;
+    __device__ int count() const { return ntiles * nsplits; }
+    __device__ void get(int item, int& p, int& tile, int& z, int& ns) const {
+        const int l = xcd_tile(item - off, ntiles * nsplits);
+        z = l / ntiles; tile = l - z * ntiles; p = 0; ns = nsplits;
+    }
+    __device__ GemmArgs load(int) const { return *g; }
+};
+template <int BM, int BN, bool A0, bool B0, bool A1, bool B1>
+__global__ __launch_bounds__(256) GEMM2_WAVES(BM, BN) void gemm2_f32_pair_kernel(GemmArgs g0, int nt0, int ns0, GemmArgs g1, int nt1, int ns1) {
+    __shared__ __attribute__((aligned(16))) float smem[v2_lds_floats<BM, BN, false>()];
+    const int n0 = nt0 * ns0;
+    if ((int)blockIdx.x < n0) {
+        const PairMap map{&g0, nt0, ns0, 0};
+        gemm2_body<BM, BN, A0, B0, false>(map, smem);
+    } else {
+        const PairMap map{&g1, nt1, ns1, n0};
+        gemm2_body<BM, BN, A1, B1, false>(map, smem);
+    }
+}
+
 template <int BM, int BN, int BKT, bool A_KC, bool B_KC, bool AIDX = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #ifdef SEQREC_PROBE_XCD_SKIP       // timing probe only (tools/overlap_probe.py): workgroups dealt to the first N XCDs do nothing
@@ -993,6 +1019,66 @@ extern "C" int seqrec_gemm_f32_slabs(int a_kcontig, int b_kcontig, int64_t M, in
     *n_slabs = 0;
     return gemm_f32_impl(a_kcontig, b_kcontig, M, N, K, A, lda, B, ldb, nullptr, N, nullptr, 0, splitk, workspace, nullptr, stream,
                          n_slabs);
+}
+
+// the pair launch: product 0 = C0 (+ its fused row add, split-K with the reduce launch behind the pair), product 1 left as slabs.
+// Taken when both products are LDS-DMA eligible at 64 x 64 tiles, un-gathered, with the layouts (1,0) and (0,0), and together at most
+// ~1 500 work items (one round of the chip: larger products fill it alone -- c4); otherwise the two products go one after the other,
+// exactly as seqrec_gemm_f32_fused and seqrec_gemm_f32_slabs would issue them.
+extern "C" int seqrec_gemm_f32_pair(seqrec_gemm_pair* p, void* stream) {
+    if (!p || !p->C0 || !p->ws1 || p->splitk0 < 1 || p->splitk1 < 1) return SEQREC_E_ARG;
+    if (p->M0 <= 0 || p->N0 <= 0 || p->K0 <= 0 || p->M1 <= 0 || p->N1 <= 0 || p->K1 <= 0) return SEQREC_E_ARG;
+    if (!p->A0 || !p->B0 || !p->A1 || !p->B1 || (p->splitk0 > 1 && !p->ws0)) return SEQREC_E_ARG;
+    hipStream_t st = as_stream(stream);
+    auto fill = [](GemmArgs& g, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, int splitk, int& splits) {
+        g.A = A; g.B = B; g.bias = nullptr; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.accumulate = 0;
+        g.epi = 0; g.tgt = nullptr; g.thr = nullptr; g.rank = nullptr; g.a_idx = nullptr;
+        g.a_vec = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 4 == 0);
+        g.b_vec = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 4 == 0);
+        long kps = (K + splitk - 1) / splitk;
+        kps = (kps + 31) / 32 * 32;
+        if (kps == 0) kps = BK;
+        splits = (int)((K + kps - 1) / kps);
+        if (splits < 1) splits = 1;
+        g.k_per_split = kps;
+    };
+    GemmArgs g0{}, g1{};
+    int s0 = 1, s1 = 1;
+    fill(g0, p->M0, p->N0, p->K0, p->A0, p->lda0, p->B0, p->ldb0, p->splitk0, s0);
+    fill(g1, p->M1, p->N1, p->K1, p->A1, p->lda1, p->B1, p->ldb1, p->splitk1, s1);
+    if (p->add_table && (!p->add_index || p->add_ld < p->N0)) return SEQREC_E_ARG;
+    g0.add_table = p->add_table; g0.add_idx = p->add_index; g0.add_scale = p->add_scale; g0.add_ld = p->add_ld;
+    const long nt0 = ((p->M0 + 63) / 64) * ((p->N0 + 63) / 64), nt1 = ((p->M1 + 63) / 64) * ((p->N1 + 63) / 64);
+    const bool together = p->a_kc0 == 1 && p->b_kc0 == 0 && p->a_kc1 == 0 && p->b_kc1 == 0 && gemm2_eligible(1, 0, g0) && gemm2_eligible(0, 0, g1)
+                          && gemm2_tile(p->M0, p->N0, s0) == 1 && gemm2_tile(p->M1, p->N1, s1) == 1 && nt0 * s0 + nt1 * s1 <= 1536;
+    if (!together) {
+        seqrec_gemm_fuse f = {};
+        f.add_table = p->add_table; f.add_index = p->add_index; f.add_scale = p->add_scale; f.add_ld = p->add_ld;
+        int rc = gemm_f32_impl(p->a_kc0, p->b_kc0, p->M0, p->N0, p->K0, p->A0, p->lda0, p->B0, p->ldb0, p->C0, p->ldc0, nullptr, 0, p->splitk0,
+                               p->ws0, &f, stream, nullptr);
+        if (rc) return rc;
+        int ns = 0;
+        rc = gemm_f32_impl(p->a_kc1, p->b_kc1, p->M1, p->N1, p->K1, p->A1, p->lda1, p->B1, p->ldb1, nullptr, p->N1, nullptr, 0, p->splitk1,
+                           p->ws1, nullptr, stream, &ns);
+        p->n_slabs1 = ns;
+        p->together = 0;
+        return rc;
+    }
+    if (s0 > 1) { g0.C = p->ws0; g0.ldc = p->N0; } else { g0.C = p->C0; g0.ldc = p->ldc0; }
+    g1.C = p->ws1; g1.ldc = p->N1;
+    g0.tiles_n = (int)((p->N0 + 63) / 64); g1.tiles_n = (int)((p->N1 + 63) / 64);
+    hipLaunchKernelGGL((gemm2_f32_pair_kernel<64, 64, true, false, false, false>), dim3((unsigned)(nt0 * s0 + nt1 * s1)), dim3(256), 0, st,
+                       g0, (int)nt0, s0, g1, (int)nt1, s1);
+    SEQREC_LAUNCH_CHECK();
+    if (s0 > 1) {
+        const long total = p->M0 * p->N0;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)min((long)2048, (total + 255) / 256)), dim3(256), 0, st, p->ws0, s0, (long)p->M0,
+                           (long)p->N0, p->C0, (long)p->ldc0, (const float*)nullptr, 0, g0);
+        SEQREC_LAUNCH_CHECK();
+    }
+    p->n_slabs1 = s1;
+    p->together = 1;
+    return 0;
 }
 
 static int gemm_f32_impl(int a_kcontig, int b_kcontig, int64_t M, int64_t N, int64_t K,

@@ -38,11 +38,22 @@ extern "C" int seqrec_train_cell(seqrec_cell_plan* p, void* st) {
                                                p->inv_denom, p->loss_rows, p->dlt, st));
     }
     if (p->stages & 2) {
-        seqrec_gemm_fuse fh = {};
-        fh.add_table = p->tgt_table; fh.add_index = p->tgt_index; fh.add_scale = p->dlt; fh.add_ld = p->tgt_ld;
-        STEP_TRY(seqrec_gemm_f32_fused(1, 0, n, Hp, K, p->ln, K, p->Eneg, Hp, p->dHd, Hp, nullptr, 0, p->sk_dh, p->sk_dh > 1 ? p->gemm_ws : nullptr,
-                                       &fh, st));
         p->ns_deneg = 0;
+        if (p->deneg_mode == 3) {          // dH and dEneg -- both products of dlogits -- in ONE launch (seqrec_gemm_f32_pair)
+            seqrec_gemm_pair q = {};
+            q.a_kc0 = 1; q.b_kc0 = 0; q.M0 = n; q.N0 = Hp; q.K0 = K; q.A0 = p->ln; q.lda0 = K; q.B0 = p->Eneg; q.ldb0 = Hp;
+            q.C0 = p->dHd; q.ldc0 = Hp; q.splitk0 = p->sk_dh; q.ws0 = p->gemm_ws;
+            q.add_table = p->tgt_table; q.add_index = p->tgt_index; q.add_scale = p->dlt; q.add_ld = p->tgt_ld;
+            q.a_kc1 = 0; q.b_kc1 = 0; q.M1 = K; q.N1 = Hp; q.K1 = n; q.A1 = p->ln; q.lda1 = K; q.B1 = p->Hout; q.ldb1 = Hp;
+            q.splitk1 = p->sk_deneg < 1 ? 1 : p->sk_deneg; q.ws1 = p->dEneg_slabs;
+            STEP_TRY(seqrec_gemm_f32_pair(&q, st));
+            p->ns_deneg = q.n_slabs1;
+        } else {
+            seqrec_gemm_fuse fh = {};
+            fh.add_table = p->tgt_table; fh.add_index = p->tgt_index; fh.add_scale = p->dlt; fh.add_ld = p->tgt_ld;
+            STEP_TRY(seqrec_gemm_f32_fused(1, 0, n, Hp, K, p->ln, K, p->Eneg, Hp, p->dHd, Hp, nullptr, 0, p->sk_dh, p->sk_dh > 1 ? p->gemm_ws : nullptr,
+                                           &fh, st));
+        }
         if (p->deneg_mode == 1) {
             int ns = 0;
             STEP_TRY(seqrec_gemm_f32_slabs(0, 0, K, Hp, n, p->ln, K, p->Hout, Hp, p->sk_deneg < 1 ? 1 : p->sk_deneg, p->dEneg_slabs, &ns, st));

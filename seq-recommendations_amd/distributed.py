@@ -895,6 +895,7 @@ class ShardedEngine(Engine):
         pl.tgt_table, pl.tgt_ld, pl.tgt_index, pl.tgt_ids, pl.lq_tgt = ptr(recv), w, ptr(d["take_tgt"]), ptr(d["tgt"]), ptr(self._lq_tgt(d))
         pl.logq_table = None
         pl.dHd, pl.gemm_ws, pl.sk_dh, pl.sk_deneg, pl.dEneg_slabs = ptr(dHd), ptr(wsp), sk_h, sk_e, ptr(dEs)
+        pl.deneg_mode = 3 if self._pair_ok(n, sk_h, sk_e) else 1      # dH and dEneg in one launch where neither fills the chip (engine.py)
         pl.sk_wgrad, pl.wgrad_ws = sk_w, ptr(wsp)
         pl.dPre, pl.scan_ws, pl.prev, pl.ones = ptr(dPre), ptr(scan_ws), ptr(d["prev"]), ptr(self._ones(n))
         pl.sk_dx, pl.dX_slabs = sk_x, ptr(dXs)

@@ -295,6 +295,11 @@ class Engine:
         # dEneg = dlogits^T . H reduces over the tokens like dW / dU and has the same operand layout: it rides in THEIR grouped
         # launch (one launch of ~950 workgroups instead of two of ~500 that fill 1.5-2 slots per CU each; A/B switch)
         self._group_deneg = _os.environ.get("SEQREC_GROUP_DENEG", "1") != "0"
+        # A/B switch, OFF: dH and dEneg (both products of dlogits) in ONE launch of two layout bodies (seqrec_gemm_f32_pair), instead of
+        # dEneg riding in the weight-gradient launch.  Built, bit-identical, measured: the pair launch takes 58.4 us where dH alone takes 34
+        # and dEneg 25 -- these launches are bound by the 64 x 64 tile's rate per CU, not by their ramp, so sharing a launch shares the
+        # CUs' time: c3 0.4040 -> 0.4061 ms per step (profiles/r04_pair_probe.txt)
+        self._pair_dh = _os.environ.get("SEQREC_PAIR_DH", "0") != "0"
         self.sq1 = z(1)                 # squared gradient norm (multi-launch path)
         self.sq2 = z(2)                 # two alternating slots of the fused optimizer launches
         self._sq_slots = (self.sq2[0:1], self.sq2[1:2])
@@ -1028,7 +1033,15 @@ class Engine:
             dln, dlt, neg, Eneg = r["dln"], r["dlt"], r["neg"], r["Eneg"]
             # dH = dlogits . Eneg + dlt * Eout[tgt]: the target-row term rides in the GEMM's final write
             sk_h = self._splitk(n, Hp, K, fill=True)
-            if self._slab_dh and self.stepwise and sk_h > 1 and "out" not in drops:
+            pair = tr[tname] and self._pair_ok(n, sk_h, self._splitk(K, Hp, n)) and apply_update and not self.priors
+            if pair:
+                # dH and dEneg = dlogits^T . H are both products of dlogits and neither fills the chip alone at these sizes: ONE launch
+                # (seqrec_gemm_f32_pair: 46.7 us side by side against 54.2 back to back, tools/pair_probe.py); dEneg comes out as slabs
+                import ctypes
+                q = self._pair_plan(n, K, dln, Eneg, dHd, sk_h, Et, d["tgt"], dlt, Hd, self._splitk(K, Hp, n))
+                call("seqrec_gemm_f32_pair", ctypes.addressof(q), st, tag="dH+dEneg")
+                pair_ns = int(q.n_slabs1)
+            elif self._slab_dh and self.stepwise and sk_h > 1 and "out" not in drops:
                 # dH's only reader is the BPTT: its split-K slabs and the target-row term go there as parts (the cluster scan
                 # adds them where it reads dHout -- no reduce launch; other scan forms sum them into dHd first)
                 hs, ns_h, ss_h = self.gemm_slabs(1, 0, n, Hp, K, dln, K, Eneg, Hp, "dH_slabs", sk_h, tag="dH")
@@ -1039,7 +1052,10 @@ class Engine:
             if tr[tname]:
                 dEneg = self.buf("dEneg", K, Hp)
                 ns_neg = ss_neg = 0
-                if self._overlap and _PROF is None:      # (the per-call profile times calls on the main stream)
+                if pair:
+                    dEneg, ns_neg, ss_neg = self.buf("dEneg_slabs", max(self._splitk(K, Hp, n), 1) * K * Hp), pair_ns, K * Hp
+                    self.last_slabs["dEneg_slabs"] = (dEneg, pair_ns, K, Hp)
+                elif self._overlap and _PROF is None:      # (the per-call profile times calls on the main stream)
                     # dEneg = dlogits^T . H needs nothing from the BPTT: it runs on a side stream UNDER the (latency-bound,
                     # one-launch) BPTT and is joined in front of the scatter that consumes it
                     side = self._side()
@@ -1285,6 +1301,25 @@ class Engine:
                 and self._slab_scatter and self._slab_wgrad and not self._slab_dh and not self._overlap and self._fuse_prologue
                 and self.Dp % 4 == 0)
 
+    def _pair_ok(self, n, sk_h, sk_e):
+        """dH and dEneg in one launch (seqrec_gemm_f32_pair)?  When both are small enough to share one round of the chip (the
+        library decides the same way and would issue them one after the other otherwise) and the slab forms are on."""
+        c, Hp, K = self.cfg, self.Hp, self.cfg.K
+        nt0 = ((n + 63) // 64) * ((Hp + 63) // 64)
+        nt1 = ((K + 63) // 64) * ((Hp + 63) // 64)
+        return (self._pair_dh and c.output == "sampled" and self._slab_scatter and c.merge != "sorted" and not self._slab_dh and not self._overlap
+                and K % 4 == 0 and nt0 * sk_h + nt1 * sk_e <= 1536)
+
+    def _pair_plan(self, n, K, dln, Eneg, dHd, sk_h, Et, tgt_idx, dlt, Hd, sk_e):
+        q = _lib.GemmPair()
+        Hp = self.Hp
+        q.a_kc0, q.b_kc0, q.M0, q.N0, q.K0, q.A0, q.lda0, q.B0, q.ldb0 = 1, 0, n, Hp, K, ptr(dln), K, ptr(Eneg), Hp
+        q.C0, q.ldc0, q.splitk0, q.ws0 = ptr(dHd), Hp, sk_h, ptr(self.buf("gemm_ws", max(sk_h, 1) * n * Hp))
+        q.add_table, q.add_index, q.add_scale, q.add_ld = ptr(Et), ptr(tgt_idx), ptr(dlt), Hp
+        q.a_kc1, q.b_kc1, q.M1, q.N1, q.K1, q.A1, q.lda1, q.B1, q.ldb1 = 0, 0, K, Hp, n, ptr(dln), K, ptr(Hd), Hp
+        q.splitk1, q.ws1 = max(sk_e, 1), ptr(self.buf("dEneg_slabs", max(sk_e, 1) * K * Hp))
+        return q
+
     def _cell_plan(self):
         """The persistent argument block of seqrec_train_cell: everything that does not change from step to step is written once
         (the parameter tensors never move; set_sampler drops the block)."""
@@ -1348,20 +1383,21 @@ class Engine:
         shapes += [(Dp, GHp), (1, GHp)]
         tiles = sum(((a + 63) // 64) * ((b + 63) // 64) for a, b in shapes)
         sk_w = self._splitk_tiles(tiles, n, fill=SPLITK_FILL_WGRAD, long_k=True)
-        ride = (self._group_deneg and n <= 4096 and len(shapes) < 6
+        sk_e = self._splitk(K, Hp, n)
+        pair = self._pair_ok(n, sk_h, sk_e)
+        ride = (not pair and self._group_deneg and n <= 4096 and len(shapes) < 6
                 and ((K + 63) // 64) * ((Hp + 63) // 64) + ((Dp + 63) // 64 + (Hp + 63) // 64 + 1) * ((GHp + 63) // 64) <= 512)
         if ride:
             tiles_all = tiles + ((K + 63) // 64) * ((Hp + 63) // 64)
             sk_w = max(sk_w, int(max(1, min(1024 // max(tiles_all, 1), n // SPLITK_MIN_K))))
         slabs_w = sk_w > 1 or ride
         wsz = sum(sk_w * a * b for a, b in shapes) + (sk_w * K * Hp if ride else 0)
-        sk_e = self._splitk(K, Hp, n)
         wsp = self.buf("gemm_ws", max(wsz, sk_h * n * Hp, 1))
         dEs = None if ride else self.buf("dEneg_slabs", max(sk_e, 1) * K * Hp)
         sk_x = self._splitk_tiles(((n + 63) // 64) * ((Dp + 63) // 64), GHp, min_k=self._slab_min_k, fill=True)
         dXs = self.buf("dX_slabs", max(sk_x, 1) * n * Dp)
         pl.dHd, pl.gemm_ws, pl.sk_dh = ptr(dHd), ptr(wsp), sk_h
-        pl.deneg_mode, pl.sk_deneg, pl.dEneg_slabs = (2 if ride else 1), sk_e, ptr(dEs)
+        pl.deneg_mode, pl.sk_deneg, pl.dEneg_slabs = (3 if pair else (2 if ride else 1)), sk_e, ptr(dEs)
         pl.sk_wgrad, pl.wgrad_slabs, pl.wgrad_ws = sk_w, int(slabs_w), ptr(wsp)
         pl.dPre, pl.scan_ws, pl.prev = ptr(dPre), ptr(scan_ws), ptr(d["prev"])
         pl.dU, pl.dW, pl.db, pl.ones = ptr(Gd["U"]), ptr(Gd["W"]), ptr(Gd["b"]), ptr(self._ones(n))

@@ -86,6 +86,7 @@ def test_deneg_riding_in_the_weight_gradient_launch_changes_nothing():
         ecfg, ocfg = make_cfg(**case)
         pair = Pair(ecfg, ocfg, init_np_params(rng, ocfg, case["V"], case["H"], case["D"]))
         pair.eng._group_deneg = ride
+        pair.eng._pair_dh = False              # (dEneg beside dH in one launch -- an option, off by default -- has its own test below)
         losses = []
         for step in range(3):
             sess = make_sessions(rng, 60, case["V"], 2, 14)
@@ -578,3 +579,65 @@ def test_scan_timeout_raises_then_the_retry_runs_stepwise_and_matches_the_oracle
         assert max(pair.max_param_diff().values()) < 2e-3
     finally:
         lib.seqrec_debug_scan_cluster(-1)                # back to the default form for the tests that follow
+
+
+def test_dh_and_deneg_in_one_launch_equal_the_two_launches():
+    """seqrec_gemm_f32_pair (round 4): dH = dlogits . Eneg (+ dlt * Eout[tgt]) and dEneg = dlogits^T . H -- both products of dlogits --
+    in ONE launch of two layout bodies.  Same tiles, same K splits, same reduce launch as the two separate launches: after a step from
+    identical parameters dH, dPre and the dEneg slabs are BIT-IDENTICAL with the pair on and off (call-by-call AND one-call cell), and
+    the library reports that the products did run together; a shape too large to share a round falls back inside the library."""
+    import importlib
+    import ctypes
+    import torch
+    B = importlib.import_module("seq-recommendations_amd.batching")
+    Lb = importlib.import_module("seq-recommendations_amd._lib")
+    rng = np.random.default_rng(13)
+    case = dict(cell="gru", act="relu", H=256, V=5000, inp="embed", out="sampled", D=256, K=500, logq=True)
+    ecfg, ocfg = make_cfg(**case)
+    params = init_np_params(rng, ocfg, case["V"], case["H"], case["D"])
+    rb = B.pack_sessions(make_sessions(rng, 60, case["V"], 2, 14))
+    got = {}
+    for pair_on in (True, False):
+        for native in (True, False):
+            p = Pair(ecfg, ocfg, params)
+            p.eng._pair_dh, p.eng.native_cell, p.eng._group_deneg = pair_on, native, False
+            loss = float(p.eng.train_step(p.eng.upload(rb), lr=0.02, step=0).item())
+            n = rb.n_tok
+            va, ns, r_, c_ = p.eng.last_slabs["dEneg_slabs"]
+            got[(pair_on, native)] = (loss, p.eng.ws["dHd"][: n * p.eng.Hp].clone(), p.eng.ws["dPre"][: n * p.eng.GHp].clone(),
+                                      ns, va[: ns * r_ * c_].clone())
+    ref = got[(False, False)]
+    for key, g in got.items():
+        assert g[0] == ref[0] and g[3] == ref[3], key
+        assert torch.equal(g[1], ref[1]) and torch.equal(g[2], ref[2]) and torch.equal(g[4], ref[4]), key
+    # the library's own report, directly: small pair together, a pair that fills the chip one after the other -- same numbers
+    dev = "cuda"
+    for n, K, H, want in ((700, 500, 256, 1), (2600, 4000, 512, 0)):
+        ln = torch.randn(n, K, device=dev); En = torch.randn(K, H, device=dev); Hd = torch.randn(n, H, device=dev)
+        Et = torch.randn(900, H, device=dev); ti = torch.randint(0, 900, (n,), dtype=torch.int32, device=dev); sc = torch.randn(n, device=dev)
+        outs = []
+        for mode in ("pair", "apart"):
+            dH = torch.empty(n, H, device=dev); ws0 = torch.empty(3 * n * H, device=dev); ws1 = torch.empty(4 * K * H, device=dev)
+            st = torch.cuda.current_stream().cuda_stream
+            if mode == "pair":
+                q = Lb.GemmPair()
+                q.a_kc0, q.b_kc0, q.M0, q.N0, q.K0, q.A0, q.lda0, q.B0, q.ldb0 = 1, 0, n, H, K, ln.data_ptr(), K, En.data_ptr(), H
+                q.C0, q.ldc0, q.splitk0, q.ws0 = dH.data_ptr(), H, 3, ws0.data_ptr()
+                q.add_table, q.add_index, q.add_scale, q.add_ld = Et.data_ptr(), ti.data_ptr(), sc.data_ptr(), H
+                q.a_kc1, q.b_kc1, q.M1, q.N1, q.K1, q.A1, q.lda1, q.B1, q.ldb1 = 0, 0, K, H, n, ln.data_ptr(), K, Hd.data_ptr(), H
+                q.splitk1, q.ws1 = 4, ws1.data_ptr()
+                Lb.call("seqrec_gemm_f32_pair", ctypes.addressof(q), st)
+                assert q.together == want, (n, K, H, q.together)
+                ns1 = q.n_slabs1
+            else:
+                f = Lb.gemm_fuse(add_table=Et, add_index=ti, add_scale=sc, add_ld=H)
+                Lb.call("seqrec_gemm_f32_fused", 1, 0, n, H, K, ln.data_ptr(), K, En.data_ptr(), H, dH.data_ptr(), H, None, 0, 3, ws0.data_ptr(),
+                        ctypes.addressof(f), st)
+                nsl = ctypes.c_int(0)
+                Lb.call("seqrec_gemm_f32_slabs", 0, 0, K, H, n, ln.data_ptr(), K, Hd.data_ptr(), H, 4, ws1.data_ptr(), ctypes.addressof(nsl), st)
+                ns1 = nsl.value
+            torch.cuda.synchronize()
+            outs.append((dH, ns1, ws1[: ns1 * K * H].clone()))
+        assert outs[0][1] == outs[1][1] and torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2]), (n, K, H)
+        want_dh = (ln.double() @ En.double() + sc.double()[:, None] * Et[ti.long()].double()).float()
+        assert float((outs[0][0] - want_dh).abs().max().item()) <= 2e-3 * float(want_dh.abs().max().item())
