@@ -697,7 +697,7 @@ def main(argv=None):
                 route_host["pack_s"] += t1 - t0; route_host["plan_s"] += time.perf_counter() - t1; route_host["windows"] += 1
             d = window.pop(i)
         else:
-            d = eng.upload_device(ds, stream.sel(i))
+            d = eng.upload_device(ds, stream.sel(i), defer=True)       # as catalogue.SampledRNNModel's fit loop does
         return d
 
     def train(i):

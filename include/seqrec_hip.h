@@ -357,6 +357,9 @@ typedef struct seqrec_cell_plan {
     const float* U; float* upack;
     const uint32_t* thresh; const int32_t* alias; int32_t V, reserved1_; const float* sample_table; const float* sample_logq;
     int32_t* neg_out; float* Eneg_out; float* lq_neg_out;
+    /* batch != 0 (needs pack_u and sample): the batch itself is gathered in the prologue launch (seqrec_rnn_pack_u_sample_batch) */
+    int32_t batch, reserved3_; const int32_t* flat; const int64_t* starts; const int32_t* sess_host;      /* sess_host: host, B entries */
+    int32_t* sess_out; int32_t* step_off_out; int32_t* ids_out; int32_t* tgt_out; int32_t* prev_out;
     /* input projection */
     const float* x_table; int64_t x_ld; const int32_t* x_index; const float* W; const float* bias;
     float *XW, *Hout, *gates, *aux;
@@ -537,6 +540,15 @@ int seqrec_sample_gather(uint64_t seed, uint64_t step, int K, const uint32_t* th
 int seqrec_rnn_pack_u_sample(int cell, int H, const float* U, float* upack, uint64_t seed, uint64_t step, int K,
                              const uint32_t* thresh, const int32_t* alias, int V, const float* table, int width,
                              const float* logq, int32_t* neg_out, float* rows_out, float* logq_out, void* stream);
+/*      ... + seqrec_pack_batch_host in the SAME launch (ABI 5): the three openers of a training step on a batch drawn from an
+ *      HBM-resident data set -- batch gather, U re-pack, negatives -- as one launch; B + T + 1 <= 640 (kernel arguments) */
+#define SEQREC_PACK_MERGED_MAX 640
+int seqrec_rnn_pack_u_sample_batch(int cell, int H, const float* U, float* upack, uint64_t seed, uint64_t step, int K,
+                                   const uint32_t* thresh, const int32_t* alias, int V, const float* table, int width,
+                                   const float* logq, int32_t* neg_out, float* rows_out, float* logq_out,
+                                   const int32_t* flat, const int64_t* starts, const int32_t* sess_host,
+                                   const int32_t* step_off_host, int B, int T, int32_t* sess_out, int32_t* step_off_out,
+                                   int32_t* ids, int32_t* tgt, int32_t* prev, void* stream);
 int seqrec_dropout_mask(uint64_t seed, uint64_t stream_id, const int64_t* rowkey, int64_t n_rows,
                         int width, int64_t ld, double rate, float* out, void* stream);
 

@@ -114,6 +114,7 @@ _SIGS = {
     "seqrec_sample_negatives": [U64, U64, I, P, P, I, P, P],
     "seqrec_sample_gather": [C.c_uint64, C.c_uint64, I, P, P, I, P, I, P, P, P, P, P],
     "seqrec_rnn_pack_u_sample": [I, I, P, P, C.c_uint64, C.c_uint64, I, P, P, I, P, I, P, P, P, P, P],
+    "seqrec_rnn_pack_u_sample_batch": [I, I, P, P, C.c_uint64, C.c_uint64, I, P, P, I, P, I, P, P, P, P, P, P, P, P, I, I, P, P, P, P, P, P],
     "seqrec_dropout_mask": [U64, U64, P, L, I, L, D, P, P],
     "seqrec_rank_count": [P, I, P, P, P, L, I, P, P, P],
     "seqrec_rank_count_thr": [P, I, P, P, P, P, L, I, P, P],
@@ -155,6 +156,7 @@ def rows_jobs(jobs):
 
 
 PACK_HOST_MAX = 960      # SEQREC_PACK_HOST_MAX (include/seqrec_hip.h)
+PACK_MERGED_MAX = 640    # SEQREC_PACK_MERGED_MAX: a batch that rides in the step's prologue launch
 
 
 class GemmDesc(C.Structure):
@@ -194,6 +196,8 @@ class CellPlan(C.Structure):
                 ("pack_u", C.c_int32), ("sample", C.c_int32), ("seed", U64), ("step", U64),
                 ("U", P), ("upack", P), ("thresh", P), ("alias", P), ("V", C.c_int32), ("reserved1_", C.c_int32), ("sample_table", P),
                 ("sample_logq", P), ("neg_out", P), ("Eneg_out", P), ("lq_neg_out", P),
+                ("batch", C.c_int32), ("reserved3_", C.c_int32), ("flat", P), ("starts", P), ("sess_host", P),
+                ("sess_out", P), ("step_off_out", P), ("ids_out", P), ("tgt_out", P), ("prev_out", P),
                 ("x_table", P), ("x_ld", L), ("x_index", P), ("W", P), ("bias", P),
                 ("XW", P), ("Hout", P), ("gates", P), ("aux", P),
                 ("Eneg", P), ("neg", P), ("lq_neg", P),

@@ -117,7 +117,7 @@ class SampledRNNModel:
         pending = []
         for i, sel in enumerate(sels):
             if ds is not None:
-                d = eng.upload_device(ds, sel)
+                d = eng.upload_device(ds, sel, defer=True)       # the gather rides in the training step's prologue launch
             elif self.dist is not None:
                 # row-sharded engine: route a window of batches at once (two collectives and one host sync per window)
                 if not pending:

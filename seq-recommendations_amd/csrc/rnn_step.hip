@@ -148,8 +148,39 @@ __device__ __forceinline__ void sample_rows(const SampleJob& sj) {
         }
     }
 }
+// ... and so does the NEXT thing a training step needs besides the weights: its batch.  Grid row `bj.row` gathers ids / targets / prev
+// links of the ragged batch from the HBM-resident data set (seqrec_pack_batch_host: step offsets and session indices in the kernel
+// arguments) -- the step's three openers (batch, U re-pack, negatives) in ONE launch (round 4: 6.6 + 8.9 us were two).
+constexpr int PACK_MERGED_MAX = 640;           // B + T + 1 ints of a batch that rides here (the kernel-argument segment is 4 KB)
+struct BatchJob { const int* flat; const long* starts; int B, T, row, gbx; int* sess_out; int* step_off_out; int* ids; int* tgt; int* prev;
+                  int v[PACK_MERGED_MAX]; };
+__device__ __forceinline__ void batch_rows(const BatchJob& h) {
+    if ((int)blockIdx.x >= h.T * h.gbx) return;
+    const int t = blockIdx.x / h.gbx;
+    const int r = (blockIdx.x - t * h.gbx) * blockDim.x + threadIdx.x;
+    if (t == 0) {
+        if (r < h.B) h.sess_out[r] = h.v[h.T + 1 + r];
+        if (r <= h.T) h.step_off_out[r] = h.v[r];
+    }
+    const int p0 = h.v[t];
+    if (r >= h.v[t + 1] - p0) return;
+    const long base = h.starts[h.v[h.T + 1 + r]] + t;
+    const int p = p0 + r;
+    h.ids[p] = h.flat[base];
+    h.tgt[p] = h.flat[base + 1];
+    h.prev[p] = t > 0 ? h.v[t - 1] + r : -1;
+}
+__device__ __forceinline__ void pack_rows(const PackStepArgs& pa);
+__global__ void pack_step_batch_kernel(PackStepArgs pa, SampleJob sj, BatchJob bj) {
+    if ((int)blockIdx.y == bj.row) { batch_rows(bj); return; }
+    if ((int)blockIdx.y == sj.njobs) { sample_rows(sj); return; }
+    pack_rows(pa);
+}
 __global__ void pack_step_kernel(PackStepArgs pa, SampleJob sj) {
     if ((int)blockIdx.y == sj.njobs) { sample_rows(sj); return; }      // njobs < 0: no sampling row in this launch
+    pack_rows(pa);
+}
+__device__ __forceinline__ void pack_rows(const PackStepArgs& pa) {
     const PackStepJob jb = pa.job[blockIdx.y];
     const float* __restrict__ U = pa.U;
     float* __restrict__ out = pa.out + jb.off;
@@ -868,7 +899,7 @@ int issue_eager(Plan& pl, hipStream_t st) {
 }  // namespace
 
 // layouts, in this order inside upack: fwd [z|r] (H x 2H), fwd h (H x H), bwd U_h^T (H x H), bwd [U_z U_r]^T (2H x H)
-static int pack_u_impl(int cell, int H, const float* U, float* upack, const SampleJob* sample, hipStream_t st) {
+static int pack_u_impl(int cell, int H, const float* U, float* upack, const SampleJob* sample, hipStream_t st, BatchJob* batch = nullptr) {
     if (cell < 0 || cell > 2) return SEQREC_E_UNSUPPORTED;
     if (!(H == 64 || H == 128 || H == 256 || H == 512)) return SEQREC_E_SHAPE;
     if (!U || !upack) return SEQREC_E_ARG;
@@ -901,7 +932,14 @@ static int pack_u_impl(int cell, int H, const float* U, float* upack, const Samp
         nj = 5;
     }
     if (sample) sj.njobs = nj;
-    hipLaunchKernelGGL(pack_step_kernel, dim3(gx, nj + extra), dim3(256), 0, st, pa, sj);
+    if (batch) {
+        batch->row = nj + (int)extra;
+        batch->gbx = (std::max(batch->B, batch->T + 1) + 255) / 256;
+        const unsigned gxb = std::max(gx, (unsigned)(batch->T * batch->gbx));
+        hipLaunchKernelGGL(pack_step_batch_kernel, dim3(gxb, nj + extra + 1), dim3(256), 0, st, pa, sj, *batch);
+    } else {
+        hipLaunchKernelGGL(pack_step_kernel, dim3(gx, nj + extra), dim3(256), 0, st, pa, sj);
+    }
     SEQREC_LAUNCH_CHECK();
     return 0;
 }
@@ -920,6 +958,30 @@ extern "C" int seqrec_rnn_pack_u_sample(int cell, int H, const float* U, float* 
     sj.key = key64(seed, 1); sj.step = step; sj.K = K; sj.V = V; sj.width = width;
     sj.thresh = thresh; sj.alias = alias; sj.table = table; sj.logq = logq; sj.neg = neg_out; sj.rows = rows_out; sj.lq = logq_out;
     return pack_u_impl(cell, H, U, upack, &sj, as_stream(stream));
+}
+
+// ... + seqrec_pack_batch_host in the same launch: the three openers of a training step on a batch drawn from an HBM-resident data set
+extern "C" int seqrec_rnn_pack_u_sample_batch(int cell, int H, const float* U, float* upack, uint64_t seed, uint64_t step, int K,
+                                              const uint32_t* thresh, const int32_t* alias, int V, const float* table, int width,
+                                              const float* logq, int32_t* neg_out, float* rows_out, float* logq_out,
+                                              const int32_t* flat, const int64_t* starts, const int32_t* sess_host,
+                                              const int32_t* step_off_host, int B, int T, int32_t* sess_out, int32_t* step_off_out,
+                                              int32_t* ids, int32_t* tgt, int32_t* prev, void* stream) {
+    if (K <= 0 || V <= 0 || width <= 0 || B <= 0 || T <= 0) return SEQREC_E_ARG;
+    if (!thresh || !alias || !table || !neg_out || !rows_out || (logq_out && !logq)) return SEQREC_E_ARG;
+    if ((width & 3) == 0 && ((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(rows_out)) & 15)) return SEQREC_E_ARG;
+    if ((long)B + T + 1 > PACK_MERGED_MAX) return SEQREC_E_SHAPE;
+    if (!flat || !starts || !sess_host || !step_off_host || !sess_out || !step_off_out || !ids || !tgt || !prev) return SEQREC_E_ARG;
+    if (step_off_host[T] < 0 || step_off_host[0] != 0) return SEQREC_E_ARG;
+    SampleJob sj = {};
+    sj.key = key64(seed, 1); sj.step = step; sj.K = K; sj.V = V; sj.width = width;
+    sj.thresh = thresh; sj.alias = alias; sj.table = table; sj.logq = logq; sj.neg = neg_out; sj.rows = rows_out; sj.lq = logq_out;
+    BatchJob bj = {};
+    bj.flat = flat; bj.starts = reinterpret_cast<const long*>(starts); bj.B = B; bj.T = T;
+    bj.sess_out = sess_out; bj.step_off_out = step_off_out; bj.ids = ids; bj.tgt = tgt; bj.prev = prev;
+    for (int i = 0; i <= T; ++i) bj.v[i] = step_off_host[i];
+    for (int i = 0; i < B; ++i) bj.v[T + 1 + i] = sess_host[i];
+    return pack_u_impl(cell, H, U, upack, &sj, as_stream(stream), &bj);
 }
 
 // ---- launch-graph cache (hidden state of the library, part 2 of 2): per (stream, launch SEQUENCE -- the ordered kernel

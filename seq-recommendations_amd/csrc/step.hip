@@ -14,11 +14,17 @@ extern "C" int64_t seqrec_cell_plan_bytes(void) { return (int64_t)sizeof(seqrec_
 
 extern "C" int seqrec_train_cell(seqrec_cell_plan* p, void* st) {
     if (!p || p->n <= 0 || p->Hp <= 0 || p->G <= 0 || p->K <= 0 || p->Dp <= 0 || !p->step_off_host) return SEQREC_E_ARG;
+    if (p->batch && !(p->pack_u && p->sample && (p->stages & 1))) return SEQREC_E_ARG;
     const int64_t n = p->n;
     const int Hp = p->Hp, GHp = p->G * p->Hp, K = p->K, Dp = p->Dp;
     if (p->stages & 1) {
         if (p->pack_u) {
-            if (p->sample)
+            if (p->sample && p->batch)
+                STEP_TRY(seqrec_rnn_pack_u_sample_batch(p->cell, Hp, p->U, p->upack, p->seed, p->step, K, p->thresh, p->alias, p->V,
+                                                        p->sample_table, Hp, p->sample_logq, p->neg_out, p->Eneg_out, p->lq_neg_out,
+                                                        p->flat, p->starts, p->sess_host, p->step_off_host, p->B, p->T, p->sess_out,
+                                                        p->step_off_out, p->ids_out, p->tgt_out, p->prev_out, st));
+            else if (p->sample)
                 STEP_TRY(seqrec_rnn_pack_u_sample(p->cell, Hp, p->U, p->upack, p->seed, p->step, K, p->thresh, p->alias, p->V,
                                                   p->sample_table, Hp, p->sample_logq, p->neg_out, p->Eneg_out, p->lq_neg_out, st));
             else

@@ -714,11 +714,24 @@ class Engine:
         return {"flat": torch.from_numpy(flat).to(self.dev), "starts": torch.from_numpy(starts).to(self.dev),
                 "starts_host": starts}
 
-    def upload_device(self, ds, sel, history=False, freq=False):
+    def _materialise(self, d):
+        """A batch built with upload_device(defer=True) whose gather has not been launched yet: launch it now (seqrec_pack_batch_host).
+        The training step's one-call form launches it INSIDE its prologue instead (seqrec_rnn_pack_u_sample_batch)."""
+        pend = d.pop("_pending", None)
+        if pend is not None:
+            ds, sess, so32 = pend
+            call("seqrec_pack_batch_host", ptr(ds["flat"]), ptr(ds["starts"]), sess.ctypes.data, so32.ctypes.data, d["B"], d["T"],
+                 ptr(d["sess"]), ptr(d["step_off"]), ptr(d["ids"]), ptr(d["tgt"]), ptr(d["prev"]), self._stream())
+        return d
+
+    def upload_device(self, ds, sel, history=False, freq=False, defer=False):
         """Device-side batcher: like upload(batching.pack_flat(flat, starts, sel)) but only
         the batch's session indices and step offsets (a few KB) cross PCIe; ids / targets / prev links
         -- and, with history=True, the x_to_y history features of datasets.build_xs -- are produced
-        by seqrec_pack_batch / seqrec_history_features from the HBM-resident dataset."""
+        by seqrec_pack_batch / seqrec_history_features from the HBM-resident dataset.
+        defer=True (training loops): the gather launch is left to the consumer -- the one-call training step issues it inside its
+        prologue launch together with the U re-pack and the negatives (one launch instead of two); every other consumer calls
+        _materialise() first, so the batch reads the same either way."""
         from .batching import index_flat
         c = self.cfg
         rb = index_flat(ds["starts_host"], sel, lean=True)
@@ -732,8 +745,11 @@ class Engine:
             blob = torch.empty(T + 1 + B, dtype=torch.int32, device=self.dev)
             d = {"n": n, "T": T, "B": B, "rb": rb, "blob": blob, "step_off": blob[: T + 1], "sess": blob[T + 1:],
                  "ids": out[:n], "tgt": out[n:2 * n], "prev": out[2 * n:3 * n], "_out": out}
-            call("seqrec_pack_batch_host", ptr(ds["flat"]), ptr(ds["starts"]), sess.ctypes.data, so32.ctypes.data, B, T,
-                 ptr(d["sess"]), ptr(d["step_off"]), ptr(d["ids"]), ptr(d["tgt"]), ptr(d["prev"]), st)
+            if defer and not history and n > 0 and B + T + 1 <= _lib.PACK_MERGED_MAX:
+                d["_pending"] = (ds, sess, so32)
+            else:
+                call("seqrec_pack_batch_host", ptr(ds["flat"]), ptr(ds["starts"]), sess.ctypes.data, so32.ctypes.data, B, T,
+                     ptr(d["sess"]), ptr(d["step_off"]), ptr(d["ids"]), ptr(d["tgt"]), ptr(d["prev"]), st)
         else:
             blob = self.pinned.put(np.concatenate([so32, sess]))
             d = {"n": n, "T": T, "B": B, "rb": rb, "blob": blob, "step_off": blob[: T + 1], "sess": blob[T + 1:],
@@ -874,6 +890,8 @@ class Engine:
         mode the gradient w.r.t. the logits is left in place of the logits."""
         c, P = self.cfg, self.P
         st = self._stream()
+        if "_pending" in d:
+            self._materialise(d)
         n, T, B = d["n"], d["T"], d["B"]
         Hp, GHp = self.Hp, self.GHp
         r = {}
@@ -1363,10 +1381,21 @@ class Engine:
         so = d["rb"].step_off
         pl.step_off_host = so.ctypes.data
         pl.step = int(step)
+        pend = d.pop("_pending", None)
+        pl.batch = 0
         if self.upack_dirty:
             pl.pack_u, pl.sample = 1, 1
             self.upack_dirty = False
+            if pend is not None:                # the batch's own gather rides in the prologue launch: three openers, one launch
+                ds_, sess_, _ = pend
+                pl.batch, pl.flat, pl.starts, pl.sess_host = 1, ptr(ds_["flat"]), ptr(ds_["starts"]), sess_.ctypes.data
+                pl.sess_out, pl.step_off_out = ptr(d["sess"]), ptr(d["step_off"])
+                pl.ids_out, pl.tgt_out, pl.prev_out = ptr(d["ids"]), ptr(d["tgt"]), ptr(d["prev"])
+                self._plan_keep_batch = (ds_, sess_)
         else:                                   # U frozen since the last pack: the negatives on their own
+            if pend is not None:
+                d["_pending"] = pend
+                self._materialise(d)
             pl.pack_u = pl.sample = 0
             call("seqrec_sample_gather", int(c.seed), int(step), K, ptr(th), ptr(al), c.V_out, ptr(Et), Hp, ptr(lq if c.logq else None),
                  ptr(neg), ptr(Eneg), ptr(lq_neg), st)

@@ -641,3 +641,46 @@ def test_dh_and_deneg_in_one_launch_equal_the_two_launches():
         assert outs[0][1] == outs[1][1] and torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2]), (n, K, H)
         want_dh = (ln.double() @ En.double() + sc.double()[:, None] * Et[ti.long()].double()).float()
         assert float((outs[0][0] - want_dh).abs().max().item()) <= 2e-3 * float(want_dh.abs().max().item())
+
+
+def test_deferred_batch_gather_rides_in_the_prologue_launch():
+    """upload_device(defer=True) leaves the batch's gather (ids / targets / prev links from the HBM-resident data set) to its consumer:
+    the one-call training step launches it INSIDE its prologue launch together with the U re-pack and the negatives
+    (seqrec_rnn_pack_u_sample_batch: three openers, one launch), every other consumer materialises it first.  Same batch arrays, same
+    loss to the bit as the immediate gather; evaluation of a deferred batch works; a step with a frozen U (no re-pack to ride in) too."""
+    import importlib
+    import torch
+    E = importlib.import_module("seq-recommendations_amd.engine")
+    rng = np.random.default_rng(17)
+    case = dict(cell="gru", act="relu", H=128, V=4000, inp="embed", out="sampled", D=128, K=256, logq=True)
+    ecfg, ocfg = make_cfg(**case)
+    params = init_np_params(rng, ocfg, case["V"], case["H"], case["D"])
+    sessions = make_sessions(rng, 300, case["V"], 2, 14)
+    flat = np.concatenate([np.asarray(s, np.int32) for s in sessions])
+    starts = np.concatenate([[0], np.cumsum([len(s) for s in sessions])]).astype(np.int64)
+    res = []
+    for defer in (True, False):
+        p = Pair(ecfg, ocfg, params)
+        eng = p.eng
+        ds = eng.put_dataset(flat, starts)
+        losses = []
+        for step in range(3):
+            sel = np.arange(step * 64, step * 64 + 64)
+            d = eng.upload_device(ds, sel, defer=defer)
+            assert ("_pending" in d) == defer
+            losses.append(float(eng.train_step(d, lr=0.02, step=step).item()))
+            assert "_pending" not in d
+            if step == 0:
+                first = {k: d[k].clone() for k in ("ids", "tgt", "prev", "step_off", "sess")}
+        # evaluation of a deferred batch; then a training step with U frozen (the prologue has no re-pack: the batch is gathered first)
+        d = eng.upload_device(ds, np.arange(200, 264), defer=defer)
+        ev = float(eng.eval_loss(d, step=7).item())
+        eng.trainable["U"] = False
+        d = eng.upload_device(ds, np.arange(100, 164), defer=defer)
+        lf = float(eng.train_step(d, lr=0.02, step=5).item())
+        eng.check_status()
+        res.append((losses, first, ev, lf))
+    assert res[0][0][0] == res[1][0][0]                          # (later steps: the scatter's float atomics round differently run to run)
+    assert np.allclose(res[0][0], res[1][0], rtol=1e-5) and abs(res[0][2] - res[1][2]) <= 1e-5 * abs(res[1][2]) and abs(res[0][3] - res[1][3]) <= 1e-5 * abs(res[1][3])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
