@@ -330,7 +330,7 @@ class Engine:
         self.drop_seed = cfg.seed       # RNG stream of the dropout masks (distributed.ShardedEngine: one per rank)
         # the cell of the common training step in ONE C-ABI call (seqrec_train_cell); SEQREC_NATIVE_CELL=0: call by call
         self.native_cell = _os.environ.get("SEQREC_NATIVE_CELL", "1") != "0"
-        self._plan, self._plan_gen, self._plan_keep = None, None, None
+        self._plan, self._plan_keep, self._plan_keep_batch = None, None, None
         # batches of more tokens than this materialise E[ids] and h_{t-1} once instead of gathering them inside three GEMMs
         self.fuse_gather_max = int(_os.environ.get("SEQREC_FUSE_GATHER_MAX", "8192"))
 
