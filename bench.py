@@ -679,23 +679,18 @@ def main(argv=None):
         resident = [eng.upload(Bt.pack_flat(flat, starts, stream.sel(i))) for i in range(nb)]
 
     tok_seen = []
-    window = {}         # sharded: the routing of the next WINDOW batches is planned together (2 collectives, 1 host sync)
-    WINDOW = 32
-    route_host = {"pack_s": 0.0, "plan_s": 0.0, "windows": 0}      # host time of the routing (inside the timed region when sharded)
+    WINDOW = 32         # sharded: the routing of the next WINDOW batches is planned together (2 collectives, no host wait)
+    planner = None
+    if sharded and not a.resident:
+        planner = Dm.WindowPlanner(eng, lambda j: Bt.pack_flat(flat, starts, stream.sel(j)), WINDOW)
 
     def next_batch(i):
         if resident:
             d = resident[i % len(resident)]
         elif sharded:
-            # the next WINDOW batches are routed while the GPU still has half a window of steps queued
-            if i not in window or (i + WINDOW // 2) not in window:
-                lo = max(window) + 1 if window else i
-                t0 = time.perf_counter()
-                rbs = [Bt.pack_flat(flat, starts, stream.sel(j)) for j in range(lo, lo + WINDOW)]
-                t1 = time.perf_counter()
-                window.update(zip(range(lo, lo + WINDOW), eng.prepare(rbs)))
-                route_host["pack_s"] += t1 - t0; route_host["plan_s"] += time.perf_counter() - t1; route_host["windows"] += 1
-            d = window.pop(i)
+            # the next WINDOW batches are routed while the GPU still has half a window of steps queued: the count exchange is begun
+            # there and ended a quarter window later (distributed.WindowPlanner) -- the loop never waits for the planner
+            d = planner.get(i)
         else:
             d = eng.upload_device(ds, stream.sel(i), defer=True)       # as catalogue.SampledRNNModel's fit loop does
         return d
@@ -985,10 +980,10 @@ def main(argv=None):
                        "t_mean": round(t_mean, 1), "t_max": t_max, "t_mean_epoch": t_mean_epoch, "settle_steps": a.settle, "batches": mode, "scan": scan_issue, "row_gradient_merge": a.merge,
                        "train_sessions_per_gpu": n_train, "test_sessions": n_test,
                        "routing_window": WINDOW if (sharded and not resident) else None,
-                       "routing_host_ms_per_window": ({"pack": round(1e3 * route_host["pack_s"] / max(route_host["windows"], 1), 2),
-                                                       "plan": round(1e3 * route_host["plan_s"] / max(route_host["windows"], 1), 2),
-                                                       "sync_wait": round(1e3 * getattr(eng.ex, "sync_wait_s", 0.0) / max(route_host["windows"], 1), 2),
-                                                       "windows": route_host["windows"]} if (sharded and not resident) else None),
+                       "routing_host_ms_per_window": ({"pack": round(1e3 * planner.pack_s / max(planner.windows, 1), 2),
+                                                       "plan": round(1e3 * planner.plan_s / max(planner.windows, 1), 2),
+                                                       "sync_wait": round(1e3 * getattr(eng.ex, "sync_wait_s", 0.0) / max(planner.windows, 1), 2),
+                                                       "windows": planner.windows} if planner is not None else None),
                        "parallelism": ("dp%d+row-sharded-tables" % world) if sharded else "single"},
             "tokens_per_s": round(tokens_per_s, 1), "final_loss": round(last_loss, 5), "recall_at_20": recall,
             "recall_after_steps": step if recall is not None else None,

@@ -114,15 +114,16 @@ class SampledRNNModel:
         tot = torch.zeros(1, device=eng.dev)
         cnt = 0
         sels = [order[s:s + batch_size] for s in range(0, len(order), batch_size)]
-        pending = []
+        planner = None
+        if ds is None and self.dist is not None:
+            # row-sharded engine: a window of batches is routed at once, its count exchange begun half a window ahead (no host wait)
+            from .distributed import WindowPlanner
+            planner = WindowPlanner(eng, lambda j: batching.pack_flat(flat, starts, sels[j]) if j < len(sels) else None, 32)
         for i, sel in enumerate(sels):
             if ds is not None:
                 d = eng.upload_device(ds, sel, defer=True)       # the gather rides in the training step's prologue launch
-            elif self.dist is not None:
-                # row-sharded engine: route a window of batches at once (two collectives and one host sync per window)
-                if not pending:
-                    pending = eng.prepare([batching.pack_flat(flat, starts, x) for x in sels[i:i + 32]])
-                d = pending.pop(0)
+            elif planner is not None:
+                d = planner.get(i)
             else:
                 d = eng.upload(batching.pack_flat(flat, starts, sel))
             if d["n"] == 0:

@@ -294,6 +294,9 @@ class RowExchange:
         return plans
 
     def plan_unified(self, rbs, V_in, tied, Kr, nid, w, lq_host=None, group="default", put_fill=None):
+        return self.plan_unified_end(self.plan_unified_begin(rbs, V_in, tied, Kr, nid, w, lq_host=lq_host, group=group, put_fill=put_fill))
+
+    def plan_unified_begin(self, rbs, V_in, tied, Kr, nid, w, lq_host=None, group="default", put_fill=None):
         """The routing of M batches of the UNIFIED step (requests = [input rows ; target rows], `Kr + nid` owner-chosen rows per
         peer pair), planned by the native host routines of csrc/route.hip: same two collectives and one host sync as
         plan_seg_many, one pass per batch instead of ~60 numpy operations (0.7 ms of host time per batch became the
@@ -332,18 +335,40 @@ class RowExchange:
         sc_dev = up(sc_ext)
         rc_dev = torch.empty_like(sc_dev)
         dist.all_to_all_single(rc_dev, sc_dev, group=grp)
-        import time as _time
-        _t0 = _time.perf_counter()
+        # ---- first half ends here: the count exchange is queued, its result on the way to page-locked memory.  Nothing has waited.
+        hv = ev = None
         if dev.type == "cuda":
             hb = getattr(self, "_rc_host", None)
             if hb is None or hb.numel() < rc_dev.numel():
                 hb = self._rc_host = torch.empty(max(rc_dev.numel(), 4096), dtype=torch.int64).pin_memory()
-            hv = hb[: rc_dev.numel()].view(rc_dev.shape)
+            self._rc_slot = (getattr(self, "_rc_slot", 0) + 1) % 2       # two windows may be between begin and end
+            half = hb.numel() // 2
+            if rc_dev.numel() > half:
+                hb = self._rc_host = torch.empty(4 * rc_dev.numel(), dtype=torch.int64).pin_memory()
+                half = hb.numel() // 2
+            hv = hb[self._rc_slot * half: self._rc_slot * half + rc_dev.numel()].view(rc_dev.shape)
             hv.copy_(rc_dev, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
-            ev.synchronize()                                                             # (the ONE host sync)
-            rc_ext = hv.numpy().copy()
+        return dict(rbs=rbs, V_in=V_in, tied=tied, Kr=Kr, nid=nid, w=w, lq_host=lq_host, grp=grp, put_fill=put_fill, up=up, ids=ids, tgt=tgt, SC=SC,
+                    rc_dev=rc_dev, hv=hv, ev=ev, M=M, extra=extra)
+
+    def plan_unified_end(self, hd):
+        """Second half of plan_unified: wait for the count exchange queued by plan_unified_begin (the ONE host sync -- none at all when a few
+        training steps were enqueued in between), exchange the requested rows, write and upload the window's index blocks."""
+        import ctypes
+        import time as _time
+        R, dist, dev = self.R, self.dist, self.dev
+        lib = _lib.load()
+        rbs, V_in, tied, Kr, nid, w, lq_host, grp, put_fill, up = (hd[k] for k in ("rbs", "V_in", "tied", "Kr", "nid", "w", "lq_host", "grp", "put_fill", "up"))
+        ids, tgt, SC, rc_dev, M, extra = hd["ids"], hd["tgt"], hd["SC"], hd["rc_dev"], hd["M"], hd["extra"]
+        i32p, i64p = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)
+        P32 = lambda a: a.ctypes.data_as(i32p)
+        P64 = lambda a: a.ctypes.data_as(i64p)
+        _t0 = _time.perf_counter()
+        if hd["ev"] is not None:
+            hd["ev"].synchronize()                                                       # (the ONE host sync)
+            rc_ext = hd["hv"].numpy().copy()
         else:
             rc_ext = rc_dev.cpu().numpy()
         self.sync_wait_s = getattr(self, "sync_wait_s", 0.0) + (_time.perf_counter() - _t0)   # how long the host stood here (bench.py reports it)
@@ -659,10 +684,35 @@ class ShardedEngine(Engine):
                 d["plan_in"] = self.ex.plan(d["ids"])
                 d["plan_tgt"] = self.ex.plan(d["tgt"])
             return ds
-        # ---- unified routing: requests = [input rows ; target rows], extras = Kr negatives + id rows
+        return self.prepare_end(self.prepare_begin(rbs))
+
+    def prepare_begin(self, rbs):
+        """First half of prepare() for the unified tables: the per-peer request counts of the window's batches are exchanged (queued on
+        the planning stream, on their way to page-locked memory) and NOTHING waits.  Collective; every rank calls prepare_begin /
+        prepare_end at the same points of its loop.  prepare_end a few training steps later finds the counts already there: the loop
+        never stands still for the planner (round 4: up to 2 ms per window on a box whose DMA engine is slow to serve the copy)."""
+        if not self.unified:
+            return {"rbs": rbs, "split": True}
+        for rb in rbs:
+            if rb.n_tok == 0:
+                raise ValueError("ShardedEngine: every rank needs at least one transition per step (collectives are unconditional)")
+        c, R = self.cfg, self.R
+        w, Kr = self.Hp, c.K // R
+        nid = -(-Kr // w)                                            # rows that carry the negatives' ids
+        lq_host = self.logq_global_host if (c.logq and self.logq_global is not None) else None
+        with torch.cuda.stream(self.plan_stream):
+            hd = self.ex.plan_unified_begin(rbs, self.gcfg.V_in, c.tied, Kr, nid, w, lq_host=lq_host, group=self.plan_group,
+                                            put_fill=self.pinned.put_fill)
+        return {"rbs": rbs, "hd": hd}
+
+    def prepare_end(self, h):
+        """Second half of prepare(): -> the device batches of the window begun with prepare_begin."""
+        rbs = h["rbs"]
+        if h.get("split"):
+            return self.prepare(rbs)
         main = torch.cuda.current_stream(self.dev)
         with torch.cuda.stream(self.plan_stream):
-            ds = self._prepare_unified(rbs)
+            ds = self._prepare_unified(rbs, h["hd"])
             ready = torch.cuda.Event()
             ready.record(self.plan_stream)
         seen = set()
@@ -675,15 +725,10 @@ class ShardedEngine(Engine):
                     t.record_stream(main)        # allocated on the planning stream, consumed on the training stream
         return ds
 
-    def _prepare_unified(self, rbs):
-        """Routing of a window of batches by the native planner (RowExchange.plan_unified, csrc/route.hip): two collectives, one
-        host sync, and per batch ONE int32 blob written straight into the engine's page-locked upload ring."""
-        c, R = self.cfg, self.R
-        w, Kr = self.Hp, c.K // R
-        nid = -(-Kr // w)                                            # rows that carry the negatives' ids
-        lq_host = self.logq_global_host if (c.logq and self.logq_global is not None) else None
-        planned = self.ex.plan_unified(rbs, self.gcfg.V_in, c.tied, Kr, nid, w, lq_host=lq_host, group=self.plan_group,
-                                       put_fill=self.pinned.put_fill)
+    def _prepare_unified(self, rbs, hd):
+        """Routing of a window of batches by the native planner (RowExchange.plan_unified_begin / _end, csrc/route.hip): two
+        collectives, one host sync, and the window's int32 index blocks written straight into the engine's page-locked upload ring."""
+        planned = self.ex.plan_unified_end(hd)
         ds = []
         for rb, (blob, parts, plan) in zip(rbs, planned):
             d = {"n": rb.n_tok, "T": rb.T, "B": rb.B, "rb": rb, "blob": blob, "plan": plan, "n_global": plan.n_global}
@@ -1339,3 +1384,58 @@ class ShardedEngine(Engine):
             call("seqrec_rows_adagrad", ptr(P[tab]), ptr(self.A[tab]), ptr(Gt[tab]), ptr(self.slot[tab]), ptr(rows), m, w, b,
                  lr, eps, ptr(self.scale), st)
         return self.loss_sum * (self.R / d["n_total"])
+
+
+class WindowPlanner:
+    """Feeds a training loop over a row-sharded engine with routed batches, a WINDOW at a time, without ever making it wait for the
+    planner: the next window's count exchange is BEGUN when half of the current one is left (ShardedEngine.prepare_begin: queued,
+    nothing waits) and ENDED a quarter window later (prepare_end: the counts are there by then).  make_rb(i) -> the host RaggedBatch of
+    step i (or None past the end); get(i) must be called with i = 0, 1, 2, ... on every rank alike (the planner's collectives are
+    issued at the same loop positions everywhere).  pack_s / plan_s: host seconds spent building batches / planning."""
+
+    def __init__(self, eng, make_rb, window=32):
+        self.eng, self.make_rb, self.W = eng, make_rb, int(window)
+        self.ready = {}            # step -> device batch
+        self.next_lo = 0           # first step not yet planned or begun
+        self.begun = None          # (lo, hi, handle) of the window whose counts are in flight
+        self.pack_s = self.plan_s = 0.0
+        self.windows = 0
+        self.done = False
+
+    def _begin(self):
+        import time
+        t0 = time.perf_counter()
+        rbs = []
+        for j in range(self.next_lo, self.next_lo + self.W):
+            rb = self.make_rb(j)
+            if rb is None:
+                self.done = True
+                break
+            rbs.append(rb)
+        t1 = time.perf_counter()
+        self.pack_s += t1 - t0
+        if rbs:
+            self.begun = (self.next_lo, self.next_lo + len(rbs), self.eng.prepare_begin(rbs))
+            self.next_lo += len(rbs)
+        self.plan_s += time.perf_counter() - t1
+
+    def _end(self):
+        import time
+        t0 = time.perf_counter()
+        lo, hi, h = self.begun
+        self.ready.update(zip(range(lo, hi), self.eng.prepare_end(h)))
+        self.begun = None
+        self.windows += 1
+        self.plan_s += time.perf_counter() - t0
+
+    def get(self, i):
+        if i not in self.ready:                                   # start of the loop (or a consumer running ahead): plan now, blocking
+            if self.begun is None and not self.done:
+                self._begin()
+            if self.begun is not None:
+                self._end()
+        elif self.begun is None and not self.done and (i + self.W // 2) >= self.next_lo:
+            self._begin()                                          # half a window left: queue the next window's count exchange
+        elif self.begun is not None and (i + self.W // 4) >= self.begun[0]:
+            self._end()                                            # a quarter left: its counts arrived long ago
+        return self.ready.pop(i)
