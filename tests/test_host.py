@@ -228,3 +228,39 @@ def test_device_status_word_decodes_to_a_raise_message():
     m = E.status_messages(0, 3)
     assert len(m) == 1 and "3 in-kernel wait" in m[0] and "NaN-poisoned" in m[0]
     assert "unknown status bits" in E.status_messages(64, 0)[0]
+
+
+def test_window_planner_begins_half_a_window_ahead_and_never_skips_a_batch():
+    """distributed.WindowPlanner (host logic, no GPU): batches come back in step order, every window is begun (count exchange
+    queued) half a window before it is needed and ended a quarter window before, a finite stream ends cleanly, and every rank
+    would issue the same begin / end sequence (it depends on the step index alone)."""
+    import importlib
+    D = importlib.import_module("seq-recommendations_amd.distributed")
+
+    class FakeEngine:
+        def __init__(self):
+            self.log = []
+
+        def prepare_begin(self, rbs):
+            self.log.append(("begin", rbs[0], rbs[-1], self.now))
+            return list(rbs)
+
+        def prepare_end(self, h):
+            self.log.append(("end", h[0], h[-1], self.now))
+            return [("batch", x) for x in h]
+
+    eng = FakeEngine()
+    n_total = 150
+    pl = D.WindowPlanner(eng, lambda j: j if j < n_total else None, window=32)
+    got = []
+    for i in range(n_total):
+        eng.now = i
+        got.append(pl.get(i))
+    assert got == [("batch", i) for i in range(n_total)]
+    begins = [(a, b, at) for k, a, b, at in eng.log if k == "begin"]
+    ends = [(a, b, at) for k, a, b, at in eng.log if k == "end"]
+    assert [b[:2] for b in begins] == [(0, 31), (32, 63), (64, 95), (96, 127), (128, 149)] == [e[:2] for e in ends]
+    assert begins[0][2] == 0 and ends[0][2] == 0                       # the first window: planned on the spot
+    for (lo, _, at_b), (_, _, at_e) in zip(begins[1:], ends[1:]):
+        assert at_b == lo - 16 and at_e == lo - 8, (lo, at_b, at_e)    # half a window ahead / a quarter ahead
+    assert pl.windows == 5 and pl.done
