@@ -235,8 +235,8 @@ int seqrec_rnn_bwd(int cell, int act, int H, int H_real, int T, int B, const int
  *      the recurrent kernel in registers and exchange h (LSTM, SimpleRNN: one exchange per step; GRU: two) inside the
  *      kernel.  Taken when all workgroups of a launch can be resident (occupancy query; larger batches go in slices).
  *      STEP-WISE form (rnn_step.hip): one small whole-chip launch per recurrent GEMM (GRU: 2 per step; LSTM/SimpleRNN:
- *      1 forward, pointwise + GEMM backward) -- for T > 159, SEQREC_SCAN_CLUSTER=0, the LSTM forward with rmask at
- *      H = 512, and as the form the cluster kernels are tested against.  Same buffers; Hout / gates / aux agree BIT FOR
+ *      1 forward, pointwise + GEMM backward) -- for T > 159, the activations beyond relu / tanh / linear, after
+ *      seqrec_debug_scan_cluster(0), and as the form the cluster kernels are tested against.  Same buffers; Hout / gates / aux agree BIT FOR
  *      BIT between the forms, dPre to the last bits.
  *      upack: seqrec_rnn_upack_floats() floats written by seqrec_rnn_pack_u_stepwise.
  *      bwd workspace: 2 * N_tok * H floats (step-wise form only).
