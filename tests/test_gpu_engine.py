@@ -360,7 +360,7 @@ def test_bench_single_gpu_line_carries_cpu_baseline_and_parity():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--config", "c2",
            "--train-sessions", "8192", "--test-sessions", "1024", "--settle", "4", "--profile-steps", "2", "--recall-steps", "60",
-           "--cpu-seconds", "3", "--parity-steps", "6", "--parity-sessions", "64"]
+           "--cpu-seconds", "3", "--parity-steps", "6", "--parity-sessions", "64", "--arbiter", "on", "--resync-steps", "4"]
     r = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="8"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -371,6 +371,11 @@ def test_bench_single_gpu_line_carries_cpu_baseline_and_parity():
     assert cb is not None and cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port"
     assert par is not None and par["steps"] >= 5 and len(par["loss_gpu"]) == len(par["loss_cpu"]) == par["steps"]
     assert par["max_rel_diff"] <= 1e-3 and par["ok"] is True, par
+    # the arbiter legs (forced on here; `auto` runs them only where the trajectories part): fp64 free run + re-synchronised steps
+    assert len(par["vs_fp64"]["loss_f64"]) == par["steps"] and max(par["vs_fp64"]["gpu_rel"]) <= 1e-3
+    rs = par["resync"]
+    assert par["resync_ok"] is True and rs["ok"] is True and rs["steps"] == 4 and max(rs["loss_rel_gpu"]) <= 1e-5, rs
+    assert set(rs["update"]) == {"E", "Eout", "W", "U", "b"} and par["trajectory_ok"] is True
     assert par["recall_at_20_sample"]["identical_ranks_frac"] > 0.97
     assert par["recall_at_20_sample_trained"]["identical_ranks_frac"] > 0.97
     assert "fresh batches" in out["config"]["batches"] and out["roofline"] is not None
