@@ -543,11 +543,28 @@ __global__ void __launch_bounds__(1024) opt_sqnorm_kernel(OptPlan pl, SlabPieces
         const int p = blockIdx.y - pl.nd;
         const float* __restrict__ ws = sp.ws[p];
         const long N = sp.N[p], total = sp.M[p] * N, ldc = sp.ldc[p];
-        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-            float v = 0.f;
-            for (int z = 0; z < sp.n_slabs; ++z) v += ws[(long)z * total + i];
-            sp.C[p][ldc == N ? i : (i / N) * ldc + i % N] = v;
-            s += v * v;
+        // four elements per thread and trip, their loads issued together slab by slab: a trip was (n_slabs dependent-looking loads ->
+        // store), five trips for a 256 x 768 gradient on this launch's 40 workgroups -- a chain of memory latencies, not bandwidth
+        // (each element still sums its slabs in slab order: the same bits as the grouped reduce launch)
+        const long stride = (long)gridDim.x * blockDim.x;
+        for (long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += 4 * stride) {
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int z = 0; z < sp.n_slabs; ++z) {
+                const float* __restrict__ w = ws + (long)z * total;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long i = i0 + u * stride;
+                    v[u] += i < total ? w[i] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long i = i0 + u * stride;
+                if (i < total) {
+                    sp.C[p][ldc == N ? i : (i / N) * ldc + i % N] = v[u];
+                    s += v[u] * v[u];
+                }
+            }
         }
     } else {
         constexpr int RPW = 4;
