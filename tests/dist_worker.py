@@ -150,6 +150,16 @@ def unified_plan_checks(D, ex, rank, R):
                 assert (plan.n_tot, plan.m_tot, plan.req_split, plan.own_split, plan.n_global) == \
                     (pr.n_tot, pr.m_tot, pr.req_split, pr.own_split, pr.n_global)
                 assert torch.equal(plan.got_pad, pr.got_pad)
+            # round 4: planning in two halves (ShardedEngine.prepare_begin / prepare_end) -- the count exchange queued, OTHER
+            # collectives of the training loop issued in between, the rest later: the same blobs and plans as the one-shot call
+            hd = ex.plan_unified_begin(rbs, V, tied, Kr, nid, w, lq_host=lq)
+            t = torch.ones(3)
+            dist.all_reduce(t)                                     # (a training step's collective between the two halves)
+            assert float(t[0]) == R
+            got2 = ex.plan_unified_end(hd)
+            for (b1, p1, q1), (b2, p2, q2) in zip(got, got2):
+                assert p1 == p2 and torch.equal(b1, b2) and torch.equal(q1.got_pad, q2.got_pad)
+                assert (q1.n_tot, q1.m_tot, q1.req_split, q1.own_split, q1.n_global) == (q2.n_tot, q2.m_tot, q2.req_split, q2.own_split, q2.n_global)
 
 
 def main():
